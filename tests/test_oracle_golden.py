@@ -177,19 +177,22 @@ def test_backbone_oracle(golden_backbone, tag, dtype, tol):
     for k in ("encoder.initial_block.bn.running_mean", "encoder.layers.9.bn2.running_var",
               "decoder.layers.3.bn.running_var"):
         assert relerr(stats[k], golden_backbone["bb_train_%s_%s" % (k, tag)]) < max(tol, 1e-6)
+    # fp32-vs-fp32 gradients of the early layers differ by ~2 % between two CPU evaluation orders
+    # (chaotic amplification through 39 train-mode BNs): that is the reference's own noise floor.
+    gtol = 50 * tol if tag == "f64" else 5e-2
     gkeys = list(golden_backbone["bb_grad_keys"])
     norms = golden_backbone["bb_grad_norms_" + tag]
     for k, n in zip(gkeys, norms):
         if n < 0:
             assert P[k].grad is None, k          # encoder.output_conv never gets a grad
         elif n > 1e-6 * norms.max():
-            assert abs(float(P[k].grad.double().norm()) - n) < 50 * tol * max(n, 1e-3 * norms.max()), k
+            assert abs(float(P[k].grad.double().norm()) - n) < gtol * max(n, 1e-3 * norms.max()), k
     for name in golden_backbone.files:
         if name.startswith("bb_grad_") and name.endswith(tag) and "norms" not in name:
             k = name[len("bb_grad_"):-len(tag) - 1]
             ref = golden_backbone[name]
             if np.abs(ref).max() > 1e-6 * norms.max():
-                assert relerr(P[k].grad, ref) < 50 * tol, k
+                assert relerr(P[k].grad, ref) < gtol, k
     P.update(stats)      # the golden eval pass ran after one train-mode step updated the running stats
     with torch.no_grad():
         _, dec = erfnet_oracle.erfnet_forward(x, P, training=False)
