@@ -1,0 +1,146 @@
+/*
+ * lanefit.h -- C ABI of liblanefit_hip.so, the MI355X (gfx950) implementation of the
+ * LaneDetection_End2End hot path: ERFNet backbone -> weighted-least-squares lane fit ->
+ * area / back-projection / segmentation losses, forward and backward.
+ *
+ * The reference has no FFI boundary of its own (it is pure PyTorch): its
+ * operator API is the nn.Module surface.  Each entry point below therefore names the
+ * reference nn.Module / function it replaces (file:line under /root/reference, with
+ * BEV/ = Birds_Eye_View_Loss/, BP/ = Backprojection_Loss/).  The Python host layer in
+ * lanedetection_end2end_amd/ binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - plain C types only: no torch / ATen / HIP types in any signature;
+ *   - return value: 0 = launches enqueued, <0 = argument error (lf_last_error() has text).
+ *     Numerical failure (singular normal matrix) is reported asynchronously through a
+ *     device-side `status` word the caller reads back (1 = singular, 2 = not positive
+ *     definite) so that the host can raise RuntimeError like torch.inverse does
+ *     (BEV/main.py:213-219 catches exactly that);
+ *   - activation tensors inside the backbone are NHWC fp32; the module boundary
+ *     (input image, logits, weight maps) is NCHW fp32 as in the reference.
+ */
+#ifndef LANEFIT_H
+#define LANEFIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_ABI_VERSION 1
+
+/* activation applied to the backbone logits: BEV/Networks/LSQ_layer.py:43-63 */
+enum { LF_ACT_SQUARE = 0, LF_ACT_ABS = 1, LF_ACT_RELU = 2, LF_ACT_SIGMOID = 3,
+       LF_ACT_SOFTPLUS = 4, LF_ACT_NONE = 5 };
+/* normal-equation solver: torch.inverse path (LSQ_layer.py:128-130) or GELS/Cholesky (BP/Networks/gels.py) */
+enum { LF_SOLVE_LU = 0, LF_SOLVE_CHOLESKY = 1 };
+/* Area_Loss weightings: BEV/Loss_crit.py:103-121 */
+enum { LF_WF_NONE = 0, LF_WF_LINEAR = 1, LF_WF_QUADRATIC = 2 };
+enum { LF_F32 = 0, LF_F64 = 1 };
+
+int lf_abi_version(void);
+const char* lf_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Fitting head.  Replaces Net.forward steps 2-4 (activation, row mask, grid, WLS):
+ * BEV/Networks/LSQ_layer.py:310-325 and Weighted_least_squares.forward :103-167
+ * (BP/Networks/LSQ_layer.py:85-154), plus the GELS option (BP/Networks/gels.py:10-15).
+ *
+ *   logits   (N,K,H,W) fp32 NCHW backbone output `output`
+ *   grid_xy  (H*W,2) fp32 (x', y') of every pixel; grid_batch_stride = 0 when shared by
+ *            all images (always the case in the reference), else floats between images
+ *   zero_rows  rows [0,zero_rows) of every map are masked to 0 (LSQ_layer.py:257-258,316)
+ *   order 0..3, reg = --reg_ls, y_offset = 1 (BEV :109) or 255 (BP :94)
+ *   beta     out (N,K,order+1) fp64, coefficients highest power first
+ *   zinv     out (N,K,(order+1)^2) fp64, (Y0^T Y0 + reg I)^-1 -- saved for backward
+ *   masked   out (N,K,H,W) fp32 weight maps after activation+mask, or NULL to skip
+ *   partials workspace, >= lf_wls_workspace_bytes(N,K,order) bytes
+ *   status   out (N*K) int32: 0 ok, 1 singular, 2 not positive definite
+ * ---------------------------------------------------------------------------------- */
+size_t lf_wls_workspace_bytes(int N, int K, int order);
+int lf_wls_fwd(const float* logits, const float* grid_xy, long grid_batch_stride,
+               int N, int K, int H, int W, int zero_rows, int order, double reg,
+               double y_offset, int act_kind, int solver,
+               double* beta, double* zinv, float* masked, void* partials, int32_t* status,
+               void* stream);
+/* d loss / d logits from d loss / d beta (autograd of the bmm/inverse chain; gels.py:17-25).
+ *   grad_beta (N,K,order+1) fp64; lanes whose beta received no gradient pass zeros.
+ *   grad_logits out (N,K,H,W) fp32 (masked rows are written as 0). */
+int lf_wls_bwd(const float* logits, const float* grid_xy, long grid_batch_stride,
+               int N, int K, int H, int W, int zero_rows, int order, double y_offset,
+               int act_kind, const double* beta, const double* zinv, const double* grad_beta,
+               float* grad_logits, void* stream);
+
+/* Area_Loss.forward -- BEV/Loss_crit.py:98-134.  beta (N,order+1) with element stride
+ * beta_stride between images, gt (N,order+1) contiguous; dtype LF_F32/LF_F64 for both.
+ * loss out: 1 element of dtype; grad out: (N,order+1) of dtype = d loss / d beta. */
+int lf_area_loss(const void* beta, long beta_stride, const void* gt, int N, int order,
+                 int weight_funct, int dtype, void* loss, void* grad, void* stream);
+
+/* backprojection_loss.forward -- BP/Loss_crit.py:202-218 (constants of :166-200 passed in).
+ *   beta (N,order+1) fp64 (stride beta_stride), x_gt/valid (N,S) fp64, Y (S,order+1) fp64,
+ *   y_prime (S) fp64, minv_host: 9 doubles (row-major M^-1) read on the HOST at call time.
+ *   loss out fp64 scalar; x_cal_valid out (N,S) fp64; grad out (N,order+1) fp64. */
+int lf_backproj_loss(const double* beta, long beta_stride, const double* x_gt, const double* valid,
+                     const double* Y, const double* y_prime, const double* minv_host,
+                     int N, int S, int order, double* loss, double* x_cal_valid, double* grad,
+                     void* stream);
+
+/* Class-weighted pixel cross entropy, weighted-mean reduction: BEV/Loss_crit.py:61-75,
+ * BP/Loss_crit.py:64-65.  logits (N,C,H,W) fp32, target (N,H,W) int64, weights (C) fp32.
+ * acc: 2 doubles of scratch.  loss out fp32 scalar. */
+int lf_ce2d_fwd(const float* logits, const int64_t* target, const float* weights,
+                int N, int C, int H, int W, double* acc, float* loss, void* stream);
+/* grad_logits (N,C,H,W) = upstream * d loss / d logits; `acc` as left by lf_ce2d_fwd. */
+int lf_ce2d_bwd(const float* logits, const int64_t* target, const float* weights,
+                int N, int C, int H, int W, const double* acc, const float* upstream,
+                float* grad_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ERFNet backbone engine.  Replaces ERFNet.Net.forward (BEV/Networks/ERFNet.py:151-157;
+ * DownsamplerBlock :11-22, non_bottleneck_1d :25-60, Encoder :63-95, UpsamplerBlock :98-107,
+ * Decoder :109-142; BP/Networks/ERFNet.py is the same network) and its autograd backward.
+ *
+ * A plan is built once per input shape (host-side object, no device allocation); every call
+ * runs the whole pass on `stream` out of a caller-owned workspace that must stay untouched
+ * between a forward and its backward (it holds the saved activations, NHWC fp32).
+ *
+ *   params: the model's parameter tensors in state_dict() order, buffers excluded (weights,
+ *     biases, BN weight/bias; 228 of them for one head, +2 with the `pretrained` second head),
+ *     given both as a HOST array of device pointers and as a DEVICE array of the same pointers;
+ *   running: 2 * lf_erfnet_num_bn() device pointers (running_mean, running_var per BN, module
+ *     order); updated in training mode exactly like nn.BatchNorm2d (momentum 0.1, eps 1e-3);
+ *   dropmask: Dropout2d keep-masks (0 or 1/(1-p) per (image, channel)) for the 13 encoder blocks
+ *     with p > 0 (ERFNet.py:41,57-58), laid out per lf_erfnet_dropmask_offset(); NULL = no dropout;
+ *   head: 0 = decoder.output_conv, 1 = decoder.output_conv2 (Decoder.forward flag, :134-141);
+ *   logits: (N, out_channels + head, H, W) fp32 NCHW.
+ * ---------------------------------------------------------------------------------- */
+typedef struct lf_erfnet_plan lf_erfnet_plan;
+lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int out_channels, int n_heads);
+void lf_erfnet_plan_destroy(lf_erfnet_plan* plan);
+size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* plan);
+int lf_erfnet_num_params(const lf_erfnet_plan* plan);
+int lf_erfnet_num_bn(const lf_erfnet_plan* plan);
+int lf_erfnet_num_dropout(const lf_erfnet_plan* plan);
+long lf_erfnet_dropmask_floats(const lf_erfnet_plan* plan);
+long lf_erfnet_dropmask_offset(const lf_erfnet_plan* plan, int i);      /* float offset of block i */
+int lf_erfnet_dropmask_channels(const lf_erfnet_plan* plan, int i);
+long lf_erfnet_encoder_offset(const lf_erfnet_plan* plan);             /* float offset of the encoder output (N,H/8,W/8,128) NHWC */
+long lf_erfnet_activation_offset(const lf_erfnet_plan* plan, int layer, int slot);
+int lf_erfnet_forward(const lf_erfnet_plan* plan, const float* img, const float* const* params_host,
+                      const float* const* params_dev, float* const* running_host, const float* dropmask,
+                      int training, int head, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* Gradients are written (not accumulated) into grads_host[i]; NULL entries are skipped. */
+int lf_erfnet_backward(const lf_erfnet_plan* plan, const float* img, const float* grad_logits,
+                       const float* const* params_host, float* const* grads_host, const float* dropmask, int head,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANEFIT_H */

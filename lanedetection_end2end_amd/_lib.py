@@ -1,0 +1,93 @@
+"""ctypes binding of liblanefit_hip.so (the C ABI in include/lanefit.h).
+
+The library is the product: there is no eager / CPU fallback.  If it is missing, or a call
+is made without a GPU tensor, this module raises -- loudly -- instead of computing anything.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_long, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblanefit_hip.so")
+_lib = None
+
+
+class LaneFitLibraryError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    P, I, L, D = c_void_p, c_int, c_long, c_double
+    sig = {
+        "lf_abi_version": (c_int, []),
+        "lf_last_error": (c_char_p, []),
+        "lf_wls_workspace_bytes": (c_size_t, [I, I, I]),
+        "lf_wls_fwd": (I, [P, P, L, I, I, I, I, I, I, D, D, I, I, P, P, P, P, P, P]),
+        "lf_wls_bwd": (I, [P, P, L, I, I, I, I, I, I, D, I, P, P, P, P, P]),
+        "lf_area_loss": (I, [P, L, P, I, I, I, I, P, P, P]),
+        "lf_backproj_loss": (I, [P, L, P, P, P, P, P, I, I, I, P, P, P, P]),
+        "lf_ce2d_fwd": (I, [P, P, P, I, I, I, I, P, P, P]),
+        "lf_ce2d_bwd": (I, [P, P, P, I, I, I, I, P, P, P, P]),
+        "lf_erfnet_plan_create": (P, [I, I, I, I, I, I]),
+        "lf_erfnet_plan_destroy": (None, [P]),
+        "lf_erfnet_workspace_bytes": (c_size_t, [P]),
+        "lf_erfnet_num_params": (I, [P]),
+        "lf_erfnet_num_bn": (I, [P]),
+        "lf_erfnet_num_dropout": (I, [P]),
+        "lf_erfnet_dropmask_floats": (L, [P]),
+        "lf_erfnet_dropmask_offset": (L, [P, I]),
+        "lf_erfnet_dropmask_channels": (I, [P, I]),
+        "lf_erfnet_encoder_offset": (L, [P]),
+        "lf_erfnet_activation_offset": (L, [P, I, I]),
+        "lf_erfnet_forward": (I, [P, P, P, P, P, P, I, I, P, P, c_size_t, P]),
+        "lf_erfnet_backward": (I, [P, P, P, P, P, P, I, P, c_size_t, P]),
+        "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+def exported_symbols():
+    """Names include/lanefit.h declares (used by the CPU test that checks the .so exports them)."""
+    return list(_declare(load()).keys()) + list(_extra_symbols)
+
+
+_extra_symbols = []
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LaneFitLibraryError(
+                "%s not found: build it with `python -m lanedetection_end2end_amd.build` "
+                "(there is no fallback path)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LaneFitLibraryError("%s failed: %s" % (what, load().lf_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LaneFitLibraryError("lanefit ops need tensors on the MI355X (got a %s tensor); "
+                                  "there is no CPU path" % t.device)
+    assert t.is_contiguous(), "internal: tensor must be contiguous"
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,38 @@
+"""``Networks.LSQ_layer`` of the BEV tree (BEV/Networks/LSQ_layer.py): same public names."""
+import torch
+import torch.nn as nn
+
+from ... import geometry
+from ...fit import WeightedLeastSquares
+from ...lsq import BEVNet as Net, activation_layer  # noqa: F401
+
+
+def Init_Projective_transform(nclasses, batch_size, resize):
+    """(size, M, M_inv) with M expanded to (batch,3,3) fp32 -- LSQ_layer.py:17-32."""
+    size = torch.Size([batch_size, nclasses, resize, 2 * resize])
+    M, M_inv = geometry.bev_homography()
+    ex = lambda m: torch.from_numpy(m).unsqueeze(0).expand(batch_size, 3, 3).float()
+    return size, ex(M), ex(M_inv)
+
+
+class ProjectiveGridGenerator(nn.Module):
+    """forward(theta) -> (N, H*W, 2) grid (LSQ_layer.py:66-87).  The grid is constant, so it is computed once."""
+
+    def __init__(self, size, theta, no_cuda=False):
+        super().__init__()
+        self.N, self.C, self.H, self.W = size
+        self.no_cuda = no_cuda
+        self._cache = None
+
+    def forward(self, theta):
+        if self._cache is None:
+            g = geometry.projective_grid(self.H, self.W, theta[0].detach().double().cpu().numpy(), True)
+            self._cache = g if self.no_cuda else g.cuda()
+        return self._cache.unsqueeze(0).expand(self.N, -1, -1)
+
+
+class Weighted_least_squares(WeightedLeastSquares):
+    """BEV flavour: y = 1 - grid_y, orders 0..2, fp32 betas (LSQ_layer.py:90-167)."""
+    y_offset = 1.0
+    max_order = 2
+    out_dtype = torch.float32

@@ -1,0 +1,84 @@
+// Internal interface of the tap-GEMM convolution kernels (gfx950, fp32 MFMA 16x16x4).
+//
+// Every convolution-like layer of the ERFNet backbone (1-D factorised 3x1 / 1x3 convs with
+// dilation, 3x3 stride-2 convs, 3x3 stride-2 transposed convs by sub-pixel phase, and all of
+// their data gradients) is ONE kernel family: for every logical pixel p and output channel co
+//     dst[dpix(p)][co] = epi( bias[co] + sum_t sum_ci pro(src[spix(p,t)][ci]) * Wp[t][ci][co] )
+// with NHWC fp32 activations, K = (taps x source channels) contracted on the matrix cores.
+// Weight gradients are the transposed contraction over pixels (lf_tapwgrad).
+#pragma once
+#include "lf_common.h"
+
+#define LF_MAX_TAPS 9
+
+struct LfTapGeom {
+    int N, Hl, Wl;                 // logical pixel grid the kernel iterates over
+    int Hs, Ws, s_pix, s_choff;    // source tensor: spatial dims, floats per pixel, channel offset
+    int ssh, ssw;                  // source coord = logical * ss + tap offset
+    int Hd, Wd, d_pix, d_choff;    // destination tensor
+    int dsh, dsw, dah, daw;        // dest coord = logical * ds + da
+    int Cs, Cd;                    // contracted channels (multiple of 16), produced channels (multiple of 16)
+    int ntaps;
+    int tdh[LF_MAX_TAPS], tdw[LF_MAX_TAPS];
+};
+
+enum { LF_PRO_NONE = 0, LF_PRO_BNRELU = 1 };
+enum {
+    LF_EPI_RELU = 1,        // v = max(v, 0)
+    LF_EPI_MASK = 2,        // v = mask_src > 0 ? v : 0        (ReLU backward from the saved output)
+    LF_EPI_ADD = 4,         // v += add_src                    (residual / accumulated gradient)
+    LF_EPI_STATS_SQ = 8,    // per-channel sum v, sum v^2      (BatchNorm forward statistics)
+    LF_EPI_MASKBN = 16,     // v = (aux*msc+msh) > 0 ? v : 0   (ReLU backward through a recomputed BN)
+    LF_EPI_STATS_XHAT = 32  // per-channel sum v, sum v*xhat, xhat = aux*asc+ash  (BatchNorm backward)
+};
+
+struct LfTapArgs {
+    const float* src;
+    const float* wp;        // packed weights [tap][Cs/4][Cd][4]
+    const float* bias;      // [Cd] or null
+    float* dst;
+    const float* pro_sc;    // prologue BN scale / shift per source channel
+    const float* pro_sh;
+    const float* mask_src;  // dest-geometry tensors
+    const float* add_src;
+    const float* aux;
+    const float* msc;       // [Cd] forward BN scale/shift (MASKBN)
+    const float* msh;
+    const float* asc;       // [Cd] rstd, -mean*rstd (STATS_XHAT)
+    const float* ash;
+    float* stats;           // [rows][2][Cd] per-wave partial sums, rows = lf_tapgemm_stat_rows()
+};
+
+int lf_tapgemm_stat_rows(const LfTapGeom& g);
+int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);
+
+struct LfWgradArgs {
+    const float* x;         // source-side tensor (gathered by taps), geometry = source fields of LfTapGeom
+    const float* g;         // dest-side gradient tensor, geometry = dest fields
+    const float* pro_sc;    // optional BN+ReLU recompute on x
+    const float* pro_sh;
+    float* partial;         // [splits][ntaps][Cs][Cd]
+    float* bias_partial;    // [bias_rows][Cd] or null
+};
+// number of k-split rows the kernel will write for this geometry
+int lf_tapwgrad_splits(const LfTapGeom& g);
+int lf_tapwgrad_bias_rows(const LfTapGeom& g);
+int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st);
+
+// dst[k*sk + n*sn + tapidx[t]] = sum_s partial[s][t][k][n]
+int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,
+                           const int* tapidx_host, hipStream_t st);
+// dst[n] (+)= sum_r rows[r][n]
+int lf_rows_reduce_launch(const float* rows, int nrows, int C, float* dst, int accumulate, hipStream_t st);
+
+// wp[((t*(Kc/4) + k/4)*Nc + n)*4 + k%4] = w[k*sk + n*sn + tapidx[t]]
+struct LfPackEntry {
+    long src_off;   // float offset into the flat parameter arena / or pointer index, see lf_erfnet
+    long dst_off;   // float offset into the packed-weight arena
+    int Kc, Nc, ntaps;
+    long sk, sn;
+    int tapidx[LF_MAX_TAPS];
+    int param;      // index of the parameter tensor holding the weights
+};
+int lf_pack_weights_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena,
+                           hipStream_t st);

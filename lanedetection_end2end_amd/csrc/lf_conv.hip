@@ -1,0 +1,465 @@
+// Tap-GEMM convolution kernels for gfx950 (see lf_conv.h for the contract).
+//
+// Matrix-core mapping (v_mfma_f32_16x16x4_f32, exact fp32, D = A*B + C, wave64):
+//   A[i][k]: lane l supplies row i = l&15, k-slot kq = l>>4      -> weights / x-channels
+//   B[k][j]: lane l supplies col j = l&15, k-slot kq = l>>4      -> pixels / g-channels
+//   D[i][j]: lane l holds rows 4*(l>>4)+e (e = 0..3), col l&15
+// Forward/dgrad: rows = output channels, cols = 16 pixels, k = source channels.  Each lane
+// loads ONE float4 = 4 consecutive channels (16*cg + 4*kq + s, s = 0..3) of its pixel / of its
+// weight row and feeds MFMA step s with element s: the k order is permuted identically on both
+// operands, which a contraction does not care about.  A pixel's 16 channels (64 B) are read by 4
+// lanes, a 16-pixel tile by one wave instruction; accumulators come out as 4 consecutive output
+// channels per lane -> one float4 store per (tile, lane).  No LDS: operands stream from L1/L2
+// straight into VGPRs, one (tap, 16-channel) step prefetched ahead of the MFMAs that use it.
+// fp32 MFMA runs at the vector rate (157 TF), 1/16 of bf16, so one dwordx4 per operand tile per
+// 16 MFMAs (512 cycles) is far below what the load path sustains.
+#include "lf_conv.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int MT = 4;                 // 16-pixel tiles per wave
+constexpr int WG_WAVES = 4;
+constexpr int PIX_PER_WG = WG_WAVES * MT * 16;
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ f32x4 max0(f32x4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+}
+__device__ __forceinline__ f32x4 keep_pos(f32x4 v, f32x4 m) {
+    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    return v;
+}
+// sum over the 16 lanes that share l>>4 (xor 1,2,4,8 stays inside the 16-lane group)
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    const long tile0 = ((long)blockIdx.x * WG_WAVES + wave) * (MT * 16);
+    const int cob = blockIdx.y * NT * 16;
+
+    int pn[MT], pi[MT], pj[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const long p = tile0 + m * 16 + pl;
+        pv[m] = p < npix;
+        const long q = pv[m] ? p : 0;
+        pj[m] = (int)(q % g.Wl);
+        const long r = q / g.Wl;
+        pi[m] = (int)(r % g.Hl);
+        pn[m] = (int)(r / g.Hl);
+    }
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+
+    const int ncg = g.Cs >> 4;
+    const int nsteps = g.ntaps * ncg;
+
+    f32x4 wa[NT], xb[MT], wa_n[NT], xb_n[MT];
+    auto load = [&](int t, int cg, f32x4(&w)[NT], f32x4(&x)[MT]) {
+        const float* wpt = a.wp + ((long)(t * (g.Cs >> 2) + cg * 4 + kq) * g.Cd + cob + pl) * 4;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) w[n] = ldg4(wpt + n * 64);
+        const int dh = g.tdh[t], dw = g.tdw[t];
+        const int ch = g.s_choff + cg * 16 + kq * 4;
+        f32x4 sc, sh;
+        if (pro == LF_PRO_BNRELU) { sc = ldg4(a.pro_sc + cg * 16 + kq * 4); sh = ldg4(a.pro_sh + cg * 16 + kq * 4); }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+            const bool ok = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            f32x4 v = zero4();
+            if (ok) {
+                v = ldg4(a.src + ((long)(pn[m] * g.Hs + sy) * g.Ws + sx) * g.s_pix + ch);
+                if (pro == LF_PRO_BNRELU) v = max0(v * sc + sh);
+            }
+            x[m] = v;
+        }
+    };
+
+    int t = 0, cg = 0;
+    load(0, 0, wa, xb);
+    for (int step = 0; step < nsteps; ++step) {
+        int tn = t, cgn = cg + 1;
+        if (cgn == ncg) { cgn = 0; tn = t + 1; }
+        const bool more = step + 1 < nsteps;
+        if (more) load(tn, cgn, wa_n, xb_n);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[n][s], xb[m][s], acc[n][m], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wa[n] = wa_n[n];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xb[m] = xb_n[m];
+        }
+        t = tn; cg = cgn;
+    }
+
+    // ---- epilogue: lane holds channels co = cob + n*16 + 4*kq + (0..3) of pixel (tile m, pl)
+    const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0;
+    f32x4 s1[NT], s2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { s1[n] = zero4(); s2[n] = zero4(); }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = cob + n * 16 + kq * 4;
+        const f32x4 b = a.bias ? ldg4(a.bias + co) : zero4();
+        f32x4 msc, msh, asc, ash;
+        if (epi & LF_EPI_MASKBN) { msc = ldg4(a.msc + co); msh = ldg4(a.msh + co); }
+        if (epi & LF_EPI_STATS_XHAT) { asc = ldg4(a.asc + co); ash = ldg4(a.ash + co); }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (!pv[m]) continue;
+            const long doff = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix +
+                              g.d_choff + co;
+            f32x4 v = acc[n][m] + b;
+            if (epi & LF_EPI_ADD) v += ldg4(a.add_src + doff);
+            if (epi & LF_EPI_MASK) v = keep_pos(v, ldg4(a.mask_src + doff));
+            f32x4 ax;
+            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) ax = ldg4(a.aux + doff);
+            if (epi & LF_EPI_MASKBN) v = keep_pos(v, ax * msc + msh);
+            if (epi & LF_EPI_RELU) v = max0(v);
+            *reinterpret_cast<f32x4*>(a.dst + doff) = v;
+            if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; }
+            if (epi & LF_EPI_STATS_XHAT) { s1[n] += v; s2[n] += v * (ax * asc + ash); }
+        }
+    }
+    if (stats) {
+        const long row = (long)blockIdx.x * WG_WAVES + wave;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x4 r1, r2;
+            r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w);
+            r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w);
+            if (pl == 0) {
+                const int co = cob + n * 16 + kq * 4;
+                *reinterpret_cast<f32x4*>(a.stats + (row * 2 + 0) * g.Cd + co) = r1;
+                *reinterpret_cast<f32x4*>(a.stats + (row * 2 + 1) * g.Cd + co) = r2;
+            }
+        }
+    }
+}
+
+int pick_nt(int Cd) {
+    const int tiles = Cd / 16;
+    if (tiles % 4 == 0) return 4;
+    if (tiles % 3 == 0) return 3;
+    if (tiles % 2 == 0) return 2;
+    return 1;
+}
+
+}  // namespace
+
+int lf_tapgemm_stat_rows(const LfTapGeom& g) {
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    return lf_cdiv(npix, PIX_PER_WG) * WG_WAVES;
+}
+
+int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st) {
+    LF_REQUIRE(g.Cs % 16 == 0 && g.Cd % 16 == 0, "tapgemm: channels must be multiples of 16 (Cs=%d Cd=%d)", g.Cs, g.Cd);
+    LF_REQUIRE(g.s_pix % 4 == 0 && g.s_choff % 4 == 0 && g.d_pix % 4 == 0 && g.d_choff % 4 == 0, "tapgemm: unaligned channel layout");
+    LF_REQUIRE(g.ntaps >= 1 && g.ntaps <= LF_MAX_TAPS, "tapgemm: bad tap count %d", g.ntaps);
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    const int nt = pick_nt(g.Cd);
+    dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
+    switch (nt) {
+        case 4: hipLaunchKernelGGL(tapgemm_kernel<4>, grid, dim3(256), 0, st, g, a, pro, epi); break;
+        case 3: hipLaunchKernelGGL(tapgemm_kernel<3>, grid, dim3(256), 0, st, g, a, pro, epi); break;
+        case 2: hipLaunchKernelGGL(tapgemm_kernel<2>, grid, dim3(256), 0, st, g, a, pro, epi); break;
+        default: hipLaunchKernelGGL(tapgemm_kernel<1>, grid, dim3(256), 0, st, g, a, pro, epi); break;
+    }
+    LF_CHECK_LAUNCH("tapgemm");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient: dW[t][ci][co] = sum_p pro(X[spix(p,t)][ci]) * G[dpix(p)][co]
+// rows = x-channels, cols = g-channels, k = 4 pixels per MFMA (k-slot kq <-> pixel p0+kq).
+// Vector mode (channels % 64 == 0): a lane's float4 = channels 4*pl..4*pl+3 of its pixel feeds
+// FOUR MFMA tiles (tile r = channels {4*i + r}); so 2 dwordx4 loads feed 16 MFMAs.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+template <bool XV, bool GV, int XT, int GT>
+__global__ __launch_bounds__(256) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
+                                                      const long pps, const int write_bias) {
+    constexpr int XTiles = XV ? 4 : XT, GTiles = GV ? 4 : GT;
+    constexpr int XB = XTiles * 16, GB = GTiles * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
+    const int t = blockIdx.y;
+    const int ncob = g.Cd / GB;
+    const int cib = blockIdx.z / ncob, cob = blockIdx.z % ncob;
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    const long sub = (long)blockIdx.x * WG_WAVES + wave;
+    const long p_begin = sub * pps;
+    long p_end = p_begin + pps;
+    if (p_end > npix) p_end = npix;
+
+    f32x4 acc[XTiles][GTiles];
+#pragma unroll
+    for (int r = 0; r < XTiles; ++r)
+#pragma unroll
+        for (int q = 0; q < GTiles; ++q) acc[r][q] = zero4();
+    float bsum[GTiles];
+#pragma unroll
+    for (int q = 0; q < GTiles; ++q) bsum[q] = 0.f;
+
+    // this lane's pixel: p = p_begin + kq + 4*iter  (Wl % 4 == 0, so j += 4 never skips a row end)
+    long p = p_begin + kq;
+    int pj, pi, pn;
+    {
+        const long q = p < npix ? p : 0;
+        pj = (int)(q % g.Wl);
+        const long r = q / g.Wl;
+        pi = (int)(r % g.Hl);
+        pn = (int)(r / g.Hl);
+    }
+    const int dh = g.tdh[t], dw = g.tdw[t];
+    const int xch = g.s_choff + cib * XB + (XV ? 4 * pl : pl);
+    const int gch = g.d_choff + cob * GB + (GV ? 4 * pl : pl);
+    f32x4 psc, psh;
+    float psc1[XTiles], psh1[XTiles];
+    if (pro == LF_PRO_BNRELU) {
+        if constexpr (XV) { psc = ldg4(a.pro_sc + cib * XB + 4 * pl); psh = ldg4(a.pro_sh + cib * XB + 4 * pl); }
+        else {
+#pragma unroll
+            for (int r = 0; r < XTiles; ++r) { psc1[r] = a.pro_sc[cib * XB + r * 16 + pl]; psh1[r] = a.pro_sh[cib * XB + r * 16 + pl]; }
+        }
+    }
+
+    for (; p - kq < p_end; p += 4) {
+        const bool valid = p < p_end;
+        float xv[XTiles], gv[GTiles];
+#pragma unroll
+        for (int r = 0; r < XTiles; ++r) xv[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < GTiles; ++q) gv[q] = 0.f;
+        if (valid) {
+            const float* gp = a.g + ((long)(pn * g.Hd + pi * g.dsh + g.dah) * g.Wd + pj * g.dsw + g.daw) * g.d_pix + gch;
+            if constexpr (GV) { const f32x4 v = ldg4(gp); gv[0] = v.x; gv[1] = v.y; gv[2] = v.z; gv[3] = v.w; }
+            else {
+#pragma unroll
+                for (int q = 0; q < GTiles; ++q) gv[q] = gp[q * 16];
+            }
+            const int sy = pi * g.ssh + dh, sx = pj * g.ssw + dw;
+            if (sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws) {
+                const float* xp = a.x + ((long)(pn * g.Hs + sy) * g.Ws + sx) * g.s_pix + xch;
+                if constexpr (XV) {
+                    f32x4 v = ldg4(xp);
+                    if (pro == LF_PRO_BNRELU) v = max0(v * psc + psh);
+                    xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < XTiles; ++r) {
+                        float v = xp[r * 16];
+                        if (pro == LF_PRO_BNRELU) v = fmaxf(v * psc1[r] + psh1[r], 0.f);
+                        xv[r] = v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < XTiles; ++r)
+#pragma unroll
+            for (int q = 0; q < GTiles; ++q)
+                acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r], gv[q], acc[r][q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < GTiles; ++q) bsum[q] += gv[q];
+        pj += 4;
+        if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
+    }
+
+    // ---- reduce the 4 waves of the workgroup through LDS, wave 0 writes one partial row
+    __shared__ float red[WG_WAVES - 1][XTiles * GTiles * 4][64];
+    __shared__ float bred[WG_WAVES][GTiles][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < XTiles; ++r)
+#pragma unroll
+            for (int q = 0; q < GTiles; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave - 1][(r * GTiles + q) * 4 + e][lane] = acc[r][q][e];
+    }
+#pragma unroll
+    for (int q = 0; q < GTiles; ++q) bred[wave][q][lane] = bsum[q];
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.partial + ((long)blockIdx.x * g.ntaps + t) * g.Cs * g.Cd;
+#pragma unroll
+        for (int r = 0; r < XTiles; ++r)
+#pragma unroll
+            for (int q = 0; q < GTiles; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[r][q][e];
+#pragma unroll
+                    for (int w = 0; w < WG_WAVES - 1; ++w) v += red[w][(r * GTiles + q) * 4 + e][lane];
+                    const int i = 4 * kq + e;                                  // row of tile (r,q)
+                    const int ci = cib * XB + (XV ? 4 * i + r : r * 16 + i);
+                    const int co = cob * GB + (GV ? 4 * pl + q : q * 16 + pl);
+                    out[(long)ci * g.Cd + co] = v;
+                }
+        if (write_bias && a.bias_partial && t == 0 && cib == 0) {
+            // column sums of G over this workgroup's pixels: lanes with equal pl (4 k-slots) x 4 waves
+#pragma unroll
+            for (int q = 0; q < GTiles; ++q) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WG_WAVES; ++w) v += bred[w][q][lane];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (kq == 0) {
+                    const int co = cob * GB + (GV ? 4 * pl + q : q * 16 + pl);
+                    a.bias_partial[(long)blockIdx.x * g.Cd + co] = v;
+                }
+            }
+        }
+    }
+}
+
+struct WgradCfg { int xv, gv, xt, gt, gx; long pps; };
+
+WgradCfg wgrad_cfg(const LfTapGeom& g) {
+    WgradCfg c;
+    c.xv = (g.Cs % 64 == 0);
+    c.gv = (g.Cd % 64 == 0);
+    c.xt = c.xv ? 4 : g.Cs / 16;
+    c.gt = c.gv ? 4 : g.Cd / 16;
+    const int xb = c.xt * 16, gb = c.gt * 16;
+    const int jobs = g.ntaps * (g.Cs / xb) * (g.Cd / gb);
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    int gx = 3072 / (jobs * WG_WAVES);          // ~3 waves per SIMD over 256 CUs
+    if (gx < 1) gx = 1;
+    const long maxgx = (npix + 64 * WG_WAVES - 1) / (64 * WG_WAVES);   // at least 64 pixels per wave
+    if (gx > maxgx) gx = (int)maxgx;
+    if (gx < 1) gx = 1;
+    long pps = (npix + (long)gx * WG_WAVES - 1) / ((long)gx * WG_WAVES);
+    pps = (pps + 3) / 4 * 4;
+    c.gx = (int)((npix + pps * WG_WAVES - 1) / (pps * WG_WAVES));
+    c.pps = pps;
+    return c;
+}
+
+}  // namespace
+
+int lf_tapwgrad_splits(const LfTapGeom& g) { return wgrad_cfg(g).gx; }
+int lf_tapwgrad_bias_rows(const LfTapGeom& g) { return wgrad_cfg(g).gx; }
+
+int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st) {
+    LF_REQUIRE(g.Cs % 16 == 0 && g.Cd % 16 == 0, "tapwgrad: channels must be multiples of 16");
+    LF_REQUIRE(g.Wl % 4 == 0, "tapwgrad: logical width %d must be a multiple of 4", g.Wl);
+    const WgradCfg c = wgrad_cfg(g);
+    const int xb = c.xt * 16, gb = c.gt * 16;
+    dim3 grid(c.gx, g.ntaps, (g.Cs / xb) * (g.Cd / gb));
+    const int wb = a.bias_partial != nullptr;
+#define LF_WG(XV, GV, XT, GT) \
+    hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb)
+    if (c.xv && c.gv) LF_WG(true, true, 4, 4);
+    else if (c.xv && c.gt == 1) LF_WG(true, false, 4, 1);
+    else if (c.xv && c.gt == 3) LF_WG(true, false, 4, 3);
+    else if (!c.xv && c.xt == 1 && c.gv) LF_WG(false, true, 1, 4);
+    else if (!c.xv && c.xt == 1 && c.gt == 1) LF_WG(false, false, 1, 1);
+    else if (!c.xv && c.xt == 1 && c.gt == 3) LF_WG(false, false, 1, 3);
+    else if (!c.xv && c.xt == 3 && c.gt == 1) LF_WG(false, false, 3, 1);
+    else if (!c.xv && c.xt == 3 && c.gv) LF_WG(false, true, 3, 4);
+    else return lf_fail("tapwgrad: unsupported channel combination Cs=%d Cd=%d", g.Cs, g.Cd);
+#undef LF_WG
+    LF_CHECK_LAUNCH("tapwgrad");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// split-K reduction + scatter into the PyTorch parameter-gradient layout; bias rows; packing
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct TapIdx { int v[LF_MAX_TAPS]; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int ntaps,
+                                                          int Cs, int Cd, float* __restrict__ grad, long sk, long sn,
+                                                          TapIdx ti) {
+    const long per = (long)ntaps * Cs * Cd;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        double s = 0.0;
+        for (int r = 0; r < splits; ++r) s += (double)partial[r * per + i];
+        const int n = (int)(i % Cd);
+        const long r2 = i / Cd;
+        const int k = (int)(r2 % Cs), t = (int)(r2 / Cs);
+        grad[k * sk + n * sn + ti.v[t]] = (float)s;
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ rows, int nrows, int C,
+                                                         float* __restrict__ dst, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < nrows; ++r) s += (double)rows[(long)r * C + c];
+    dst[c] = accumulate ? dst[c] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const LfPackEntry* __restrict__ entries,
+                                                          const float* const* __restrict__ params,
+                                                          float* __restrict__ arena) {
+    const LfPackEntry e = entries[blockIdx.x];
+    const float* w = params[e.param];
+    float* dst = arena + e.dst_off;
+    const long total = (long)e.ntaps * e.Kc * e.Nc;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const int k4 = (int)(i & 3);
+        long r = i >> 2;
+        const int n = (int)(r % e.Nc);
+        r /= e.Nc;
+        const int kb = (int)(r % (e.Kc >> 2));
+        const int t = (int)(r / (e.Kc >> 2));
+        const int k = kb * 4 + k4;
+        dst[i] = w[k * e.sk + n * e.sn + e.tapidx[t]];
+    }
+}
+
+}  // namespace
+
+int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,
+                           const int* tapidx_host, hipStream_t st) {
+    TapIdx ti;
+    for (int i = 0; i < LF_MAX_TAPS; ++i) ti.v[i] = i < ntaps ? tapidx_host[i] : 0;
+    const long per = (long)ntaps * Cs * Cd;
+    int grid = lf_cdiv(per, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, splits, ntaps, Cs, Cd, grad, sk, sn, ti);
+    LF_CHECK_LAUNCH("wgrad_reduce");
+    return 0;
+}
+
+int lf_rows_reduce_launch(const float* rows, int nrows, int C, float* dst, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3(lf_cdiv(C, 256)), dim3(256), 0, st, rows, nrows, C, dst, accumulate);
+    LF_CHECK_LAUNCH("rows_reduce");
+    return 0;
+}
+
+int lf_pack_weights_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nentries, 16), dim3(256), 0, st, entries_dev, params_dev, arena);
+    LF_CHECK_LAUNCH("pack_weights");
+    return 0;
+}

@@ -1,0 +1,618 @@
+// Bandwidth-bound backbone kernels (contract in lf_eltwise.h).  All tensors NHWC fp32 unless
+// noted; every global access is a 16-byte vector over the channel axis.
+// Reference behaviour: BEV/Networks/ERFNet.py (DownsamplerBlock :11-22, non_bottleneck_1d :44-60,
+// UpsamplerBlock :98-107, Decoder.output_conv :124), nn.BatchNorm2d(eps=1e-3), nn.Dropout2d.
+#include "lf_eltwise.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 z4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); return v;
+}
+__device__ __forceinline__ f32x4 pos4(f32x4 v, f32x4 m) {
+    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f; return v;
+}
+
+// Reduce per-thread (a1,a2) over all threads sharing the same channel quad (tid % Q); thread tid < Q
+// ends up with the block totals.  256 threads, Q a power of two dividing 256.
+__device__ __forceinline__ void block_reduce_quads(f32x4& a1, f32x4& a2, int Q, float (*sm)[8]) {
+    const int tid = threadIdx.x;
+    sm[tid][0] = a1.x; sm[tid][1] = a1.y; sm[tid][2] = a1.z; sm[tid][3] = a1.w;
+    sm[tid][4] = a2.x; sm[tid][5] = a2.y; sm[tid][6] = a2.z; sm[tid][7] = a2.w;
+    __syncthreads();
+    for (int s = 128; s >= Q; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm[tid][j] += sm[tid + s][j];
+        }
+        __syncthreads();
+    }
+    a1.x = sm[tid][0]; a1.y = sm[tid][1]; a1.z = sm[tid][2]; a1.w = sm[tid][3];
+    a2.x = sm[tid][4]; a2.y = sm[tid][5]; a2.z = sm[tid][6]; a2.w = sm[tid][7];
+}
+
+struct StatParts { LfStatPart p[2]; int n; };
+
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ rmean, float* __restrict__ rvar,
+                                                             float momentum, float eps, int training,
+                                                             float* __restrict__ scale, float* __restrict__ shift,
+                                                             float* __restrict__ asc, float* __restrict__ ash) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
+    __shared__ double sm[16][16][2];
+    double s1 = 0.0, s2 = 0.0;
+    if (training && c < C) {
+        for (int k = 0; k < sp.n; ++k) {
+            const LfStatPart& q = sp.p[k];
+            const int cc = c - q.ch_off;
+            if (cc < 0 || cc >= q.C) continue;
+            for (int r = rg; r < q.nrows; r += 16) {
+                s1 += (double)q.rows[((long)r * 2 + 0) * q.C + cc];
+                s2 += (double)q.rows[((long)r * 2 + 1) * q.C + cc];
+            }
+        }
+    }
+    sm[rg][threadIdx.x & 15][0] = s1;
+    sm[rg][threadIdx.x & 15][1] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        double mean, var;
+        if (training) {
+            s1 = 0.0; s2 = 0.0;
+            for (int r = 0; r < 16; ++r) { s1 += sm[r][threadIdx.x][0]; s2 += sm[r][threadIdx.x][1]; }
+            mean = s1 / count;
+            var = s2 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mean);
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+        } else {
+            mean = (double)rmean[c];
+            var = (double)rvar[c];
+        }
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double sc = (double)gamma[c] * rstd;
+        scale[c] = (float)sc;
+        shift[c] = (float)((double)beta[c] - mean * sc);
+        asc[c] = (float)rstd;
+        ash[c] = (float)(-mean * rstd);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                    const float* __restrict__ sh, const float* __restrict__ dm,
+                                                    const float* __restrict__ res, float* __restrict__ y, long units,
+                                                    int Q, long pix_per_image) {
+    const int C = Q * 4;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
+        const int c = (int)(u % Q) * 4;
+        f32x4 v = ld4(x + u * 4) * ld4(sc + c) + ld4(sh + c);
+        if (dm) v *= ld4(dm + ((u / Q) / pix_per_image) * C + c);
+        if (res) v += ld4(res + u * 4);
+        st4(y + u * 4, relu4(v));
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ t, const float* __restrict__ asc,
+                                                           const float* __restrict__ ash, const float* __restrict__ dm,
+                                                           float* __restrict__ rows, long npix, int Q, long pix_per_image) {
+    const int C = Q * 4, ppi = 256 / Q;
+    const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
+    const int c = cq * 4;
+    const f32x4 a_sc = ld4(asc + c), a_sh = ld4(ash + c);
+    f32x4 a1 = z4(), a2 = z4();
+    const long per_block = ((npix + gridDim.x - 1) / gridDim.x + ppi - 1) / ppi * ppi;
+    const long p0 = (long)blockIdx.x * per_block;
+    long p1 = p0 + per_block;
+    if (p1 > npix) p1 = npix;
+    for (long p = p0 + pr; p < p1; p += ppi) {
+        const long off = p * C + c;
+        f32x4 gm = ld4(g + off);
+        if (y) gm = pos4(gm, ld4(y + off));
+        if (dm) gm *= ld4(dm + (p / pix_per_image) * C + c);
+        a1 += gm;
+        a2 += gm * (ld4(t + off) * a_sc + a_sh);
+    }
+    __shared__ float sm[256][8];
+    block_reduce_quads(a1, a2, Q, sm);
+    if (threadIdx.x < Q) {
+        st4(rows + ((long)blockIdx.x * 2 + 0) * C + c, a1);
+        st4(rows + ((long)blockIdx.x * 2 + 1) * C + c, a2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int C, double count, float* __restrict__ c1,
+                                                             float* __restrict__ c2, float* __restrict__ ggamma,
+                                                             float* __restrict__ gbeta) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
+    __shared__ double sm[16][16][2];
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int k = 0; k < sp.n; ++k) {
+            const LfStatPart& q = sp.p[k];
+            const int cc = c - q.ch_off;
+            if (cc < 0 || cc >= q.C) continue;
+            for (int r = rg; r < q.nrows; r += 16) {
+                s1 += (double)q.rows[((long)r * 2 + 0) * q.C + cc];
+                s2 += (double)q.rows[((long)r * 2 + 1) * q.C + cc];
+            }
+        }
+    }
+    sm[rg][threadIdx.x & 15][0] = s1;
+    sm[rg][threadIdx.x & 15][1] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        s1 = 0.0; s2 = 0.0;
+        for (int r = 0; r < 16; ++r) { s1 += sm[r][threadIdx.x][0]; s2 += sm[r][threadIdx.x][1]; }
+        c1[c] = (float)(s1 / count);
+        c2[c] = (float)(s2 / count);
+        ggamma[c] = (float)s2;
+        gbeta[c] = (float)s1;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                          const float* __restrict__ t, const float* __restrict__ asc,
+                                                          const float* __restrict__ ash, const float* __restrict__ gamma,
+                                                          const float* __restrict__ c1, const float* __restrict__ c2,
+                                                          const float* __restrict__ dm, float* __restrict__ g_t,
+                                                          float* __restrict__ g_z, long units, int Q, long pix_per_image) {
+    const int C = Q * 4;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
+        const int c = (int)(u % Q) * 4;
+        f32x4 gm = ld4(g + u * 4);
+        if (y) gm = pos4(gm, ld4(y + u * 4));
+        if (g_z) st4(g_z + u * 4, gm);
+        if (dm) gm *= ld4(dm + ((u / Q) / pix_per_image) * C + c);
+        const f32x4 rstd = ld4(asc + c);
+        const f32x4 xh = ld4(t + u * 4) * rstd + ld4(ash + c);
+        st4(g_t + u * 4, ld4(gamma + c) * rstd * (gm - ld4(c1 + c) - xh * ld4(c2 + c)));
+    }
+}
+
+// ---- max-pool branch of DownsamplerBlock ------------------------------------------------
+__global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int Q,
+                                                             float* __restrict__ cat, int cat_pix, int choff,
+                                                             float* __restrict__ rows) {
+    const int C = Q * 4, ppi = 256 / Q, Ho = H / 2, Wo = W / 2;
+    const int cq = threadIdx.x % Q, pr = threadIdx.x / Q, c = cq * 4;
+    const long npix = (long)N * Ho * Wo;
+    const long per_block = ((npix + gridDim.x - 1) / gridDim.x + ppi - 1) / ppi * ppi;
+    const long p0 = (long)blockIdx.x * per_block;
+    long p1 = p0 + per_block;
+    if (p1 > npix) p1 = npix;
+    f32x4 a1 = z4(), a2 = z4();
+    for (long p = p0 + pr; p < p1; p += ppi) {
+        const int ow = (int)(p % Wo);
+        const long r = p / Wo;
+        const int oh = (int)(r % Ho), n = (int)(r / Ho);
+        const float* b = x + (((long)n * H + 2 * oh) * W + 2 * ow) * C + c;
+        f32x4 v = ld4(b);
+        f32x4 u = ld4(b + C);
+        v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+        u = ld4(b + (long)W * C);
+        v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+        u = ld4(b + (long)W * C + C);
+        v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+        st4(cat + p * cat_pix + choff + c, v);
+        a1 += v;
+        a2 += v * v;
+    }
+    __shared__ float sm[256][8];
+    block_reduce_quads(a1, a2, Q, sm);
+    if (rows && threadIdx.x < Q) {
+        st4(rows + ((long)blockIdx.x * 2 + 0) * C + c, a1);
+        st4(rows + ((long)blockIdx.x * 2 + 1) * C + c, a2);
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gcat, int N,
+                                                      int H, int W, int Q, int cat_pix, int choff, float* __restrict__ gx) {
+    const int C = Q * 4, Ho = H / 2, Wo = W / 2;
+    const long units = (long)N * Ho * Wo * Q;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
+        const int c = (int)(u % Q) * 4;
+        const long p = u / Q;
+        const int ow = (int)(p % Wo);
+        const long r = p / Wo;
+        const int oh = (int)(r % Ho), n = (int)(r / Ho);
+        const long base = (((long)n * H + 2 * oh) * W + 2 * ow) * C + c;
+        const long o1 = C, o2 = (long)W * C, o3 = (long)W * C + C;
+        const f32x4 v0 = ld4(x + base), v1 = ld4(x + base + o1), v2 = ld4(x + base + o2), v3 = ld4(x + base + o3);
+        const f32x4 g = ld4(gcat + p * cat_pix + choff + c);
+        f32x4 r0 = z4(), r1 = z4(), r2 = z4(), r3 = z4();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // first maximum in window scan order wins (strict >), as ATen's max_pool2d
+            int arg = 0;
+            float m = v0[e];
+            if (v1[e] > m) { m = v1[e]; arg = 1; }
+            if (v2[e] > m) { m = v2[e]; arg = 2; }
+            if (v3[e] > m) { m = v3[e]; arg = 3; }
+            r0[e] = arg == 0 ? g[e] : 0.f; r1[e] = arg == 1 ? g[e] : 0.f;
+            r2[e] = arg == 2 ? g[e] : 0.f; r3[e] = arg == 3 ? g[e] : 0.f;
+        }
+        st4(gx + base, r0); st4(gx + base + o1, r1); st4(gx + base + o2, r2); st4(gx + base + o3, r3);
+    }
+}
+
+// ---- stem --------------------------------------------------------------------------------
+constexpr int STEM_MAXCIN = 4;
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, int N, int Cin, int H, int W,
+                                                      const float* __restrict__ w, const float* __restrict__ b,
+                                                      float* __restrict__ cat, float* __restrict__ rows) {
+    const int Cc = 16 - Cin, Ho = H / 2, Wo = W / 2, KK = Cin * 9;
+    __shared__ float sw[16 * STEM_MAXCIN * 9 + 16];
+    for (int i = threadIdx.x; i < Cc * KK; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cc; i += 256) sw[16 * STEM_MAXCIN * 9 + i] = b[i];
+    __syncthreads();
+    const long npix = (long)N * Ho * Wo;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    float out[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = 0.f;
+    const bool valid = p < npix;
+    if (valid) {
+        const int ow = (int)(p % Wo);
+        const long r = p / Wo;
+        const int oh = (int)(r % Ho), n = (int)(r / Ho);
+        float patch[STEM_MAXCIN * 9];
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* pl = img + ((long)n * Cin + ci) * H * W;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+                    patch[ci * 9 + kh * 3 + kw] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? pl[(long)ih * W + iw] : 0.f;
+                }
+        }
+        for (int co = 0; co < Cc; ++co) {
+            float s = sw[16 * STEM_MAXCIN * 9 + co];
+            for (int j = 0; j < KK; ++j) s = fmaf(patch[j], sw[co * KK + j], s);
+            out[co] = s;
+        }
+        for (int ci = 0; ci < Cin; ++ci)   // pool window = patch taps (1,1),(1,2),(2,1),(2,2)
+            out[Cc + ci] = fmaxf(fmaxf(patch[ci * 9 + 4], patch[ci * 9 + 5]), fmaxf(patch[ci * 9 + 7], patch[ci * 9 + 8]));
+        float* o = cat + p * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {out[q * 4], out[q * 4 + 1], out[q * 4 + 2], out[q * 4 + 3]};
+            st4(o + q * 4, v);
+        }
+    }
+    if (rows) {
+        __shared__ float red[4][32];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = valid ? out[i] : 0.f;
+            const float s1 = lf_wave_sum(v), s2 = lf_wave_sum(v * v);
+            if (lane == 0) { red[wave][i] = s1; red[wave][16 + i] = s2; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            rows[((long)blockIdx.x * 2 + (threadIdx.x >> 4)) * 16 + (threadIdx.x & 15)] = s;
+        }
+    }
+}
+
+// dW[co][ci][kh][kw] partial rows: blockIdx.y = co
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ gcat, int N,
+                                                        int Cin, int H, int W, float* __restrict__ wrows,
+                                                        float* __restrict__ brows) {
+    const int Cc = 16 - Cin, Ho = H / 2, Wo = W / 2, KK = Cin * 9, co = blockIdx.y;
+    const long npix = (long)N * Ho * Wo;
+    float acc[STEM_MAXCIN * 9 + 1];
+#pragma unroll
+    for (int j = 0; j < STEM_MAXCIN * 9 + 1; ++j) acc[j] = 0.f;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const float gv = gcat[p * 16 + co];
+        const int ow = (int)(p % Wo);
+        const long r = p / Wo;
+        const int oh = (int)(r % Ho), n = (int)(r / Ho);
+#pragma unroll
+        for (int ci = 0; ci < STEM_MAXCIN; ++ci) {
+            if (ci >= Cin) break;
+            const float* pl = img + ((long)n * Cin + ci) * H * W;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+                    const float xv = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? pl[(long)ih * W + iw] : 0.f;
+                    acc[ci * 9 + kh * 3 + kw] = fmaf(gv, xv, acc[ci * 9 + kh * 3 + kw]);
+                }
+        }
+        acc[STEM_MAXCIN * 9] += gv;
+    }
+    __shared__ float red[4][STEM_MAXCIN * 9 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < STEM_MAXCIN * 9 + 1; ++j) {
+        const float s = lf_wave_sum(acc[j]);
+        if (lane == 0) red[wave][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < KK)
+        wrows[((long)blockIdx.x * Cc + co) * KK + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x == 0) {
+        const int j = STEM_MAXCIN * 9;
+        brows[(long)blockIdx.x * Cc + co] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    }
+}
+
+// ---- head: ConvTranspose2d(16, K, 2, stride=2), weight (16,K,2,2) -------------------------
+constexpr int HEAD_MAXK = 8;
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ out, int N, int h,
+                                                      int wd, int K) {
+    __shared__ float sw[16 * HEAD_MAXK * 4 + HEAD_MAXK];
+    for (int i = threadIdx.x; i < 16 * K * 4; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < K; i += 256) sw[16 * HEAD_MAXK * 4 + i] = b[i];
+    __syncthreads();
+    const long npix = (long)N * h * wd;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const int j = (int)(p % wd);
+        const long r = p / wd;
+        const int i = (int)(r % h), n = (int)(r / h);
+        float xv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = ld4(x + p * 16 + q * 4);
+            xv[q * 4] = v.x; xv[q * 4 + 1] = v.y; xv[q * 4 + 2] = v.z; xv[q * 4 + 3] = v.w;
+        }
+        for (int k = 0; k < K; ++k) {
+            float o[4];
+            const float bk = sw[16 * HEAD_MAXK * 4 + k];
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) o[ab] = bk;
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) o[ab] = fmaf(xv[ci], sw[(ci * K + k) * 4 + ab], o[ab]);
+            float* op = out + (((long)n * K + k) * (2 * h) + 2 * i) * (2 * wd) + 2 * j;
+            *reinterpret_cast<float2*>(op) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2*>(op + 2 * wd) = make_float2(o[2], o[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ gout, const float* __restrict__ w,
+                                                           float* __restrict__ gx, int N, int h, int wd, int K) {
+    __shared__ float sw[16 * HEAD_MAXK * 4];
+    for (int i = threadIdx.x; i < 16 * K * 4; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const long npix = (long)N * h * wd;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const int j = (int)(p % wd);
+        const long r = p / wd;
+        const int i = (int)(r % h), n = (int)(r / h);
+        float acc[16];
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) acc[ci] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float* gp = gout + (((long)n * K + k) * (2 * h) + 2 * i) * (2 * wd) + 2 * j;
+            const float2 g0 = *reinterpret_cast<const float2*>(gp);
+            const float2 g1 = *reinterpret_cast<const float2*>(gp + 2 * wd);
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) {
+                const float* wk = sw + (ci * K + k) * 4;
+                acc[ci] = fmaf(g0.x, wk[0], fmaf(g0.y, wk[1], fmaf(g1.x, wk[2], fmaf(g1.y, wk[3], acc[ci]))));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+            st4(gx + p * 16 + q * 4, v);
+        }
+    }
+}
+
+// blockIdx.y = input-channel quad; rows[(b*16 + ci)*K*4 + k*4 + ab]
+template <int K>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                        float* __restrict__ wrows, float* __restrict__ brows, int N, int h,
+                                                        int wd) {
+    const int cq = blockIdx.y;
+    float acc[4][K * 4];
+    float bacc[K];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < K * 4; ++j) acc[c][j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) bacc[k] = 0.f;
+    const long npix = (long)N * h * wd;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const int j = (int)(p % wd);
+        const long r = p / wd;
+        const int i = (int)(r % h), n = (int)(r / h);
+        const f32x4 xv = ld4(x + p * 16 + cq * 4);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float* gp = gout + (((long)n * K + k) * (2 * h) + 2 * i) * (2 * wd) + 2 * j;
+            const float2 g0 = *reinterpret_cast<const float2*>(gp);
+            const float2 g1 = *reinterpret_cast<const float2*>(gp + 2 * wd);
+            const float gv[4] = {g0.x, g0.y, g1.x, g1.y};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) acc[c][k * 4 + ab] = fmaf(xv[c], gv[ab], acc[c][k * 4 + ab]);
+            bacc[k] += (g0.x + g0.y) + (g1.x + g1.y);
+        }
+    }
+    __shared__ float red[4][4 * K * 4 + K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < K * 4; ++j) {
+            const float s = lf_wave_sum(acc[c][j]);
+            if (lane == 0) red[wave][c * K * 4 + j] = s;
+        }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = lf_wave_sum(bacc[k]);
+        if (lane == 0) red[wave][4 * K * 4 + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * K * 4) {
+        const int c = threadIdx.x / (K * 4), j = threadIdx.x % (K * 4);
+        wrows[((long)blockIdx.x * 16 + cq * 4 + c) * (K * 4) + j] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+    if (cq == 0 && threadIdx.x < K) {
+        const int j = 4 * K * 4 + threadIdx.x;
+        brows[(long)blockIdx.x * K + threadIdx.x] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    }
+}
+
+inline int grid_for(long units, int cap) {
+    long g = (units + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+inline bool quad_ok(int C) { return C % 4 == 0 && 256 % (C / 4) == 0; }
+
+}  // namespace
+
+int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
+                       float* shift, float* asc, float* ash, hipStream_t st) {
+    LF_REQUIRE(nparts >= 0 && nparts <= 2, "bn_finalize: at most 2 partial sources");
+    StatParts sp;
+    sp.n = nparts;
+    for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(lf_cdiv(C, 16)), dim3(256), 0, st, sp, C, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, scale, shift, asc, ash);
+    LF_CHECK_LAUNCH("bn_finalize_fwd");
+    return 0;
+}
+
+int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm, const float* res, float* y, long npix,
+              int C, long pix_per_image, hipStream_t st) {
+    LF_REQUIRE(C % 4 == 0, "bn_act: C %% 4");
+    const long units = npix * (C / 4);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(units, 4096)), dim3(256), 0, st, x, sc, sh, dm, res, y, units, C / 4,
+                       pix_per_image);
+    LF_CHECK_LAUNCH("bn_act");
+    return 0;
+}
+
+int lf_bn_bwd_reduce_rows(long npix) { return grid_for(npix * 4, 1024); }
+
+int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* dm,
+                     float* rows, long npix, int C, long pix_per_image, hipStream_t st) {
+    LF_REQUIRE(quad_ok(C), "bn_bwd_reduce: unsupported channel count %d", C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(lf_bn_bwd_reduce_rows(npix)), dim3(256), 0, st, g, y, t, asc, ash, dm, rows,
+                       npix, C / 4, pix_per_image);
+    LF_CHECK_LAUNCH("bn_bwd_reduce");
+    return 0;
+}
+
+int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count, float* c1, float* c2, float* ggamma,
+                       float* gbeta, hipStream_t st) {
+    LF_REQUIRE(nparts >= 1 && nparts <= 2, "bn_bwd_finalize: 1..2 partial sources");
+    StatParts sp;
+    sp.n = nparts;
+    for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 16)), dim3(256), 0, st, sp, C, count, c1, c2, ggamma, gbeta);
+    LF_CHECK_LAUNCH("bn_bwd_finalize");
+    return 0;
+}
+
+int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* gamma,
+                    const float* c1, const float* c2, const float* dm, float* g_t, float* g_z, long npix, int C,
+                    long pix_per_image, hipStream_t st) {
+    LF_REQUIRE(C % 4 == 0, "bn_bwd_apply: C %% 4");
+    const long units = npix * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(units, 4096)), dim3(256), 0, st, g, y, t, asc, ash, gamma, c1, c2,
+                       dm, g_t, g_z, units, C / 4, pix_per_image);
+    LF_CHECK_LAUNCH("bn_bwd_apply");
+    return 0;
+}
+
+int lf_pool_rows(long npix_out) { return grid_for(npix_out * 4, 1024); }
+
+int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat, int cat_pix, int choff, float* rows,
+                       hipStream_t st) {
+    LF_REQUIRE(quad_ok(Cin) && H % 2 == 0 && W % 2 == 0, "pool_concat: unsupported shape");
+    const long npo = (long)N * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(pool_concat_fwd_kernel, dim3(lf_pool_rows(npo)), dim3(256), 0, st, x, N, H, W, Cin / 4, cat, cat_pix,
+                       choff, rows);
+    LF_CHECK_LAUNCH("pool_concat_fwd");
+    return 0;
+}
+
+int lf_pool_bwd(const float* x, const float* gcat, int N, int H, int W, int Cin, int cat_pix, int choff, float* gx,
+                hipStream_t st) {
+    const long units = (long)N * (H / 2) * (W / 2) * (Cin / 4);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(units, 4096)), dim3(256), 0, st, x, gcat, N, H, W, Cin / 4, cat_pix,
+                       choff, gx);
+    LF_CHECK_LAUNCH("pool_bwd");
+    return 0;
+}
+
+int lf_stem_rows(int N, int H, int W) { return lf_cdiv((long)N * (H / 2) * (W / 2), 256); }
+
+int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, const float* b, float* cat, float* rows,
+                hipStream_t st) {
+    LF_REQUIRE(Cin >= 1 && Cin <= STEM_MAXCIN, "stem: in_channels %d not in 1..%d", Cin, STEM_MAXCIN);
+    LF_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: odd image size");
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(lf_stem_rows(N, H, W)), dim3(256), 0, st, img, N, Cin, H, W, w, b, cat, rows);
+    LF_CHECK_LAUNCH("stem_fwd");
+    return 0;
+}
+
+int lf_stem_wgrad_rows(int N, int H, int W) { return grid_for((long)N * (H / 2) * (W / 2), 256); }
+
+int lf_stem_wgrad(const float* img, const float* gcat, int N, int Cin, int H, int W, float* wrows, float* brows,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(lf_stem_wgrad_rows(N, H, W), 16 - Cin), dim3(256), 0, st, img, gcat, N, Cin, H,
+                       W, wrows, brows);
+    LF_CHECK_LAUNCH("stem_wgrad");
+    return 0;
+}
+
+int lf_head_fwd(const float* x, const float* w, const float* b, float* out, int N, int h, int w_, int K, hipStream_t st) {
+    LF_REQUIRE(K >= 1 && K <= HEAD_MAXK, "head: out_channels %d not in 1..%d", K, HEAD_MAXK);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for((long)N * h * w_, 4096)), dim3(256), 0, st, x, w, b, out, N, h, w_, K);
+    LF_CHECK_LAUNCH("head_fwd");
+    return 0;
+}
+
+int lf_head_bwd_data(const float* gout, const float* w, float* gx, int N, int h, int w_, int K, hipStream_t st) {
+    LF_REQUIRE(K >= 1 && K <= HEAD_MAXK, "head: out_channels %d not in 1..%d", K, HEAD_MAXK);
+    hipLaunchKernelGGL(head_bwd_data_kernel, dim3(grid_for((long)N * h * w_, 4096)), dim3(256), 0, st, gout, w, gx, N, h, w_, K);
+    LF_CHECK_LAUNCH("head_bwd_data");
+    return 0;
+}
+
+int lf_head_wgrad_rows(int N, int h, int w_) { return grid_for((long)N * h * w_, 512); }
+
+int lf_head_wgrad(const float* x, const float* gout, float* wrows, float* brows, int N, int h, int w_, int K,
+                  hipStream_t st) {
+    dim3 grid(lf_head_wgrad_rows(N, h, w_), 4);
+#define LF_HW(KK) hipLaunchKernelGGL(head_wgrad_kernel<KK>, grid, dim3(256), 0, st, x, gout, wrows, brows, N, h, w_)
+    switch (K) {
+        case 1: LF_HW(1); break;
+        case 2: LF_HW(2); break;
+        case 3: LF_HW(3); break;
+        case 4: LF_HW(4); break;
+        case 5: LF_HW(5); break;
+        default: return lf_fail("head_wgrad: out_channels %d not in 1..5", K);
+    }
+#undef LF_HW
+    LF_CHECK_LAUNCH("head_wgrad");
+    return 0;
+}

@@ -1,0 +1,622 @@
+// ERFNet backbone engine: a host-side plan (layer table -> kernel launches + workspace layout)
+// and the two C-ABI calls that run the whole forward / backward pass on one stream.
+//
+// Replaces ERFNet.Net.forward (BEV/Networks/ERFNet.py:151-157; Encoder :63-95, Decoder :109-142)
+// and the autograd backward PyTorch derives for it.
+//
+// Data layout in HBM: activations NHWC fp32, every tensor a block's backward needs (t1..t4, out,
+// pre-BN conv outputs) stays resident in one caller-provided workspace; gradients ping-pong
+// through three buffers.  Weights are re-packed into the MFMA operand order once per forward
+// (2 M floats).  Train-mode BatchNorm = per-wave partial sums written by the producing conv's
+// epilogue + a tiny finalise kernel; the apply is fused into the next conv's operand load where
+// the dataflow allows (conv3x1_2) and into the residual/ReLU pass otherwise.
+#include <vector>
+
+#include "lf_conv.h"
+#include "lf_eltwise.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-3f, BN_MOM = 0.1f;
+enum { K_DOWN = 0, K_NB = 1, K_UP = 2 };
+
+struct GemmOp {
+    LfTapGeom geom;
+    int pack;   // index into plan->packs
+};
+struct BNRef {
+    int p_g, p_b, idx, C;
+    long sc, sh, asc, ash, c1, c2;   // float offsets into the workspace
+};
+struct ConvRef {
+    int p_w, p_b;
+    GemmOp fwd;                  // also the wgrad geometry
+    GemmOp dg[4];                // data-gradient launches (1, or 4 phases)
+    int ndg;
+    GemmOp fph[4];               // forward phases for transposed convs (nfph > 0 replaces fwd)
+    int nfph;
+};
+struct Layer {
+    int kind, Cin, Cout, Hin, Win, Hout, Wout, dil, drop_idx;
+    long x;                      // input activation (float offset); -1 = the NCHW image
+    long b[5];                   // down: cat,y | nb: t1,t2,t3,t4,out | up: c,y
+    ConvRef cv[4];
+    BNRef bn[2];
+};
+
+}  // namespace
+
+struct lf_erfnet_plan {
+    int N, H, W, Cin, Cout;
+    std::vector<Layer> layers;
+    std::vector<LfPackEntry> packs;
+    int n_params, n_bn, n_drop;
+    int p_head_w[2], p_head_b[2], n_heads;
+    long off_entries, off_packed, packed_floats;
+    long off_stat0, off_stat1, stat_floats;     // two scratch regions for BN partial rows
+    long off_wpart, wpart_floats, off_bpart, bpart_floats;
+    long off_gA, off_gB, off_gC, gbuf_floats;
+    long total_floats;
+    long head_in;                               // activation feeding the head
+    std::vector<long> drop_off;                 // per dropout block: float offset into the mask buffer
+    long drop_floats;
+};
+
+namespace {
+
+struct Bump {
+    long cur = 0;
+    long take(long nfloats) { long o = cur; cur += (nfloats + 63) / 64 * 64; return o; }
+};
+
+LfTapGeom base_geom(int N, int Hl, int Wl, int Hs, int Ws, int Cs_pix, int Hd, int Wd, int Cd_pix, int Cs, int Cd) {
+    LfTapGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.Hl = Hl; g.Wl = Wl;
+    g.Hs = Hs; g.Ws = Ws; g.s_pix = Cs_pix; g.s_choff = 0; g.ssh = 1; g.ssw = 1;
+    g.Hd = Hd; g.Wd = Wd; g.d_pix = Cd_pix; g.d_choff = 0; g.dsh = 1; g.dsw = 1; g.dah = 0; g.daw = 0;
+    g.Cs = Cs; g.Cd = Cd; g.ntaps = 0;
+    return g;
+}
+
+int add_pack(lf_erfnet_plan* P, int param, int Kc, int Nc, long sk, long sn, const LfTapGeom& g, const int* tapidx) {
+    LfPackEntry e;
+    memset(&e, 0, sizeof(e));
+    e.param = param; e.Kc = Kc; e.Nc = Nc; e.ntaps = g.ntaps; e.sk = sk; e.sn = sn;
+    for (int t = 0; t < g.ntaps; ++t) e.tapidx[t] = tapidx[t];
+    e.dst_off = P->packed_floats;
+    P->packed_floats += (long)g.ntaps * Kc * Nc;
+    P->packs.push_back(e);
+    return (int)P->packs.size() - 1;
+}
+
+// 1-D factorised conv (3 taps along H (axis 0) or W (axis 1), dilation d): forward + data gradient
+void build_conv1d(lf_erfnet_plan* P, ConvRef& c, int N, int H, int W, int C, int axis, int d) {
+    LfTapGeom g = base_geom(N, H, W, H, W, C, H, W, C, C, C);
+    g.ntaps = 3;
+    int idx_f[3], idx_d[3];
+    for (int t = 0; t < 3; ++t) {
+        g.tdh[t] = axis == 0 ? (t - 1) * d : 0;
+        g.tdw[t] = axis == 1 ? (t - 1) * d : 0;
+        idx_f[t] = t;        // Conv2d weight (Co,Ci,3,1)/(Co,Ci,1,3): tap t = kernel element t
+        idx_d[t] = 2 - t;    // data gradient = correlation with the flipped kernel
+    }
+    c.fwd.geom = g;
+    c.fwd.pack = add_pack(P, c.p_w, C, C, /*sk (ci)*/ 3, /*sn (co)*/ (long)C * 3, g, idx_f);
+    c.nfph = 0;
+    c.ndg = 1;
+    c.dg[0].geom = g;
+    c.dg[0].pack = add_pack(P, c.p_w, C, C, /*sk (co)*/ (long)C * 3, /*sn (ci)*/ 3, g, idx_d);
+}
+
+// sub-pixel phase tap sets shared by "3x3 s2 conv data-gradient" and "3x3 s2 transposed conv forward"
+int phase_taps(int a, int* k, int* off) {
+    if (a == 0) { k[0] = 1; off[0] = 0; return 1; }
+    k[0] = 0; off[0] = 1; k[1] = 2; off[1] = 0;
+    return 2;
+}
+
+// DownsamplerBlock conv: Conv2d(Cin, Cc, 3, stride 2, pad 1) writing channels [0,Cc) of the concat buffer
+void build_down_conv(lf_erfnet_plan* P, ConvRef& c, int N, int H, int W, int Cin, int Cc, int Ccat) {
+    const int Ho = H / 2, Wo = W / 2;
+    LfTapGeom g = base_geom(N, Ho, Wo, H, W, Cin, Ho, Wo, Ccat, Cin, Cc);
+    g.ssh = 2; g.ssw = 2; g.ntaps = 9;
+    int idx[9];
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) { g.tdh[kh * 3 + kw] = kh - 1; g.tdw[kh * 3 + kw] = kw - 1; idx[kh * 3 + kw] = kh * 3 + kw; }
+    c.fwd.geom = g;
+    c.fwd.pack = add_pack(P, c.p_w, Cin, Cc, /*sk (ci)*/ 9, /*sn (co)*/ (long)Cin * 9, g, idx);
+    c.nfph = 0;
+    c.ndg = 4;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            LfTapGeom d = base_geom(N, Ho, Wo, Ho, Wo, Ccat, H, W, Cin, Cc, Cin);
+            d.dsh = 2; d.dsw = 2; d.dah = a; d.daw = b;
+            int kh[2], oh[2], kw[2], ow[2], ti[4];
+            const int na = phase_taps(a, kh, oh), nb = phase_taps(b, kw, ow);
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < nb; ++j) { d.tdh[d.ntaps] = oh[i]; d.tdw[d.ntaps] = ow[j]; ti[d.ntaps] = kh[i] * 3 + kw[j]; ++d.ntaps; }
+            c.dg[a * 2 + b].geom = d;
+            c.dg[a * 2 + b].pack = add_pack(P, c.p_w, Cc, Cin, /*sk (co)*/ (long)Cin * 9, /*sn (ci)*/ 9, d, ti);
+        }
+}
+
+// UpsamplerBlock conv: ConvTranspose2d(Cin, Co, 3, stride 2, pad 1, output_padding 1), weight (Cin,Co,3,3)
+void build_up_conv(lf_erfnet_plan* P, ConvRef& c, int N, int Hi, int Wi, int Cin, int Co) {
+    c.nfph = 4;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            LfTapGeom g = base_geom(N, Hi, Wi, Hi, Wi, Cin, 2 * Hi, 2 * Wi, Co, Cin, Co);
+            g.dsh = 2; g.dsw = 2; g.dah = a; g.daw = b;
+            int kh[2], oh[2], kw[2], ow[2], ti[4];
+            const int na = phase_taps(a, kh, oh), nb = phase_taps(b, kw, ow);
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < nb; ++j) { g.tdh[g.ntaps] = oh[i]; g.tdw[g.ntaps] = ow[j]; ti[g.ntaps] = kh[i] * 3 + kw[j]; ++g.ntaps; }
+            c.fph[a * 2 + b].geom = g;
+            c.fph[a * 2 + b].pack = add_pack(P, c.p_w, Cin, Co, /*sk (ci)*/ (long)Co * 9, /*sn (co)*/ 9, g, ti);
+        }
+    LfTapGeom d = base_geom(N, Hi, Wi, 2 * Hi, 2 * Wi, Co, Hi, Wi, Cin, Co, Cin);
+    d.ssh = 2; d.ssw = 2; d.ntaps = 9;
+    int idx[9];
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) { d.tdh[kh * 3 + kw] = kh - 1; d.tdw[kh * 3 + kw] = kw - 1; idx[kh * 3 + kw] = kh * 3 + kw; }
+    c.ndg = 1;
+    c.dg[0].geom = d;
+    c.dg[0].pack = add_pack(P, c.p_w, Co, Cin, /*sk (co)*/ 9, /*sn (ci)*/ (long)Co * 9, d, idx);
+    c.fwd = c.fph[0];
+}
+
+void bn_alloc(Bump& ws, BNRef& b) {
+    b.sc = ws.take(b.C); b.sh = ws.take(b.C); b.asc = ws.take(b.C); b.ash = ws.take(b.C);
+    b.c1 = ws.take(b.C); b.c2 = ws.take(b.C);
+}
+
+long maxl(long a, long b) { return a > b ? a : b; }
+
+void account_fwd_stats(lf_erfnet_plan* P, const LfTapGeom& g) {
+    P->stat_floats = maxl(P->stat_floats, (long)lf_tapgemm_stat_rows(g) * 2 * g.Cd);
+}
+void account_wgrad(lf_erfnet_plan* P, const LfTapGeom& g) {
+    P->wpart_floats = maxl(P->wpart_floats, (long)lf_tapwgrad_splits(g) * g.ntaps * g.Cs * g.Cd);
+    P->bpart_floats = maxl(P->bpart_floats, (long)lf_tapwgrad_bias_rows(g) * g.Cd);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Build the plan for a fixed input shape.  out_channels = channels of the selected head
+// (nclasses or nclasses+1); n_heads = 2 when the model was built with pretrained=True
+// (Decoder.output_conv2, ERFNet.py:125-126).  Returns NULL on error.
+lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int out_channels, int n_heads) {
+    if (N < 1 || H % 16 != 0 || W % 32 != 0 || in_channels < 1 || in_channels > 4 || out_channels < 1 || out_channels + n_heads - 1 > 5 ||
+        n_heads < 1 || n_heads > 2) {
+        lf_fail("lf_erfnet_plan_create: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (need H%%16==0, W%%32==0)", N, H, W,
+                in_channels, out_channels);
+        return nullptr;
+    }
+    lf_erfnet_plan* P = new lf_erfnet_plan();
+    P->N = N; P->H = H; P->W = W; P->Cin = in_channels; P->Cout = out_channels; P->n_heads = n_heads;
+    P->packed_floats = 0; P->stat_floats = 0; P->wpart_floats = 0; P->bpart_floats = 0; P->drop_floats = 0;
+    Bump ws;
+    int param = 0, bn = 0, drop = 0;
+    long cur = -1;
+    int h = H, w = W;
+    auto add_down = [&](int cin, int cout) {
+        Layer L;
+        memset(&L, 0, sizeof(L));
+        L.kind = K_DOWN; L.Cin = cin; L.Cout = cout; L.Hin = h; L.Win = w; L.Hout = h / 2; L.Wout = w / 2; L.drop_idx = -1;
+        L.x = cur;
+        L.cv[0].p_w = param++; L.cv[0].p_b = param++;
+        L.bn[0].p_g = param++; L.bn[0].p_b = param++; L.bn[0].idx = bn++; L.bn[0].C = cout;
+        const long sz = (long)N * (h / 2) * (w / 2) * cout;
+        L.b[0] = ws.take(sz); L.b[1] = ws.take(sz);
+        bn_alloc(ws, L.bn[0]);
+        if (cur >= 0) {
+            build_down_conv(P, L.cv[0], N, h, w, cin, cout - cin, cout);
+            account_fwd_stats(P, L.cv[0].fwd.geom);
+            account_wgrad(P, L.cv[0].fwd.geom);
+        }
+        P->layers.push_back(L);
+        cur = L.b[1]; h /= 2; w /= 2;
+    };
+    auto add_nb = [&](int c, float pdrop, int d) {
+        Layer L;
+        memset(&L, 0, sizeof(L));
+        L.kind = K_NB; L.Cin = c; L.Cout = c; L.Hin = L.Hout = h; L.Win = L.Wout = w; L.dil = d;
+        L.drop_idx = pdrop > 0.f ? drop++ : -1;
+        L.x = cur;
+        const long sz = (long)N * h * w * c;
+        for (int i = 0; i < 5; ++i) L.b[i] = ws.take(sz);
+        const int axis[4] = {0, 1, 0, 1}, dil[4] = {1, 1, d, d};
+        for (int i = 0; i < 4; ++i) {
+            if (i == 2) { L.bn[0].p_g = param++; L.bn[0].p_b = param++; L.bn[0].idx = bn++; L.bn[0].C = c; }
+            L.cv[i].p_w = param++; L.cv[i].p_b = param++;
+            build_conv1d(P, L.cv[i], N, h, w, c, axis[i], dil[i]);
+        }
+        L.bn[1].p_g = param++; L.bn[1].p_b = param++; L.bn[1].idx = bn++; L.bn[1].C = c;
+        bn_alloc(ws, L.bn[0]); bn_alloc(ws, L.bn[1]);
+        account_fwd_stats(P, L.cv[0].fwd.geom);
+        account_wgrad(P, L.cv[0].fwd.geom);
+        if (L.drop_idx >= 0) { P->drop_off.push_back(P->drop_floats); P->drop_floats += (long)N * c; }
+        P->layers.push_back(L);
+        cur = L.b[4];
+    };
+    auto add_up = [&](int cin, int cout) {
+        Layer L;
+        memset(&L, 0, sizeof(L));
+        L.kind = K_UP; L.Cin = cin; L.Cout = cout; L.Hin = h; L.Win = w; L.Hout = 2 * h; L.Wout = 2 * w; L.drop_idx = -1;
+        L.x = cur;
+        L.cv[0].p_w = param++; L.cv[0].p_b = param++;
+        L.bn[0].p_g = param++; L.bn[0].p_b = param++; L.bn[0].idx = bn++; L.bn[0].C = cout;
+        const long sz = (long)N * 2 * h * 2 * w * cout;
+        L.b[0] = ws.take(sz); L.b[1] = ws.take(sz);
+        bn_alloc(ws, L.bn[0]);
+        build_up_conv(P, L.cv[0], N, h, w, cin, cout);
+        long rows4 = 0;
+        for (int ph = 0; ph < 4; ++ph) { rows4 += lf_tapgemm_stat_rows(L.cv[0].fph[ph].geom); account_wgrad(P, L.cv[0].fph[ph].geom); }
+        P->stat_floats = maxl(P->stat_floats, rows4 * 2 * cout);   // the 4 phases' rows are laid end to end
+        P->layers.push_back(L);
+        cur = L.b[1]; h *= 2; w *= 2;
+    };
+    // Encoder (ERFNet.py:63-84)
+    add_down(in_channels, 16);
+    add_down(16, 64);
+    for (int i = 0; i < 5; ++i) add_nb(64, 0.03f, 1);
+    add_down(64, 128);
+    const int dils[8] = {2, 4, 8, 16, 2, 4, 8, 16};
+    for (int i = 0; i < 8; ++i) add_nb(128, 0.3f, dils[i]);
+    param += 2;   // encoder.output_conv (1x1, only used by only_encode=True; never trained, ERFNet.py:84,92-93)
+    // Decoder (ERFNet.py:109-126)
+    add_up(128, 64);
+    add_nb(64, 0.f, 1); add_nb(64, 0.f, 1);
+    add_up(64, 16);
+    add_nb(16, 0.f, 1); add_nb(16, 0.f, 1);
+    for (int i = 0; i < n_heads; ++i) { P->p_head_w[i] = param++; P->p_head_b[i] = param++; }
+    P->head_in = cur;
+    P->n_params = param; P->n_bn = bn; P->n_drop = drop;
+
+    // stem / pool / bn-backward partial rows also use the stat scratch regions
+    const long npix1 = (long)N * (H / 2) * (W / 2);
+    P->stat_floats = maxl(P->stat_floats, (long)lf_stem_rows(N, H, W) * 2 * 16);
+    P->stat_floats = maxl(P->stat_floats, (long)lf_pool_rows(npix1) * 2 * 128);
+    P->stat_floats = maxl(P->stat_floats, (long)lf_bn_bwd_reduce_rows(npix1) * 2 * 128);
+    P->wpart_floats = maxl(P->wpart_floats, (long)lf_stem_wgrad_rows(N, H, W) * 16 * 36);
+    P->wpart_floats = maxl(P->wpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 16 * 5 * 4);
+    P->bpart_floats = maxl(P->bpart_floats, (long)lf_stem_wgrad_rows(N, H, W) * 16);
+    P->bpart_floats = maxl(P->bpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 8);
+
+    P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
+    P->off_packed = ws.take(P->packed_floats);
+    P->off_stat0 = ws.take(P->stat_floats);
+    P->off_stat1 = ws.take(P->stat_floats);
+    P->off_wpart = ws.take(P->wpart_floats);
+    P->off_bpart = ws.take(P->bpart_floats);
+    P->gbuf_floats = (long)N * (H / 2) * (W / 2) * 16;          // largest activation (= N*(H/4)*(W/4)*64)
+    P->off_gA = ws.take(P->gbuf_floats);
+    P->off_gB = ws.take(P->gbuf_floats);
+    P->off_gC = ws.take(P->gbuf_floats);
+    P->total_floats = ws.cur;
+    return P;
+}
+
+void lf_erfnet_plan_destroy(lf_erfnet_plan* P) { delete P; }
+size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)P->total_floats * sizeof(float); }
+int lf_erfnet_num_params(const lf_erfnet_plan* P) { return P->n_params; }
+int lf_erfnet_num_bn(const lf_erfnet_plan* P) { return P->n_bn; }
+// Dropout2d keep-masks: one (N, C) fp32 block per non_bottleneck_1d with p > 0, in module order;
+// values 0 or 1/(1-p).  Returns the total float count; offsets via lf_erfnet_dropmask_offset.
+long lf_erfnet_dropmask_floats(const lf_erfnet_plan* P) { return P->drop_floats; }
+int lf_erfnet_num_dropout(const lf_erfnet_plan* P) { return P->n_drop; }
+long lf_erfnet_dropmask_offset(const lf_erfnet_plan* P, int i) { return P->drop_off[i]; }
+int lf_erfnet_dropmask_channels(const lf_erfnet_plan* P, int i) {
+    int k = 0;
+    for (const Layer& L : P->layers)
+        if (L.drop_idx >= 0 && k++ == i) return L.Cout;
+    return -1;
+}
+// byte offset / float count of a named activation inside the workspace (parity tests): layer index in
+// module order (0 = stem), slot as in Layer::b.  Returns -1 when out of range.
+long lf_erfnet_encoder_offset(const lf_erfnet_plan* P) {
+    for (const Layer& L : P->layers)
+        if (L.kind == K_UP) return L.x;      // input of the first UpsamplerBlock = encoder output (N,H/8,W/8,128)
+    return -1;
+}
+long lf_erfnet_activation_offset(const lf_erfnet_plan* P, int layer, int slot) {
+    if (layer < 0 || layer >= (int)P->layers.size() || slot < 0 || slot > 4) return -1;
+    return P->layers[layer].b[slot];
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Ctx {
+    const lf_erfnet_plan* P;
+    float* ws;
+    const float* const* params;      // host array of device pointers
+    float* const* grads;             // host array of device pointers (may hold nulls)
+    float* const* running;           // host array: [2*i] running_mean, [2*i+1] running_var
+    const float* dropmask;           // device buffer or null
+    int training;
+    hipStream_t st;
+    float* at(long off) const { return ws + off; }
+    const float* packed(int pack) const { return ws + P->off_packed + P->packs[pack].dst_off; }
+};
+
+#define LF_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const float* bias, int pro, int epi,
+             LfTapArgs extra) {
+    extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
+    return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
+}
+
+LfTapArgs no_args() { LfTapArgs a; memset(&a, 0, sizeof(a)); return a; }
+
+int bn_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int nparts, double count) {
+    return lf_bn_finalize_fwd(parts, nparts, b.C, count, c.params[b.p_g], c.params[b.p_b], c.running[2 * b.idx],
+                              c.running[2 * b.idx + 1], BN_MOM, BN_EPS, c.training, c.at(b.sc), c.at(b.sh), c.at(b.asc),
+                              c.at(b.ash), c.st);
+}
+
+int forward_layers(const Ctx& c, const float* img) {
+    const lf_erfnet_plan* P = c.P;
+    const int N = P->N;
+    float* stat0 = c.at(P->off_stat0);
+    float* stat1 = c.at(P->off_stat1);
+    for (const Layer& L : P->layers) {
+        const long npo = (long)N * L.Hout * L.Wout;
+        if (L.kind == K_DOWN) {
+            LfStatPart parts[2];
+            int np = 0;
+            if (L.x < 0) {
+                LF_TRY(lf_stem_fwd(img, N, L.Cin, L.Hin, L.Win, c.params[L.cv[0].p_w], c.params[L.cv[0].p_b], c.at(L.b[0]),
+                                   c.training ? stat0 : nullptr, c.st));
+                parts[np++] = {stat0, lf_stem_rows(N, L.Hin, L.Win), 16, 0};
+            } else {
+                LfTapArgs a = no_args();
+                a.stats = stat0;
+                LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
+                                c.training ? LF_EPI_STATS_SQ : 0, a));
+                parts[np++] = {stat0, lf_tapgemm_stat_rows(L.cv[0].fwd.geom), L.Cout - L.Cin, 0};
+                LF_TRY(lf_pool_concat_fwd(c.at(L.x), N, L.Hin, L.Win, L.Cin, c.at(L.b[0]), L.Cout, L.Cout - L.Cin,
+                                          c.training ? stat1 : nullptr, c.st));
+                parts[np++] = {stat1, lf_pool_rows(npo), L.Cin, L.Cout - L.Cin};
+            }
+            LF_TRY(bn_finalize(c, L.bn[0], parts, np, (double)npo));
+            LF_TRY(lf_bn_act(c.at(L.b[0]), c.at(L.bn[0].sc), c.at(L.bn[0].sh), nullptr, nullptr, c.at(L.b[1]), npo, L.Cout,
+                             (long)L.Hout * L.Wout, c.st));
+        } else if (L.kind == K_NB) {
+            const int srows = lf_tapgemm_stat_rows(L.cv[0].fwd.geom);
+            LfTapArgs a = no_args();
+            LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE, LF_EPI_RELU, a));
+            a.stats = stat0;
+            LF_TRY(run_gemm(c, L.cv[1].fwd, c.at(L.b[0]), c.at(L.b[1]), c.params[L.cv[1].p_b], LF_PRO_NONE,
+                            c.training ? LF_EPI_STATS_SQ : 0, a));
+            LfStatPart p0 = {stat0, srows, L.Cout, 0};
+            LF_TRY(bn_finalize(c, L.bn[0], &p0, 1, (double)npo));
+            a = no_args();
+            a.pro_sc = c.at(L.bn[0].sc); a.pro_sh = c.at(L.bn[0].sh);
+            LF_TRY(run_gemm(c, L.cv[2].fwd, c.at(L.b[1]), c.at(L.b[2]), c.params[L.cv[2].p_b], LF_PRO_BNRELU, LF_EPI_RELU, a));
+            a = no_args();
+            a.stats = stat0;
+            LF_TRY(run_gemm(c, L.cv[3].fwd, c.at(L.b[2]), c.at(L.b[3]), c.params[L.cv[3].p_b], LF_PRO_NONE,
+                            c.training ? LF_EPI_STATS_SQ : 0, a));
+            LF_TRY(bn_finalize(c, L.bn[1], &p0, 1, (double)npo));
+            const float* dm = (c.training && L.drop_idx >= 0 && c.dropmask) ? c.dropmask + P->drop_off[L.drop_idx] : nullptr;
+            LF_TRY(lf_bn_act(c.at(L.b[3]), c.at(L.bn[1].sc), c.at(L.bn[1].sh), dm, c.at(L.x), c.at(L.b[4]), npo, L.Cout,
+                             (long)L.Hout * L.Wout, c.st));
+        } else {
+            LfStatPart parts[1];
+            // the 4 sub-pixel phases write disjoint pixels of c; their stat rows are laid end to end
+            int rows = 0;
+            for (int ph = 0; ph < 4; ++ph) {
+                LfTapArgs a = no_args();
+                a.stats = stat0 + (long)rows * 2 * L.Cout;
+                LF_TRY(run_gemm(c, L.cv[0].fph[ph], c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
+                                c.training ? LF_EPI_STATS_SQ : 0, a));
+                rows += lf_tapgemm_stat_rows(L.cv[0].fph[ph].geom);
+            }
+            parts[0] = {stat0, rows, L.Cout, 0};
+            LF_TRY(bn_finalize(c, L.bn[0], parts, 1, (double)npo));
+            LF_TRY(lf_bn_act(c.at(L.b[0]), c.at(L.bn[0].sc), c.at(L.bn[0].sh), nullptr, nullptr, c.at(L.b[1]), npo, L.Cout,
+                             (long)L.Hout * L.Wout, c.st));
+        }
+    }
+    return 0;
+}
+
+// weight + bias gradient of one forward-geometry GEMM
+int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x, const float* g, const float* pro_sc,
+              const float* pro_sh, int bias_accumulate) {
+    const lf_erfnet_plan* P = c.P;
+    if (!c.grads[cv.p_w]) return 0;
+    LfWgradArgs a;
+    a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh;
+    a.partial = c.at(P->off_wpart);
+    a.bias_partial = c.grads[cv.p_b] ? c.at(P->off_bpart) : nullptr;
+    LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, c.st));
+    const LfPackEntry& e = P->packs[op.pack];
+    LF_TRY(lf_wgrad_reduce_launch(a.partial, lf_tapwgrad_splits(op.geom), op.geom.ntaps, op.geom.Cs, op.geom.Cd,
+                                  c.grads[cv.p_w], e.sk, e.sn, e.tapidx, c.st));
+    if (a.bias_partial)
+        LF_TRY(lf_rows_reduce_launch(a.bias_partial, lf_tapwgrad_bias_rows(op.geom), op.geom.Cd, c.grads[cv.p_b],
+                                     bias_accumulate, c.st));
+    return 0;
+}
+
+int bn_bwd_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int nparts, double count) {
+    // parameter gradients go straight to bn.weight.grad / bn.bias.grad; c1/c2 stay in the workspace
+    if (!c.grads[b.p_g] || !c.grads[b.p_b]) return lf_fail("erfnet backward: BatchNorm weight/bias must both require grad");
+    return lf_bn_bwd_finalize(parts, nparts, b.C, count, c.at(b.c1), c.at(b.c2), c.grads[b.p_g], c.grads[b.p_b], c.st);
+}
+
+int backward_layers(const Ctx& c, const float* img, float* gA, float* gB, float* gC) {
+    // on entry gA holds d loss / d (output of the last block), NHWC
+    const lf_erfnet_plan* P = c.P;
+    const int N = P->N;
+    float* stat0 = c.at(P->off_stat0);
+    for (int li = (int)P->layers.size() - 1; li >= 0; --li) {
+        const Layer& L = P->layers[li];
+        const long npo = (long)N * L.Hout * L.Wout;
+        const long ppi = (long)L.Hout * L.Wout;
+        if (L.kind == K_NB) {
+            const float* x = c.at(L.x);
+            const float *t1 = c.at(L.b[0]), *t2 = c.at(L.b[1]), *t3 = c.at(L.b[2]), *t4 = c.at(L.b[3]), *out = c.at(L.b[4]);
+            const BNRef &b1 = L.bn[0], &b2 = L.bn[1];
+            const float* dm = (L.drop_idx >= 0 && c.dropmask) ? c.dropmask + P->drop_off[L.drop_idx] : nullptr;
+            const int rrows = lf_bn_bwd_reduce_rows(npo);
+            // bn2 + dropout + residual + relu backward
+            LF_TRY(lf_bn_bwd_reduce(gA, out, t4, c.at(b2.asc), c.at(b2.ash), dm, stat0, npo, L.Cout, ppi, c.st));
+            LfStatPart rp = {stat0, rrows, L.Cout, 0};
+            LF_TRY(bn_bwd_finalize(c, b2, &rp, 1, (double)npo));
+            LF_TRY(lf_bn_bwd_apply(gA, out, t4, c.at(b2.asc), c.at(b2.ash), c.params[b2.p_g], c.at(b2.c1), c.at(b2.c2), dm,
+                                   gB /*g_t4*/, gC /*g_z*/, npo, L.Cout, ppi, c.st));
+            // conv1x3_2: wgrad(t3, g_t4), dgrad -> g_t3 = (.) * [t3 > 0]
+            LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, gB, nullptr, nullptr, 0));
+            LfTapArgs a = no_args();
+            a.mask_src = t3;
+            LF_TRY(run_gemm(c, L.cv[3].dg[0], gB, gA, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
+            // conv3x1_2: input a = relu(bn1(t2)) recomputed on the fly
+            LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, gA, c.at(b1.sc), c.at(b1.sh), 0));
+            a = no_args();
+            a.aux = t2; a.msc = c.at(b1.sc); a.msh = c.at(b1.sh); a.asc = c.at(b1.asc); a.ash = c.at(b1.ash);
+            a.stats = stat0;
+            LF_TRY(run_gemm(c, L.cv[2].dg[0], gA, gB /*g_y1*/, nullptr, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, a));
+            LfStatPart sp = {stat0, lf_tapgemm_stat_rows(L.cv[2].dg[0].geom), L.Cout, 0};
+            LF_TRY(bn_bwd_finalize(c, b1, &sp, 1, (double)npo));
+            LF_TRY(lf_bn_bwd_apply(gB, nullptr, t2, c.at(b1.asc), c.at(b1.ash), c.params[b1.p_g], c.at(b1.c1), c.at(b1.c2),
+                                   nullptr, gA /*g_t2*/, nullptr, npo, L.Cout, ppi, c.st));
+            // conv1x3_1
+            LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, gA, nullptr, nullptr, 0));
+            a = no_args();
+            a.mask_src = t1;
+            LF_TRY(run_gemm(c, L.cv[1].dg[0], gA, gB /*g_t1*/, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
+            // conv3x1_1 (+ residual branch gradient g_z)
+            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, gB, nullptr, nullptr, 0));
+            a = no_args();
+            a.add_src = gC;
+            LF_TRY(run_gemm(c, L.cv[0].dg[0], gB, gA, nullptr, LF_PRO_NONE, LF_EPI_ADD, a));
+        } else {
+            // y = relu(bn(cpre)); gA = g_y
+            const BNRef& b = L.bn[0];
+            const float *cpre = c.at(L.b[0]), *y = c.at(L.b[1]);
+            LF_TRY(lf_bn_bwd_reduce(gA, y, cpre, c.at(b.asc), c.at(b.ash), nullptr, stat0, npo, L.Cout, ppi, c.st));
+            LfStatPart rp = {stat0, lf_bn_bwd_reduce_rows(npo), L.Cout, 0};
+            LF_TRY(bn_bwd_finalize(c, b, &rp, 1, (double)npo));
+            LF_TRY(lf_bn_bwd_apply(gA, y, cpre, c.at(b.asc), c.at(b.ash), c.params[b.p_g], c.at(b.c1), c.at(b.c2), nullptr,
+                                   gB /*g_cpre*/, nullptr, npo, L.Cout, ppi, c.st));
+            if (L.kind == K_UP) {
+                for (int ph = 0; ph < 4; ++ph) LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), gB, nullptr, nullptr, ph > 0));
+                LF_TRY(run_gemm(c, L.cv[0].dg[0], gB, gA, nullptr, LF_PRO_NONE, 0, no_args()));
+            } else if (L.x < 0) {
+                // stem: weight gradient only (the image needs no gradient)
+                const int Cc = 16 - L.Cin, rows = lf_stem_wgrad_rows(N, L.Hin, L.Win);
+                if (c.grads[L.cv[0].p_w]) {
+                    LF_TRY(lf_stem_wgrad(img, gB, N, L.Cin, L.Hin, L.Win, c.at(P->off_wpart), c.at(P->off_bpart), c.st));
+                    LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, Cc * L.Cin * 9, c.grads[L.cv[0].p_w], 0, c.st));
+                    if (c.grads[L.cv[0].p_b])
+                        LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, Cc, c.grads[L.cv[0].p_b], 0, c.st));
+                }
+            } else {
+                LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], c.at(L.x), gB, nullptr, nullptr, 0));
+                LF_TRY(lf_pool_bwd(c.at(L.x), gB, N, L.Hin, L.Win, L.Cin, L.Cout, L.Cout - L.Cin, gA, c.st));
+                for (int ph = 0; ph < 4; ++ph) {
+                    LfTapArgs a = no_args();
+                    a.add_src = gA;
+                    LF_TRY(run_gemm(c, L.cv[0].dg[ph], gB, gA, nullptr, LF_PRO_NONE, LF_EPI_ADD, a));
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+int upload_and_pack(const Ctx& c, const float* const* params_dev) {
+    const lf_erfnet_plan* P = c.P;
+    LfPackEntry* ent = reinterpret_cast<LfPackEntry*>(c.at(P->off_entries));
+    if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
+        return lf_fail("erfnet: upload of the pack table failed");
+    return lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Forward.  img (N,Cin,H,W) fp32 NCHW; params_host / params_dev: the n_params parameter tensors in
+// state_dict order (weights, biases, BN weight/bias; buffers excluded), as a HOST array and a DEVICE
+// array of device pointers; running_host: 2*n_bn device pointers (mean, var per BN, module order);
+// dropmask: device buffer of lf_erfnet_dropmask_floats() floats or NULL; head = 0 (output_conv) or 1
+// (output_conv2); logits out (N,Cout,H,W) NCHW; enc_out: optional NHWC->NCHW copy target is NOT
+// produced here (the encoder output stays in the workspace: lf_erfnet_export_encoder).
+int lf_erfnet_forward(const lf_erfnet_plan* P, const float* img, const float* const* params_host,
+                      const float* const* params_dev, float* const* running_host, const float* dropmask, int training,
+                      int head, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    LF_REQUIRE(P && img && params_host && params_dev && running_host && logits && workspace, "lf_erfnet_forward: null pointer");
+    LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_forward: workspace too small");
+    LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_forward: head %d out of range", head);
+    Ctx c{P, (float*)workspace, params_host, nullptr, running_host, dropmask, training, (hipStream_t)stream};
+    LF_TRY(upload_and_pack(c, params_dev));
+    LF_TRY(forward_layers(c, img));
+    return lf_head_fwd(c.at(P->head_in), params_host[P->p_head_w[head]], params_host[P->p_head_b[head]], logits, P->N, P->H / 2,
+                       P->W / 2, P->Cout + head, c.st);   // output_conv2 has one more channel (ERFNet.py:125-126)
+}
+
+// Backward of the forward that last used `workspace`.  grad_logits (N,Cout,H,W) NCHW;
+// grads_host: n_params device pointers receiving d loss / d param (NULL entries are skipped:
+// encoder.output_conv, the unused head).  Gradients are WRITTEN, not accumulated.
+int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* grad_logits,
+                       const float* const* params_host, float* const* grads_host, const float* dropmask, int head,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    LF_REQUIRE(P && img && grad_logits && params_host && grads_host && workspace, "lf_erfnet_backward: null pointer");
+    LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_backward: workspace too small");
+    LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_backward: head %d out of range", head);
+    Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, 1, (hipStream_t)stream};
+    float *gA = c.at(P->off_gA), *gB = c.at(P->off_gB), *gC = c.at(P->off_gC);
+    const int h = P->H / 2, w = P->W / 2, K = P->Cout + head;
+    const int pw = P->p_head_w[head], pb = P->p_head_b[head];
+    if (grads_host[pw]) {
+        const int rows = lf_head_wgrad_rows(P->N, h, w);
+        LF_TRY(lf_head_wgrad(c.at(P->head_in), grad_logits, c.at(P->off_wpart), c.at(P->off_bpart), P->N, h, w, K, c.st));
+        LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, 16 * K * 4, grads_host[pw], 0, c.st));
+        if (grads_host[pb]) LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, K, grads_host[pb], 0, c.st));
+    }
+    LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.st));
+    return backward_layers(c, img, gA, gB, gC);
+}
+
+// Copy an NHWC activation of the workspace to an NCHW tensor (encoder output for the drop-in tuple,
+// per-layer parity tests).
+int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+
+}  // extern "C"
+
+namespace {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ s, float* __restrict__ d, int H, int W,
+                                                          int C, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        long r = i / W;
+        const int h = (int)(r % H);
+        r /= H;
+        const int ch = (int)(r % C);
+        const long n = r / C;
+        d[i] = s[((n * H + h) * W + w) * C + ch];
+    }
+}
+}  // namespace
+
+extern "C" int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream) {
+    const long total = (long)N * H * W * C;
+    int grid = lf_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, total);
+    LF_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}

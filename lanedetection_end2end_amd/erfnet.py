@@ -1,0 +1,254 @@
+"""ERFNet backbone as an ``nn.Module`` whose forward/backward run in liblanefit_hip.so.
+
+Drop-in for the reference's ``Networks.ERFNet.Net`` (BEV/Networks/ERFNet.py:145-157): same
+constructor, same ``forward(input, flag, only_encode=False)``, same ``state_dict()`` keys and
+shapes (so reference checkpoints load and ``define_init_weights`` -- which matches on the class
+names 'Conv' / 'BatchNorm2d', BEV/Networks/utils.py:458-503 -- initialises it identically).
+The torch sub-modules below only HOLD parameters and buffers; no torch convolution is ever
+called.  One ``torch.autograd.Function`` spans the whole backbone: its forward and backward
+are single C-ABI calls (``lf_erfnet_forward`` / ``lf_erfnet_backward``).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_BN_EPS = 1e-3
+
+
+class _Holder(nn.Module):
+    """Parameter container; compute happens in the engine."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("lanefit ERFNet blocks hold parameters only; call the top-level Net")
+
+
+class DownsamplerBlock(_Holder):
+    """conv3x3 s2 (ninput -> noutput-ninput) || maxpool2 -> BN -> ReLU (ERFNet.py:11-22)."""
+
+    def __init__(self, ninput, noutput):
+        super().__init__()
+        self.conv = nn.Conv2d(ninput, noutput - ninput, (3, 3), stride=2, padding=1, bias=True)
+        self.pool = nn.MaxPool2d(2, stride=2)
+        self.bn = nn.BatchNorm2d(noutput, eps=_BN_EPS)
+
+
+class non_bottleneck_1d(_Holder):
+    """Factorised residual block: 3x1, 1x3, BN, dilated 3x1, 1x3, BN, Dropout2d (ERFNet.py:25-60)."""
+
+    def __init__(self, chann, dropprob, dilated):
+        super().__init__()
+        d = dilated
+        self.conv3x1_1 = nn.Conv2d(chann, chann, (3, 1), padding=(1, 0), bias=True)
+        self.conv1x3_1 = nn.Conv2d(chann, chann, (1, 3), padding=(0, 1), bias=True)
+        self.bn1 = nn.BatchNorm2d(chann, eps=_BN_EPS)
+        self.conv3x1_2 = nn.Conv2d(chann, chann, (3, 1), padding=(d, 0), bias=True, dilation=(d, 1))
+        self.conv1x3_2 = nn.Conv2d(chann, chann, (1, 3), padding=(0, d), bias=True, dilation=(1, d))
+        self.bn2 = nn.BatchNorm2d(chann, eps=_BN_EPS)
+        self.dropout = nn.Dropout2d(dropprob)
+        self._built_with_dropout = dropprob > 0      # the engine plan has a mask slot for these blocks
+
+
+class UpsamplerBlock(_Holder):
+    """ConvTranspose2d 3x3 s2 -> BN -> ReLU (ERFNet.py:98-107)."""
+
+    def __init__(self, ninput, noutput):
+        super().__init__()
+        self.conv = nn.ConvTranspose2d(ninput, noutput, 3, stride=2, padding=1, output_padding=1, bias=True)
+        self.bn = nn.BatchNorm2d(noutput, eps=_BN_EPS)
+
+
+class Encoder(_Holder):
+    def __init__(self, in_channels, num_classes):
+        super().__init__()
+        self.initial_block = DownsamplerBlock(in_channels, 16)
+        blocks = [DownsamplerBlock(16, 64)] + [non_bottleneck_1d(64, 0.03, 1) for _ in range(5)]
+        blocks.append(DownsamplerBlock(64, 128))
+        blocks += [non_bottleneck_1d(128, 0.3, d) for d in (2, 4, 8, 16, 2, 4, 8, 16)]
+        self.layers = nn.ModuleList(blocks)
+        # only used by the reference's only_encode=True path; never trained (ERFNet.py:84,92-93)
+        self.output_conv = nn.Conv2d(128, num_classes, 1, stride=1, padding=0, bias=True)
+
+
+class Decoder(_Holder):
+    def __init__(self, num_classes, pretrain):
+        super().__init__()
+        self.pretrain = pretrain
+        self.layers = nn.ModuleList([
+            UpsamplerBlock(128, 64), non_bottleneck_1d(64, 0, 1), non_bottleneck_1d(64, 0, 1),
+            UpsamplerBlock(64, 16), non_bottleneck_1d(16, 0, 1), non_bottleneck_1d(16, 0, 1)])
+        self.output_conv = nn.ConvTranspose2d(16, num_classes, 2, stride=2, padding=0, output_padding=0, bias=True)
+        if pretrain:
+            self.output_conv2 = nn.ConvTranspose2d(16, num_classes + 1, 2, stride=2, padding=0, output_padding=0,
+                                                   bias=True)
+
+
+class _Plan:
+    """Host-side engine plan for one input shape (owns the C object)."""
+
+    def __init__(self, N, H, W, cin, cout, n_heads):
+        lib = _lib.load()
+        self.handle = lib.lf_erfnet_plan_create(N, H, W, cin, cout, n_heads)
+        if not self.handle:
+            raise _lib.LaneFitLibraryError("lf_erfnet_plan_create: " + lib.lf_last_error().decode())
+        self.handle = ctypes.c_void_p(self.handle)
+        self.ws_bytes = lib.lf_erfnet_workspace_bytes(self.handle)
+        self.n_params = lib.lf_erfnet_num_params(self.handle)
+        self.n_bn = lib.lf_erfnet_num_bn(self.handle)
+        self.n_drop = lib.lf_erfnet_num_dropout(self.handle)
+        self.drop_floats = lib.lf_erfnet_dropmask_floats(self.handle)
+        self.drop_off = [lib.lf_erfnet_dropmask_offset(self.handle, i) for i in range(self.n_drop)]
+        self.drop_ch = [lib.lf_erfnet_dropmask_channels(self.handle, i) for i in range(self.n_drop)]
+        self.enc_off = lib.lf_erfnet_encoder_offset(self.handle)
+        self.shape = (N, H, W)
+
+    def __del__(self):
+        try:
+            _lib.load().lf_erfnet_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, plan, x, head, training, dropmask, *params):
+        lib = _lib.load()
+        N, H, W = plan.shape
+        dev = x.device
+        ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+        logits = torch.empty(N, net.out_channels + head, H, W, dtype=torch.float32, device=dev)
+        params = [p.detach() for p in params]
+        for p in params:
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+        host = _ptr_array(params)
+        devarr = net._device_ptr_table(params)
+        running = _ptr_array(net._running_buffers())
+        _lib.check(lib.lf_erfnet_forward(plan.handle, _lib.ptr(x), host, _lib.ptr(devarr), running,
+                                         _lib.ptr(dropmask), int(training), head, _lib.ptr(logits), _lib.ptr(ws),
+                                         plan.ws_bytes, _lib.stream()), "lf_erfnet_forward")
+        enc = torch.empty(N, 128, H // 8, W // 8, dtype=torch.float32, device=dev)
+        _lib.check(lib.lf_nhwc_to_nchw(ctypes.c_void_p(ws.data_ptr() + 4 * plan.enc_off), _lib.ptr(enc), N, H // 8,
+                                       W // 8, 128, _lib.stream()), "lf_nhwc_to_nchw")
+        ctx.net, ctx.plan, ctx.head, ctx.ws, ctx.x, ctx.dropmask = net, plan, head, ws, x, dropmask
+        ctx.params = params
+        ctx.mark_non_differentiable(enc)
+        return logits, enc
+
+    @staticmethod
+    def backward(ctx, glogits, _genc):
+        lib = _lib.load()
+        plan, params = ctx.plan, ctx.params
+        needs = ctx.needs_input_grad[6:]
+        used = ctx.net._used_param_mask(ctx.head)
+        grads = [torch.empty_like(p) if (n and u) else None for p, n, u in zip(params, needs, used)]
+        glogits = glogits.contiguous()
+        _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _ptr_array(params),
+                                          _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.head, _lib.ptr(ctx.ws),
+                                          plan.ws_bytes, _lib.stream()), "lf_erfnet_backward")
+        ctx.ws = None
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+class Net(nn.Module):
+    """``Net(layers=18, in_channels=1, out_channels=1, pretrained=False, pool=False)`` and
+    ``forward(input, flag, only_encode=False) -> (encoder_output, decoder_output)``
+    exactly as BEV/Networks/ERFNet.py:145-157.  ``three_outputs=True`` gives the BP variant's
+    ``(encoder_output, decoder_output, output_seg=None)`` (BP/Networks/ERFNet.py:170-176).
+
+    Deviations, all outside the training hot path: ``only_encode=True`` is not implemented;
+    ``encoder_output`` is returned detached (it only feeds the out-of-scope ``--clas`` heads);
+    no gradient is produced for the input image.
+    """
+    three_outputs = False
+
+    def __init__(self, layers=18, in_channels=1, out_channels=1, pretrained=False, pool=False):
+        super().__init__()
+        self.encoder = Encoder(in_channels, out_channels)
+        self.decoder = Decoder(out_channels, pretrained)
+        self.in_channels, self.out_channels, self.pretrained = in_channels, out_channels, bool(pretrained)
+        self._plans = {}
+        self._ptr_cache = (None, None)
+
+    # ---- bookkeeping -------------------------------------------------------------------
+    def _ordered_params(self):
+        return [p for _, p in self.named_parameters()]
+
+    def _running_buffers(self):
+        out = []
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                out += [m.running_mean, m.running_var]
+        return out
+
+    def _batchnorms(self):
+        return [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+
+    def _dropouts(self):
+        return [m.dropout for m in self.modules() if isinstance(m, non_bottleneck_1d) and m.dropout.p != 0]
+
+    def _used_param_mask(self, head):
+        names = [n for n, _ in self.named_parameters()]
+        unused_head = "decoder.output_conv." if head == 1 else "decoder.output_conv2."
+        return [not (n.startswith("encoder.output_conv.") or n.startswith(unused_head)) for n in names]
+
+    def _device_ptr_table(self, params):
+        key = tuple(p.data_ptr() for p in params)
+        if self._ptr_cache[0] != key:
+            self._ptr_cache = (key, torch.tensor(key, dtype=torch.int64, device=params[0].device))
+        return self._ptr_cache[1]
+
+    def _plan(self, N, H, W):
+        key = (N, H, W)
+        if key not in self._plans:
+            self._plans[key] = _Plan(N, H, W, self.in_channels, self.out_channels, 2 if self.pretrained else 1)
+        return self._plans[key]
+
+    def _make_dropmask(self, plan, device):
+        """Dropout2d keep-masks (N,C) per block with p > 0, drawn with torch's generator on the device."""
+        if plan.n_drop == 0:
+            return None
+        # the engine enumerates blocks built with p > 0; a block whose p was later set to 0 gets a mask of ones
+        built = [m for m in self.modules() if isinstance(m, non_bottleneck_1d) and m._built_with_dropout]
+        keep = torch.empty(plan.drop_floats, dtype=torch.float32, device=device)
+        N = plan.shape[0]
+        for m, off, ch in zip(built, plan.drop_off, plan.drop_ch):
+            p = float(m.dropout.p)
+            seg = keep[off: off + N * ch]
+            if p <= 0:
+                seg.fill_(1.0)
+            else:
+                seg.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+        return keep
+
+    # ---- forward -----------------------------------------------------------------------
+    def forward(self, input, flag, only_encode=False):
+        if only_encode:
+            raise NotImplementedError("lanefit ERFNet: only_encode=True (encoder.output_conv) is outside the "
+                                      "accelerated hot path")
+        if not input.is_cuda:
+            raise _lib.LaneFitLibraryError("lanefit ERFNet needs its input on the MI355X; there is no CPU path")
+        x = input.contiguous().float()
+        N, C, H, W = x.shape
+        assert C == self.in_channels, "expected %d input channels, got %d" % (self.in_channels, C)
+        plan = self._plan(N, H, W)
+        head = 0
+        if self.pretrained and not flag:
+            head = 1                                  # Decoder.forward: flag selects output_conv (ERFNet.py:134-141)
+        dropmask = self._make_dropmask(plan, x.device) if self.training else None
+        params = self._ordered_params()
+        logits, enc = _BackboneFn.apply(self, plan, x, head, self.training, dropmask, *params)
+        if self.training:
+            torch._foreach_add_([m.num_batches_tracked for m in self._batchnorms()], 1)
+        if self.three_outputs:
+            return enc, logits, None
+        return enc, logits
+

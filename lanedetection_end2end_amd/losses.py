@@ -1,0 +1,127 @@
+"""Loss modules with the reference's names and call signatures (BEV/Loss_crit.py, BP/Loss_crit.py),
+computed by liblanefit_hip.so."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import geometry, ops
+
+
+class polynomial():
+    """Trapezoid-rule area metric of the reference (BEV/Loss_crit.py:12-35), vectorised.
+
+    Works on whatever device the coefficients live on (the reference calls it on ``.cpu()``
+    tensors after every step, BEV/main.py:273-280; passing GPU tensors removes those syncs).
+    """
+
+    def __init__(self, coeffs, a=0, b=0.7, n=100):
+        c = coeffs.reshape(coeffs.shape[0], -1)
+        self.a1, self.b1, self.c1 = c[:, 0], c[:, 1], c[:, 2]
+        self.a, self.b, self.n = a, b, n
+
+    def calc_pol(self, x):
+        return self.a1 * x ** 2 + self.b1 * x + self.c1
+
+    def trapezoidal(self, other):
+        h = float(self.b - self.a) / self.n
+        xs = self.a + h * torch.arange(0, self.n + 1, device=self.a1.device, dtype=self.a1.dtype)
+        d = (self.calc_pol(xs[:, None]) - other.calc_pol(xs[:, None])).abs()
+        w = torch.ones_like(xs)
+        w[0] = w[-1] = 0.5
+        return (d * w[:, None]).sum(0) * h
+
+
+class Area_Loss(nn.Module):
+    """Integral of the squared x-difference between fitted and ground-truth curves over
+    y in [0, 0.7], three weightings; ``forward(params, gt_params, compute=True)``
+    (BEV/Loss_crit.py:78-134).  Deviation: when no lane is kept the reference returns the
+    Python int 0; this returns a zero tensor (still differentiable, gradient 0)."""
+
+    def __init__(self, order, weight_funct):
+        super().__init__()
+        if order not in (1, 2):
+            raise NotImplementedError('The requested order is not implemented')
+        if weight_funct not in ops.WEIGHT_FUNCTS:
+            raise NotImplementedError('The requested weight function is not implemented')
+        self.order = order
+        self.weight_funct = weight_funct
+
+    def forward(self, params, gt_params, compute=True):
+        return ops.AreaLossFn.apply(params, gt_params, self.order, ops.WEIGHT_FUNCTS[self.weight_funct])
+
+
+class MSE_Loss(nn.Module):
+    """MSE on curve parameters (BEV/Loss_crit.py:137-150) -- "next" row, plain torch."""
+
+    def __init__(self, options=None):
+        super().__init__()
+        self.loss_crit = nn.MSELoss()
+
+    def forward(self, params, gt_params, compute=True):
+        return self.loss_crit(params.squeeze(-1), gt_params)
+
+
+class CrossEntropyLoss2d(nn.Module):
+    """Class-weighted pixel cross entropy (BEV/Loss_crit.py:61-75): weights [1, w, w],
+    target = targets[:, 0].  ``nclasses`` generalises to BP's [1] + [w]*nclasses (:64)."""
+
+    def __init__(self, weight=None, size_average=True, seg=False, nclasses=2):
+        super().__init__()
+        w = [1.0] + [float(weight)] * nclasses if seg else [1.0] * (nclasses + 1)
+        self.register_buffer("weights", torch.tensor(w, dtype=torch.float32), persistent=False)
+
+    def forward(self, inputs, targets):
+        if targets.dim() == 4:
+            targets = targets[:, 0, :, :]
+        return ops.CrossEntropy2dFn.apply(inputs, targets.long(), self.weights)
+
+
+class backprojection_loss(nn.Module):
+    """MSE in image space after back-projecting 56 sampled curve points through M^-1
+    (BP/Loss_crit.py:161-218).  ``forward(params, x_gt, valid_samples) -> (loss, x_cal*valid)``."""
+
+    def __init__(self, options):
+        super().__init__()
+        M, M_inv = geometry.get_homography(options.resize, getattr(options, "no_mapping", False))
+        self.M, self.M_inv = torch.from_numpy(M), np.ascontiguousarray(M_inv, dtype=np.float64)
+        order = options.order
+        if order < 0 or order > 3:
+            raise NotImplementedError(
+                'Requested order {} for polynomial fit is not implemented'.format(order))
+        y_d = (torch.arange(160, 720, 10) - 80).double() / 2.5           # :170-173 (literal 80 / 2.5)
+        y_prime = (M[1, 1] * y_d + M[1, 2]) / (M[2, 1] * y_d + M[2, 2])   # :175
+        y_eval = 255 - y_prime                                            # :176 (literal 255)
+        Y = torch.stack([y_eval ** (order - j) for j in range(order + 1)], 1)
+        dev = "cpu" if getattr(options, "no_cuda", False) else "cuda"
+        self.Y = Y.contiguous().to(dev)
+        self.y_prime = y_prime.contiguous().to(dev)
+        self.order = order
+
+    def forward(self, params, x_gt, valid_samples):
+        return ops.BackprojLossFn.apply(params, x_gt, valid_samples, self.Y, self.y_prime, self.M_inv)
+
+
+def define_loss_crit_bev(options):
+    """BEV/Loss_crit.py:45-58."""
+    if options.loss_policy == 'mse':
+        crit = MSE_Loss(options)
+    elif options.loss_policy == 'area':
+        crit = Area_Loss(options.order, options.weight_funct)
+    else:
+        return NotImplementedError('The requested loss criterion is not implemented')
+    seg = CrossEntropyLoss2d(options.weight_seg, seg=True)
+    return crit, (seg if getattr(options, "no_cuda", False) else seg.cuda())
+
+
+def define_loss_crit_bp(options):
+    """BP/Loss_crit.py:47-67."""
+    if options.loss_policy == 'mse':
+        crit = MSE_Loss(options)
+    elif options.loss_policy == 'backproject':
+        crit = backprojection_loss(options)
+    elif options.loss_policy == 'area':
+        crit = Area_Loss(options.order, options.weight_funct)
+    else:
+        return NotImplementedError('The requested loss criterion is not implemented')
+    seg = CrossEntropyLoss2d(options.weight_seg, seg=True, nclasses=options.nclasses)
+    return crit, (seg if getattr(options, "no_cuda", False) else seg.cuda())

@@ -1,0 +1,142 @@
+"""The reference's ``LSQ_layer.Net`` wrappers (backbone -> activation -> row mask -> grid -> WLS),
+BEV flavour (normalised coordinates, fp32 betas) and BP flavour (pixel coordinates, fp64 betas).
+
+Reference: BEV/Networks/LSQ_layer.py:231-326, BP/Networks/LSQ_layer.py:210-315.
+"""
+from math import ceil
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import erfnet, fit, geometry
+
+
+def activation_layer(activation='square', no_cuda=False):
+    """Returns a callable like the reference's (LSQ_layer.py:43-63); inside ``Net`` the activation is
+    fused into the WLS kernel, this exists for API compatibility."""
+    table = {'sigmoid': torch.sigmoid, 'relu': torch.relu, 'softplus': nn.functional.softplus,
+             'square': lambda x: x ** 2, 'abs': torch.abs, 'none': lambda x: x}
+    if activation not in table:
+        raise NotImplementedError('Activation type: {} is not implemented'.format(activation))
+    return table[activation]
+
+
+def define_model(mod, **kwargs):
+    """Backbone registry (BEV/Networks/__init__.py:9-20)."""
+    if mod not in model_dict:
+        raise KeyError("The requested model: {} is not implemented".format(mod))
+    return model_dict[mod](**kwargs)
+
+
+model_dict = {'erfnet': erfnet.Net}
+
+
+class _LaneFitNet(nn.Module):
+    normalised = True
+    y_offset = 1.0
+    beta_dtype = torch.float32
+    max_order = 2
+
+    def _common_init(self, args, M, backbone_cls):
+        self.nclasses = args.nclasses
+        self.order = args.order
+        if self.order < 0 or self.order > self.max_order:
+            raise NotImplementedError(
+                'Requested order {} for polynomial fit is not implemented'.format(self.order))
+        if getattr(args, "clas", False):
+            raise NotImplementedError("the --clas line/horizon heads are outside the accelerated hot path")
+        if getattr(args, "no_cuda", False):
+            raise RuntimeError("lanefit: no_cuda=True requested but this implementation has no CPU path")
+        out_channels = args.nclasses + int(not args.end_to_end)
+        self.net = backbone_cls(layers=args.layers, in_channels=args.channels_in, out_channels=out_channels,
+                                pretrained=args.pretrained, pool=args.pool)
+        self.activation_name = args.activation_layer
+        self.activation = activation_layer(args.activation_layer)
+        resize = args.resize
+        self.resize = resize
+        self.zero_rows = ceil(resize * args.mask_percentage)          # LSQ_layer.py:257
+        self.reg_ls = float(args.reg_ls)
+        self.use_cholesky = bool(args.use_cholesky)
+        self.end_to_end = args.end_to_end
+        self.pretrained = args.pretrained
+        self.classification_branch = False
+        self.check_singular = True      # False: skip the per-step D2H status read; inspect self.last_status
+        self.return_masked = True
+        self.last_status = None
+        # constant (H*W,2) grid, computed once on the host with the reference's fp32 ops
+        self._grid_cpu = geometry.projective_grid(resize, 2 * resize, M, self.normalised)
+        self._grid = None
+
+    def grid_on(self, device):
+        if self._grid is None or self._grid.device != device:
+            self._grid = self._grid_cpu.to(device)
+        return self._grid
+
+    def _seg_maps(self, output):
+        """Non-end-to-end path: arg-max of the segmentation logits -> per-lane maps valued k at class k
+        (LSQ_layer.py:302-308; BP :279-293), detached."""
+        act = output.detach().argmax(1).float()
+        ks = range(1, (2 if self.nclasses < 3 else 4) + 1)
+        return torch.stack([act * (act == k).float() for k in ks], 1)
+
+    def _fit(self, output, end_to_end, gt_line=None):
+        grid = self.grid_on(output.device)
+        if end_to_end:
+            beta, masked, status = fit.fit_lanes(output, grid, self.zero_rows, self.order, self.reg_ls, self.y_offset,
+                                                 self.activation_name, self.use_cholesky, self.return_masked,
+                                                 self.check_singular)
+        else:
+            maps = self._seg_maps(output)
+            maps[:, :, : self.zero_rows] = 0
+            if gt_line is not None and gt_line.sum() != 0:
+                # "Prevent singular matrix" (BP/Networks/LSQ_layer.py:308-311): absent lanes borrow map [0,0]
+                sel = gt_line.bool()
+                maps[sel] = maps[0, 0]
+            beta, _, status = fit.fit_lanes(maps, grid, 0, self.order, self.reg_ls, self.y_offset, "none",
+                                            self.use_cholesky, False, self.check_singular)
+            masked = maps
+        self.last_status = status
+        return fit.split_lanes(beta, self.nclasses, self.beta_dtype), masked
+
+
+class BEVNet(_LaneFitNet):
+    """``Net(args)``; ``forward(input, end_to_end) ->
+    (beta0, beta1, beta2, beta3, masked, M, output, line, horizon)`` (BEV/Networks/LSQ_layer.py:290-326)."""
+
+    def __init__(self, args):
+        super().__init__()
+        M, _ = geometry.bev_homography()
+        self._common_init(args, M, erfnet.Net)
+        self.M = torch.from_numpy(M).unsqueeze(0).expand(args.batch_size, 3, 3).float().cuda()
+
+    def forward(self, input, end_to_end):
+        shared_encoder, output = self.net(input, end_to_end * self.pretrained)
+        (b0, b1, b2, b3), masked = self._fit(output, end_to_end)
+        return b0, b1, b2, b3, masked, self.M, output, None, None
+
+
+class _BPBackbone(erfnet.Net):
+    three_outputs = True
+
+
+class BPNet(_LaneFitNet):
+    """``Net(args)``; ``forward(input, gt_line, end_to_end, early_return=False, gt=None) ->
+    (beta0..3, masked, output, line, horizon, output_seg)`` or bare ``output``
+    (BP/Networks/LSQ_layer.py:269-315).  Pixel coordinates, ``255 - y``, orders 0..3, fp64 betas."""
+    normalised = False
+    y_offset = 255.0
+    beta_dtype = torch.float64
+    max_order = 3
+
+    def __init__(self, args):
+        super().__init__()
+        M, _ = geometry.get_homography(args.resize, getattr(args, "no_mapping", False))
+        self._common_init(args, M, _BPBackbone)
+
+    def forward(self, input, gt_line, end_to_end, early_return=False, gt=None):
+        shared_encoder, output, output_seg = self.net(input, end_to_end * self.pretrained)
+        if early_return:
+            return output
+        (b0, b1, b2, b3), masked = self._fit(output, end_to_end, gt_line)
+        return b0, b1, b2, b3, masked, output, None, None, output_seg

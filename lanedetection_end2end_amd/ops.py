@@ -1,0 +1,157 @@
+"""torch.autograd.Function wrappers around the C ABI (fitting head and losses).
+
+Each Function only marshals pointers: all arithmetic happens in liblanefit_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_KINDS = {"square": 0, "abs": 1, "relu": 2, "sigmoid": 3, "softplus": 4, "none": 5}
+WEIGHT_FUNCTS = {"none": 0, "linear": 1, "quadratic": 2}
+
+
+class SingularMatrixError(RuntimeError):
+    """Raised like torch.inverse's error so `except RuntimeError` in the reference's main.py
+    (BEV/main.py:213-219) keeps skipping the batch."""
+
+
+def _raise_if_singular(status, solver):
+    bad = int(status.max().item())       # D2H sync, by design: the reference raises synchronously
+    if bad:
+        idx = int((status != 0).nonzero()[0, 0])
+        if bad == 2:
+            raise SingularMatrixError("lanefit WLS: normal matrix of (image,lane) #%d is not positive-definite "
+                                      "(Cholesky/GELS path)" % idx)
+        raise SingularMatrixError("lanefit WLS: normal matrix of (image,lane) #%d is singular, the inversion "
+                                  "could not be completed" % idx)
+
+
+class WLSFit(torch.autograd.Function):
+    """(logits NCHW fp32, grid (P,2)|(N,P,2) fp32) -> beta (N,K,order+1) fp64 [, masked (N,K,H,W) fp32]."""
+
+    @staticmethod
+    def forward(ctx, logits, grid, zero_rows, order, reg, y_offset, act_kind, solver, want_masked, check):
+        lib = _lib.load()
+        logits = logits.contiguous()
+        assert logits.dtype == torch.float32 and logits.dim() == 4
+        N, K, H, W = logits.shape
+        grid = grid.contiguous()
+        assert grid.dtype == torch.float32 and grid.shape[-2:] == (H * W, 2), (grid.shape, H, W)
+        gbs = H * W * 2 if grid.dim() == 3 and grid.shape[0] > 1 else 0
+        if grid.dim() == 3 and grid.shape[0] > 1:
+            assert grid.shape[0] >= N
+        D = order + 1
+        dev = logits.device
+        beta = torch.empty(N, K, D, dtype=torch.float64, device=dev)
+        zinv = torch.empty(N, K, D * D, dtype=torch.float64, device=dev)
+        status = torch.empty(N * K, dtype=torch.int32, device=dev)
+        masked = torch.empty_like(logits) if want_masked else None
+        ws = torch.empty(lib.lf_wls_workspace_bytes(N, K, order), dtype=torch.uint8, device=dev)
+        _lib.check(lib.lf_wls_fwd(_lib.ptr(logits), _lib.ptr(grid), gbs, N, K, H, W, zero_rows, order, float(reg),
+                                  float(y_offset), act_kind, solver, _lib.ptr(beta), _lib.ptr(zinv),
+                                  _lib.ptr(masked), _lib.ptr(ws), _lib.ptr(status), _lib.stream()), "lf_wls_fwd")
+        if check:
+            _raise_if_singular(status, solver)
+        ctx.save_for_backward(logits, grid, beta, zinv)
+        ctx.cfg = (gbs, zero_rows, order, float(y_offset), act_kind)
+        ctx.status = status
+        if want_masked:
+            ctx.mark_non_differentiable(masked)
+            return beta, masked, status
+        return beta, None, status
+
+    @staticmethod
+    def backward(ctx, gbeta, _gm, _gs):
+        lib = _lib.load()
+        logits, grid, beta, zinv = ctx.saved_tensors
+        gbs, zero_rows, order, y_offset, act_kind = ctx.cfg
+        N, K, H, W = logits.shape
+        gbeta = gbeta.to(torch.float64).contiguous()
+        gl = torch.empty_like(logits)
+        _lib.check(lib.lf_wls_bwd(_lib.ptr(logits), _lib.ptr(grid), gbs, N, K, H, W, zero_rows, order, y_offset,
+                                  act_kind, _lib.ptr(beta), _lib.ptr(zinv), _lib.ptr(gbeta), _lib.ptr(gl),
+                                  _lib.stream()), "lf_wls_bwd")
+        return gl, None, None, None, None, None, None, None, None, None
+
+
+class AreaLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, gt, order, weight_funct):
+        lib = _lib.load()
+        p = params.squeeze(-1) if params.dim() == 3 else params
+        p = p.contiguous()
+        gt = gt.to(p.dtype).contiguous()
+        assert p.dtype in (torch.float32, torch.float64) and p.shape == gt.shape and p.shape[1] == order + 1
+        loss = torch.empty((), dtype=p.dtype, device=p.device)
+        grad = torch.empty_like(p)
+        _lib.check(lib.lf_area_loss(_lib.ptr(p), p.shape[1], _lib.ptr(gt), p.shape[0], order, weight_funct,
+                                    1 if p.dtype == torch.float64 else 0, _lib.ptr(loss), _lib.ptr(grad),
+                                    _lib.stream()), "lf_area_loss")
+        ctx.save_for_backward(grad)
+        ctx.pshape = params.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return (grad * gout).view(ctx.pshape), None, None, None
+
+
+class BackprojLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, x_gt, valid, Y, y_prime, minv):
+        lib = _lib.load()
+        p = params.squeeze(-1) if params.dim() == 3 else params
+        p = p.to(torch.float64).contiguous()
+        x_gt = x_gt.to(torch.float64).contiguous()
+        valid = valid.to(torch.float64).contiguous()
+        N, D = p.shape
+        S = x_gt.shape[1]
+        loss = torch.empty((), dtype=torch.float64, device=p.device)
+        xcv = torch.empty(N, S, dtype=torch.float64, device=p.device)
+        grad = torch.empty(N, D, dtype=torch.float64, device=p.device)
+        m = (ctypes.c_double * 9)(*[float(v) for v in minv.reshape(-1)])
+        _lib.check(lib.lf_backproj_loss(_lib.ptr(p), D, _lib.ptr(x_gt), _lib.ptr(valid), _lib.ptr(Y),
+                                        _lib.ptr(y_prime), ctypes.cast(m, ctypes.c_void_p), N, S, D - 1,
+                                        _lib.ptr(loss), _lib.ptr(xcv), _lib.ptr(grad), _lib.stream()),
+                   "lf_backproj_loss")
+        ctx.save_for_backward(grad)
+        ctx.pshape, ctx.pdtype = params.shape, params.dtype
+        ctx.mark_non_differentiable(xcv)
+        return loss, xcv
+
+    @staticmethod
+    def backward(ctx, gout, _gx):
+        (grad,) = ctx.saved_tensors
+        return (grad * gout).view(ctx.pshape).to(ctx.pdtype), None, None, None, None, None
+
+
+class CrossEntropy2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weights):
+        lib = _lib.load()
+        logits = logits.contiguous()
+        target = target.contiguous()
+        weights = weights.to(device=logits.device, dtype=torch.float32).contiguous()
+        assert logits.dtype == torch.float32 and target.dtype == torch.int64
+        N, C, H, W = logits.shape
+        assert target.shape == (N, H, W), (target.shape, logits.shape)
+        acc = torch.empty(2, dtype=torch.float64, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        _lib.check(lib.lf_ce2d_fwd(_lib.ptr(logits), _lib.ptr(target), _lib.ptr(weights), N, C, H, W,
+                                   _lib.ptr(acc), _lib.ptr(loss), _lib.stream()), "lf_ce2d_fwd")
+        ctx.save_for_backward(logits, target, weights, acc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        logits, target, weights, acc = ctx.saved_tensors
+        N, C, H, W = logits.shape
+        up = gout.to(torch.float32).reshape(1).contiguous()
+        g = torch.empty_like(logits)
+        _lib.check(lib.lf_ce2d_bwd(_lib.ptr(logits), _lib.ptr(target), _lib.ptr(weights), N, C, H, W,
+                                   _lib.ptr(acc), _lib.ptr(up), _lib.ptr(g), _lib.stream()), "lf_ce2d_bwd")
+        return g, None, None

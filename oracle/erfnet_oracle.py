@@ -139,31 +139,37 @@ def _bn(x, P, prefix, training, stats_out):
     return xh * w[None, :, None, None] + b[None, :, None, None]
 
 
-def _down(x, P, p, training, stats_out):
+def _down(x, P, p, training, stats_out, taps=None):
     """DownsamplerBlock.forward -- ERFNet.py:19-22."""
     y = torch.cat([F.conv2d(x, P[p + ".conv.weight"], P[p + ".conv.bias"], stride=2, padding=1),
                    F.max_pool2d(x, 2, stride=2)], 1)
+    if taps is not None:
+        taps[p + "#0"] = y
     return F.relu(_bn(y, P, p + ".bn", training, stats_out))
 
 
-def _nb1d(x, P, p, d, training, stats_out, keep):
+def _nb1d(x, P, p, d, training, stats_out, keep, taps=None):
     """non_bottleneck_1d.forward -- ERFNet.py:44-60.  ``keep`` = (N,C) scaled keep-mask or None."""
-    y = F.relu(F.conv2d(x, P[p + ".conv3x1_1.weight"], P[p + ".conv3x1_1.bias"], padding=(1, 0)))
-    y = F.conv2d(y, P[p + ".conv1x3_1.weight"], P[p + ".conv1x3_1.bias"], padding=(0, 1))
-    y = F.relu(_bn(y, P, p + ".bn1", training, stats_out))
-    y = F.relu(F.conv2d(y, P[p + ".conv3x1_2.weight"], P[p + ".conv3x1_2.bias"],
-                        padding=(d, 0), dilation=(d, 1)))
-    y = F.conv2d(y, P[p + ".conv1x3_2.weight"], P[p + ".conv1x3_2.bias"], padding=(0, d), dilation=(1, d))
-    y = _bn(y, P, p + ".bn2", training, stats_out)
+    t1 = F.relu(F.conv2d(x, P[p + ".conv3x1_1.weight"], P[p + ".conv3x1_1.bias"], padding=(1, 0)))
+    t2 = F.conv2d(t1, P[p + ".conv1x3_1.weight"], P[p + ".conv1x3_1.bias"], padding=(0, 1))
+    y = F.relu(_bn(t2, P, p + ".bn1", training, stats_out))
+    t3 = F.relu(F.conv2d(y, P[p + ".conv3x1_2.weight"], P[p + ".conv3x1_2.bias"],
+                         padding=(d, 0), dilation=(d, 1)))
+    t4 = F.conv2d(t3, P[p + ".conv1x3_2.weight"], P[p + ".conv1x3_2.bias"], padding=(0, d), dilation=(1, d))
+    if taps is not None:
+        taps[p + "#0"], taps[p + "#1"], taps[p + "#2"], taps[p + "#3"] = t1, t2, t3, t4
+    y = _bn(t4, P, p + ".bn2", training, stats_out)
     if keep is not None:
         y = y * keep[:, :, None, None].to(y.dtype)
     return F.relu(y + x)
 
 
-def _up(x, P, p, training, stats_out):
+def _up(x, P, p, training, stats_out, taps=None):
     """UpsamplerBlock.forward -- ERFNet.py:104-107."""
     y = F.conv_transpose2d(x, P[p + ".conv.weight"], P[p + ".conv.bias"], stride=2, padding=1,
                            output_padding=1)
+    if taps is not None:
+        taps[p + "#0"] = y
     return F.relu(_bn(y, P, p + ".bn", training, stats_out))
 
 
@@ -174,7 +180,8 @@ def erfnet_forward(x, P, training=True, keep_masks=None, head="output_conv", sta
     ``keep_masks``: dict prefix -> (N,C) tensor holding 0 or 1/(1-p) per (sample, channel),
     i.e. what nn.Dropout2d draws (ERFNet.py:41,57-58); None => dropout disabled.
     ``head``: 'output_conv' or 'output_conv2' (Decoder.forward flag, :134-141).
-    ``taps``: optional dict filled with every block output (for per-layer parity tests).
+    ``taps``: optional dict filled with every block output (key = prefix) and the tensors inside the
+    block (key = prefix#slot: down/up pre-BN = #0; nb1d t1..t4 = #0..#3) for per-layer parity tests.
     """
     enc = None
     y = x
@@ -182,12 +189,12 @@ def erfnet_forward(x, P, training=True, keep_masks=None, head="output_conv", sta
         if prefix == "decoder.layers.0":
             enc = y
         if kind == "down":
-            y = _down(y, P, prefix, training, stats_out)
+            y = _down(y, P, prefix, training, stats_out, taps)
         elif kind == "nb1d":
             keep = None if keep_masks is None else keep_masks.get(prefix)
-            y = _nb1d(y, P, prefix, d, training, stats_out, keep)
+            y = _nb1d(y, P, prefix, d, training, stats_out, keep, taps)
         else:
-            y = _up(y, P, prefix, training, stats_out)
+            y = _up(y, P, prefix, training, stats_out, taps)
         if taps is not None:
             taps[prefix] = y
     dec = F.conv_transpose2d(y, P["decoder.%s.weight" % head], P["decoder.%s.bias" % head], stride=2)

@@ -1,0 +1,214 @@
+"""GPU parity: fused WLS kernels and the loss kernels (through the C ABI) vs the CPU oracle
+and vs golden vectors produced by the real reference.
+
+Tolerances (north_star: 1e-5 relative): the HIP path accumulates in fp64, so it is compared
+with the fp64 evaluation of the reference formula at 1e-6 or tighter; the reference's own
+fp32 result is compared at its measured noise floor (printed).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr
+from oracle import fit_oracle, inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.asarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+@pytest.fixture(scope="module")
+def lf():
+    import lanedetection_end2end_amd as pkg
+    from lanedetection_end2end_amd import fit, geometry, losses, ops
+    return type("ns", (), dict(pkg=pkg, fit=fit, geometry=geometry, losses=losses, ops=ops))
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("reg", [0.0, 1e-3])
+def test_wls_bev_vs_golden(lf, golden_fit, order, reg):
+    N, K, H, W = 2, 2, 64, 128
+    o = inputs.lane_like_logits(N, K, H, W, seed=11)
+    grid = golden_fit["bev_grid_64x128_f32"]
+    zr = fit_oracle.zero_rows_of(H, 0.3)
+    ot = dev(o).requires_grad_(True)
+    beta, masked, status = lf.fit.fit_lanes(ot, dev(grid), zr, order, reg, 1.0, "square")
+    gb = np.random.default_rng(5).standard_normal((2, N, order + 1, 1))[..., 0].transpose(1, 0, 2)
+    (beta * dev(gb)).sum().backward()
+    key = "bev_wls_o%d_r%g_" % (order, reg)
+    e64 = relerr(beta.detach().cpu(), golden_fit[key + "f64_beta"])
+    e32 = relerr(beta.detach().cpu(), golden_fit[key + "f32_beta"])
+    floor = relerr(golden_fit[key + "f32_beta"], golden_fit[key + "f64_beta"])
+    print("order %d reg %g: |hip-ref64| %.2e  |hip-ref32| %.2e  |ref32-ref64| %.2e" % (order, reg, e64, e32, floor))
+    assert e64 < 1e-6
+    assert e32 < 2 * floor + 1e-6
+    assert relerr(ot.grad.cpu(), golden_fit[key + "f64_grad"]) < 1e-5
+    assert int(status.abs().sum()) == 0
+    ref_masked = o.astype(np.float32) ** 2
+    ref_masked[:, :, :zr] = 0
+    assert np.array_equal(masked.cpu().numpy(), ref_masked)          # bit-exact: fp32 square + mask
+
+
+@pytest.mark.parametrize("order", [2, 3])
+@pytest.mark.parametrize("chol", [False, True])
+def test_wls_bp_vs_golden(lf, golden_fit, order, chol):
+    N, K, H, W = 1, 4, 256, 512
+    o = inputs.lane_like_logits(N, K, H, W, seed=12)
+    M, _ = lf.geometry.get_homography(256)
+    grid = lf.geometry.projective_grid(H, W, M, False)
+    zr = fit_oracle.zero_rows_of(H, 0.3)
+    ot = dev(o).requires_grad_(True)
+    beta, _, _ = lf.fit.fit_lanes(ot, grid.cuda(), zr, order, 0.0, 255.0, "square", use_cholesky=chol)
+    gb = np.random.default_rng(6).standard_normal((4, N, order + 1, 1))[..., 0].transpose(1, 0, 2)
+    (beta * dev(gb)).sum().backward()
+    key = "bp_wls_o%d_c0_f64" % order
+    ys = np.linspace(5, 175, 9)
+    Yv = np.stack([ys ** (order - j) for j in range(order + 1)], 1)
+    fa, fb = beta.detach().cpu().numpy() @ Yv.T, golden_fit[key + "_beta"] @ Yv.T
+    tol = 1e-6 if order == 2 else 1e-3          # cond(Z) ~ 1e8 / 5e12: see SURVEY 8c noise floor
+    assert np.abs(fa - fb).max() < tol * np.abs(fb).max()
+    assert relerr(ot.grad.cpu().numpy()[:, :, ::8, ::8], golden_fit[key + "_grad_sample"]) < 100 * tol
+
+
+@pytest.mark.parametrize("act", ["square", "abs", "relu", "sigmoid", "softplus", "none"])
+def test_wls_activations_vs_oracle(lf, act):
+    N, K, H, W = 3, 2, 32, 64
+    o = inputs.lane_like_logits(N, K, H, W, seed=3) + 0.2
+    M, _ = fit_oracle.bev_homography()
+    grid = fit_oracle.projective_grid(H, W, M.astype(np.float32), True, np.float32)
+    zr = 10
+    ot = dev(o).requires_grad_(True)
+    beta, _, _ = lf.fit.fit_lanes(ot, dev(grid), zr, 2, 0.0, 1.0, act)
+    gb = np.random.default_rng(1).standard_normal((N, K, 3))
+    (beta * dev(gb)).sum().backward()
+    c = fit_oracle.wls_forward(o, grid.astype(np.float64), zr, 2, 0.0, 1.0, act)
+    g = fit_oracle.wls_backward(c, gb)
+    assert relerr(beta.detach().cpu(), c["beta"]) < 1e-5
+    assert relerr(ot.grad.cpu(), g) < 1e-4
+
+
+def test_wls_full_size_and_known_answers(lf):
+    """C2-size maps.  Known answers of SURVEY 8c(ii),(iii); linearity-in-weight property:
+    scaling all logits of a lane by a constant does not change its beta."""
+    N, K, H, W = 32, 2, 256, 512
+    M, _ = lf.geometry.bev_homography()
+    grid = lf.geometry.projective_grid(H, W, M, True).cuda()
+    zr = 77
+    o = torch.ones(N, K, H, W, device="cuda")
+    col = torch.arange(W, device="cuda", dtype=torch.float32) / 511
+    # weight map W = col/511 (the WLS layer squares it again): logit = sqrt(W) under 'square'
+    o[1, 0] = (col ** 0.5)[None, :]
+    o[1, 1] = ((1 - col) ** 0.5)[None, :]
+    beta, _, _ = lf.fit.fit_lanes(o, grid, zr, 2, 0.0, 1.0, "square", return_masked=False)
+    b = beta.cpu().numpy()
+    assert np.allclose(b[0, 0], [1.3322623e-07, -1.2208050e-03, 0.49987791730], atol=2e-6)
+    assert np.allclose(b[1, 0], [2.6307e-07, 0.31158333448, 0.53115833822], atol=5e-6)
+    assert np.allclose(b[1, 1], [1.0515e-07, -0.31402500728, 0.46859750179], atol=5e-6)
+    o2 = torch.from_numpy(inputs.lane_like_logits(N, K, H, W, seed=8)).cuda()
+    b1, _, _ = lf.fit.fit_lanes(o2, grid, zr, 2, 0.0, 1.0, "square", return_masked=False)
+    b2, _, _ = lf.fit.fit_lanes(o2 * 1.7, grid, zr, 2, 0.0, 1.0, "square", return_masked=False)
+    assert relerr(b2.cpu(), b1.cpu()) < 1e-9
+    # determinism: identical bits on a second run
+    b3, _, _ = lf.fit.fit_lanes(o2, grid, zr, 2, 0.0, 1.0, "square", return_masked=False)
+    assert torch.equal(b1, b3)
+
+
+def test_wls_singular_raises(lf):
+    N, K, H, W = 2, 2, 32, 64
+    M, _ = lf.geometry.bev_homography()
+    grid = lf.geometry.projective_grid(H, W, M, True).cuda()
+    o = torch.zeros(N, K, H, W, device="cuda")          # all-zero weights: Z = 0
+    with pytest.raises(RuntimeError):
+        lf.fit.fit_lanes(o, grid, 8, 2, 0.0, 1.0, "square")
+    beta, _, status = lf.fit.fit_lanes(o, grid, 8, 2, 0.0, 1.0, "square", check_singular=False)
+    assert status.cpu().tolist() == [1] * (N * K)
+    with pytest.raises(RuntimeError):
+        lf.fit.fit_lanes(o, grid, 8, 2, 0.0, 1.0, "square", use_cholesky=True)
+    # reg_ls makes it solvable, beta = 0
+    beta, _, status = lf.fit.fit_lanes(o, grid, 8, 2, 1e-3, 1.0, "square")
+    assert float(beta.abs().max()) == 0.0
+
+
+def test_wls_module_surface(lf, golden_fit):
+    """Reference-compatible Weighted_least_squares.forward(W, grid) -> 4-tuple."""
+    from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Weighted_least_squares
+    N, K, H, W = 2, 2, 64, 128
+    o = inputs.lane_like_logits(N, K, H, W, seed=11)
+    zr = fit_oracle.zero_rows_of(H, 0.3)
+    masked = o ** 2
+    masked[:, :, :zr] = 0
+    grid = dev(golden_fit["bev_grid_64x128_f32"]).unsqueeze(0).expand(N, -1, -1)
+    ls = Weighted_least_squares(torch.Size([N, K, H, W]), K, 2, False, 0, False)
+    b0, b1, b2, b3 = ls(dev(masked), grid)
+    assert b2 is None and b3 is None and b0.shape == (N, 3, 1) and b0.dtype == torch.float32
+    ref = golden_fit["bev_wls_o2_r0_f64_beta"]
+    assert relerr(torch.stack([b0, b1], 1)[..., 0].cpu(), ref) < 1e-6
+
+
+@pytest.mark.parametrize("order,wf", [(2, "none"), (2, "linear"), (2, "quadratic"), (1, "none")])
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f64", torch.float64)])
+def test_area_loss(lf, golden_fit, order, wf, tag, dtype):
+    beta = golden_fit["area_beta"][:, : order + 1]
+    gt = golden_fit["area_gt"][:, : order + 1]
+    b = dev(beta, dtype).requires_grad_(True)
+    L = lf.losses.Area_Loss(order, wf)(b, dev(gt, dtype))
+    (3.0 * L).backward()
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    assert abs(float(L) - golden_fit["area_o%d_%s_f64_loss" % (order, wf)]) < tol
+    assert relerr(b.grad.cpu() / 3.0, golden_fit["area_o%d_%s_f64_grad" % (order, wf)]) < max(tol, 1e-10) * 10
+    assert L.dtype == dtype and b.grad.shape == b.shape
+
+
+def test_area_loss_no_lane(lf):
+    b = torch.rand(4, 3, 1, device="cuda", requires_grad=True)
+    L = lf.losses.Area_Loss(2, "none")(b, torch.zeros(4, 3, device="cuda"))
+    L.backward()
+    assert float(L) == 0.0 and float(b.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("order", [2, 3])
+def test_backproj_loss(lf, golden_fit, order):
+    from argparse import Namespace
+    crit = lf.losses.backprojection_loss(Namespace(resize=256, no_mapping=False, order=order, batch_size=6,
+                                                   no_cuda=False))
+    assert relerr(crit.y_prime.cpu(), golden_fit["bp_yprime_o%d" % order]) < 1e-12
+    lanes, valid = inputs.bp_targets(6, 1, 256, seed=31)
+    b = dev(golden_fit["bp_loss_o%d_beta" % order]).requires_grad_(True)
+    L, xc = crit(b, dev(lanes[:, 0]), dev(valid[:, 0]))
+    L.backward()
+    assert abs(float(L) - golden_fit["bp_loss_o%d_loss" % order]) < 1e-10 * abs(float(L))
+    assert relerr(xc.cpu(), golden_fit["bp_loss_o%d_xcal" % order]) < 1e-12
+    assert relerr(b.grad.cpu(), golden_fit["bp_loss_o%d_grad" % order]) < 1e-10
+    L0, _ = crit(b, dev(lanes[:, 0]), dev(valid[:, 0] * 0))
+    assert float(L0) == 0.0
+
+
+def test_cross_entropy(lf, golden_fit):
+    tgt = inputs.seg_targets(2, 8, 16, 3, seed=41)
+    z = dev(golden_fit["ce_logits"]).requires_grad_(True)
+    crit = lf.losses.CrossEntropyLoss2d(30, seg=True).cuda()
+    L = crit(z, dev(tgt).unsqueeze(1))
+    L.backward()
+    assert abs(float(L) - float(golden_fit["ce_loss"])) < 2e-6 * abs(float(L))
+    assert relerr(z.grad.cpu(), golden_fit["ce_grad"]) < 5e-6
+    # config-5-like size vs oracle
+    N, C, H, W = 2, 3, 128, 256
+    zz = np.random.default_rng(4).standard_normal((N, C, H, W)).astype(np.float32) * 3
+    tt = inputs.seg_targets(N, H, W, C, seed=42)
+    z2 = dev(zz).requires_grad_(True)
+    L2 = crit(z2, dev(tt))
+    L2.backward()
+    Lo, go = fit_oracle.cross_entropy_2d(zz, tt, [1, 30, 30])
+    assert abs(float(L2) - Lo) < 1e-5 * Lo and relerr(z2.grad.cpu(), go) < 1e-5
+
+
+def test_trapezoid_metric(lf, golden_fit):
+    b = torch.tensor([[0.1, -0.2, 0.5], [0, 0.1, 0.4]], dtype=torch.float64, device="cuda")
+    g = torch.tensor([[0.05, -0.1, 0.45], [0.01, 0.2, 0.5]], dtype=torch.float64, device="cuda")
+    tz = lf.losses.polynomial(b.unsqueeze(2)).trapezoidal(lf.losses.polynomial(g))
+    assert np.allclose(tz.cpu().numpy(), golden_fit["trapezoid_survey"], atol=1e-12)
