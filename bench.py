@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path (BASELINE.json metric): images/sec forward+backward of
+BEV ERFNet -> fused WLS lane fit -> Area loss, 256x512, 2 lanes, batch 32 per GPU, fp32.
+
+    python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run)
+
+A step = model(x, True) -> loss = criterion(beta0, gt0) + criterion(beta1, gt1) -> grads to zero ->
+loss.backward() [-> one flat RCCL all-reduce of the gradients when N > 1].  The optimizer is excluded
+(SURVEY.md 8d).  Inputs are synthetic and resident in HBM before the timed region.  Prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMG_FWD_BWD = 39.67e9      # conv FLOPs, BASELINE.md section 2 (256x512, Cout = 2)
+PEAK_FP32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def make_args(batch):
+    return Namespace(batch_size=batch, nclasses=2, resize=256, end_to_end=True, mod="erfnet", layers=18, channels_in=3,
+                     pretrained=False, pool=True, activation_layer="square", no_cuda=False, order=2, reg_ls=0.0,
+                     use_cholesky=False, mask_percentage=0.3, clas=False, loss_policy="area", weight_funct="none",
+                     weight_seg=30)
+
+
+def build_model(batch, seed):
+    from lanedetection_end2end_amd.bev.Loss_crit import Area_Loss
+    from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Net
+    torch.manual_seed(seed)
+    model = Net(make_args(batch))
+
+    def kaiming(m):            # the reference's weights_init_kaiming (BEV/Networks/utils.py:490-503)
+        n = m.__class__.__name__
+        if n.find('Conv') != -1:
+            torch.nn.init.kaiming_normal_(m.weight.data, a=0, mode='fan_in', nonlinearity='relu')
+            m.bias.data.zero_()
+        elif n.find('BatchNorm2d') != -1:
+            torch.nn.init.normal_(m.weight.data, 1.0, 0.02)
+            torch.nn.init.constant_(m.bias.data, 0.0)
+    model.apply(kaiming)
+    return model.cuda().train(), Area_Loss(2, "none")
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle ("port": torch-CPU functional ERFNet + numpy WLS/area loss with analytic backward)
+    timed on this box's host cores on a bounded sample: batch 4 (config C1), as many steps as fit the budget."""
+    from oracle import erfnet_oracle, fit_oracle, inputs
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    N, R = 4, 256
+    P = erfnet_oracle.make_params(seed=4, out_channels=2)
+    for k, v in P.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    x = torch.from_numpy(inputs.images(N, R, 2 * R, seed=61))
+    gt = inputs.bev_gt_params(N, seed=62)
+    M, _ = fit_oracle.bev_homography()
+    grid = fit_oracle.projective_grid(R, 2 * R, M.astype(np.float32), True, np.float32)
+
+    def step():
+        for v in P.values():
+            if v.is_floating_point() and v.grad is not None:
+                v.grad = None
+        _, dec = erfnet_oracle.erfnet_forward(x, P, training=True)
+        c = fit_oracle.wls_forward(dec.detach().numpy(), grid, 77, 2, 0.0, 1.0, "square")
+        gb = np.zeros_like(c["beta"])
+        loss = 0.0
+        for k in range(2):
+            l, g = fit_oracle.area_loss(c["beta"][:, k], gt[:, k], 2, "none")
+            loss += l
+            gb[:, k] = g
+        dec.backward(torch.from_numpy(fit_oracle.wls_backward(c, gb)).float())
+        return loss
+    step()
+    times = []
+    t_end = time.perf_counter() + seconds_budget
+    while time.perf_counter() < t_end and len(times) < 20:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(N / med, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "batch 4, 256x512, 2 lanes, fp32 backbone + fp64 fit, %d steps, median" % len(times)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="disable Dropout2d (parity-style run)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")      # RCCL over xGMI
+
+    from lanedetection_end2end_amd import _lib
+    from oracle import inputs
+    B = a.batch
+    model, crit = build_model(B, seed=0)     # identical weights on every rank (same seed)
+    if a.no_dropout:
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0
+    model.check_singular = False             # no per-step D2H read; status is checked after the timed region
+    x = torch.from_numpy(inputs.images(B, 256, 512, seed=100 + rank)).cuda()
+    gt = torch.from_numpy(inputs.bev_gt_params(B, seed=200 + rank)).cuda()
+    params = [p for p in model.parameters()]
+    flat = None
+    statuses = []
+
+    def step():
+        b0, b1, _, _, _, _, _, _, _ = model(x, True)
+        loss = crit(b0, gt[:, 0]) + crit(b1, gt[:, 1])
+        for p in params:
+            p.grad = None
+        loss.backward()
+        statuses.append(model.last_status)
+        if world > 1:
+            nonlocal flat
+            gs = [p.grad for p in params if p.grad is not None]
+            flat = torch._utils._flatten_dense_tensors(gs)
+            dist.all_reduce(flat)
+            flat.div_(world)
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    statuses.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    bad = int(torch.stack(statuses).abs().sum())
+    if bad or not torch.isfinite(loss):
+        raise SystemExit("bench: singular normal matrix / non-finite loss inside the timed region")
+
+    out = None
+    if rank == 0:
+        ips = world * B * a.steps / dt
+        # ---- roofline of the dominant kernel family: extra steps with HIP events around every MFMA launch
+        lib = _lib.load()
+        plan = model.net._plan(B, 256, 512)
+        lib.lf_erfnet_profile(plan.handle, 1)
+        psteps = 3
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
+        buf = (ctypes.c_double * 6)()
+        lib.lf_erfnet_profile_read(plan.handle, ctypes.cast(buf, ctypes.c_void_p))
+        lib.lf_erfnet_profile(plan.handle, 0)
+        fam = [dict(ms=buf[i * 3], flops=buf[i * 3 + 1], launches=buf[i * 3 + 2]) for i in range(2)]
+        names = ["tapgemm_kernel (conv forward + data gradient)", "tapwgrad_kernel (weight gradient)"]
+        dom = 0 if fam[0]["ms"] >= fam[1]["ms"] else 1
+        d = fam[dom]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA / 1e12,
+                    "unit": "TFLOP/s", "frac": round(ach / (PEAK_FP32_MFMA / 1e12), 4), "traffic": None,
+                    "avg_launch_us": round(1e3 * d["ms"] / max(d["launches"], 1), 2),
+                    "launches_per_step": d["launches"] / psteps,
+                    "families": {names[i]: {"ms_per_step": round(fam[i]["ms"] / psteps, 3),
+                                            "tflops": round(fam[i]["flops"] / max(fam[i]["ms"], 1e-9) / 1e9, 2)}
+                                 for i in range(2)},
+                    "whole_step_frac_of_conv_roofline": round(ips * FLOP_PER_IMG_FWD_BWD / world / PEAK_FP32_MFMA, 4)}
+        out = {"metric": "images/sec fwd+bwd, 256x512 2-lane bs32", "value": round(ips, 2), "unit": "images/sec",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BEV ERFNet + fused WLS fit + Area loss, 2 lanes, 256x512, batch %d per GPU, "
+                                      "fp32, train mode (BN batch stats, Dropout2d %s), fwd+bwd, optimizer excluded"
+                                      % (B, "off" if a.no_dropout else "on"),
+                          "global_batch": world * B, "parallelism": "dp%d" % world,
+                          "grad_allreduce": "flat fp32 bucket, RCCL" if world > 1 else "none"},
+               "roofline": roofline}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -139,6 +139,11 @@ int lf_erfnet_backward(const lf_erfnet_plan* plan, const float* img, const float
                        const float* const* params_host, float* const* grads_host, const float* dropmask, int head,
                        void* workspace, size_t workspace_bytes, void* stream);
 int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+/* Roofline instrumentation (bench.py): HIP event pairs around every matrix-core launch of the engine.
+ * out6 = {ms, algorithmic FLOPs, launches} for family 0 (tap-GEMM forward + data gradient) and
+ * family 1 (weight gradient), accumulated since the last read. */
+int lf_erfnet_profile(const lf_erfnet_plan* plan, int enable);
+int lf_erfnet_profile_read(const lf_erfnet_plan* plan, double* out6_host);
 
 #ifdef __cplusplus
 }

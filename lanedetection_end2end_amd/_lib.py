@@ -44,6 +44,8 @@ def _declare(lib):
         "lf_erfnet_forward": (I, [P, P, P, P, P, P, I, I, P, P, c_size_t, P]),
         "lf_erfnet_backward": (I, [P, P, P, P, P, P, I, P, c_size_t, P]),
         "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
+        "lf_erfnet_profile": (I, [P, I]),
+        "lf_erfnet_profile_read": (I, [P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

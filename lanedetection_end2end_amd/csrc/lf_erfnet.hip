@@ -60,6 +60,10 @@ struct lf_erfnet_plan {
     long head_in;                               // activation feeding the head
     std::vector<long> drop_off;                 // per dropout block: float offset into the mask buffer
     long drop_floats;
+    // optional per-kernel-family timing (bench.py roofline): HIP events around every MFMA launch
+    mutable int prof_on = 0;
+    struct ProfRec { hipEvent_t a, b; int family; double flops; };
+    mutable std::vector<ProfRec> prof;
 };
 
 namespace {
@@ -350,9 +354,26 @@ struct Ctx {
         if (rc_ != 0) return rc_; \
     } while (0)
 
+double gemm_flops(const LfTapGeom& g) { return 2.0 * (double)g.N * g.Hl * g.Wl * g.Cs * g.Cd * g.ntaps; }
+
+struct ProfScope {   // records a HIP event pair on the launch stream around one kernel when profiling is on
+    const Ctx& c; int idx = -1;
+    ProfScope(const Ctx& ctx, int family, double flops) : c(ctx) {
+        if (!c.P->prof_on) return;
+        lf_erfnet_plan::ProfRec r;
+        r.family = family; r.flops = flops;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        (void)hipEventRecord(r.a, c.st);
+        c.P->prof.push_back(r);
+        idx = (int)c.P->prof.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c.P->prof[idx].b, c.st); }
+};
+
 int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const float* bias, int pro, int epi,
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
+    ProfScope ps(c, 0, gemm_flops(op.geom));
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
 }
 
@@ -440,7 +461,10 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh;
     a.partial = c.at(P->off_wpart);
     a.bias_partial = c.grads[cv.p_b] ? c.at(P->off_bpart) : nullptr;
-    LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, c.st));
+    {
+        ProfScope ps(c, 1, gemm_flops(op.geom));
+        LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, c.st));
+    }
     const LfPackEntry& e = P->packs[op.pack];
     LF_TRY(lf_wgrad_reduce_launch(a.partial, lf_tapwgrad_splits(op.geom), op.geom.ntaps, op.geom.Cs, op.geom.Cd,
                                   c.grads[cv.p_w], e.sk, e.sn, e.tapidx, c.st));
@@ -589,6 +613,24 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
     }
     LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.st));
     return backward_layers(c, img, gA, gB, gC);
+}
+
+// Per-kernel-family timing for the roofline report.  enable=1 starts recording a HIP event pair around
+// every tap-GEMM (family 0: forward + data-gradient) and weight-gradient (family 1) launch of subsequent
+// forward/backward calls; lf_erfnet_profile_read waits for them, adds up elapsed ms, algorithmic FLOPs
+// (2 * pixels * Cs * Cd * taps) and launch counts per family (3 doubles each), and clears the records.
+int lf_erfnet_profile(const lf_erfnet_plan* P, int enable) { P->prof_on = enable; return 0; }
+int lf_erfnet_profile_read(const lf_erfnet_plan* P, double* out6) {
+    for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+    for (auto& r : P->prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            out6[r.family * 3 + 0] += ms; out6[r.family * 3 + 1] += r.flops; out6[r.family * 3 + 2] += 1.0;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    P->prof.clear();
+    return 0;
 }
 
 // Copy an NHWC activation of the workspace to an NCHW tensor (encoder output for the drop-in tuple,

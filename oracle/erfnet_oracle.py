@@ -118,6 +118,17 @@ def make_params(seed=0, in_channels=3, out_channels=2, pretrained=False, bias_sc
     return out
 
 
+def _tap(taps, override, key, t):
+    """Record tensor ``t`` under ``key``; with ``override`` replace its VALUE by override[key] while
+    keeping the autograd graph (straight-through): lets a test evaluate the fp64 backward at exactly
+    the forward state another implementation produced (identical ReLU masks / saved tensors)."""
+    if override is not None and key in override:
+        t = t + (override[key].to(t.dtype) - t).detach()
+    if taps is not None:
+        taps[key] = t
+    return t
+
+
 def _bn(x, P, prefix, training, stats_out):
     """nn.BatchNorm2d(eps=1e-3): batch stats in train mode, running stats in eval."""
     w, b = P[prefix + ".weight"], P[prefix + ".bias"]
@@ -139,42 +150,42 @@ def _bn(x, P, prefix, training, stats_out):
     return xh * w[None, :, None, None] + b[None, :, None, None]
 
 
-def _down(x, P, p, training, stats_out, taps=None):
+def _down(x, P, p, training, stats_out, taps=None, override=None):
     """DownsamplerBlock.forward -- ERFNet.py:19-22."""
     y = torch.cat([F.conv2d(x, P[p + ".conv.weight"], P[p + ".conv.bias"], stride=2, padding=1),
                    F.max_pool2d(x, 2, stride=2)], 1)
-    if taps is not None:
-        taps[p + "#0"] = y
+    y = _tap(taps, override, p + "#0", y)
     return F.relu(_bn(y, P, p + ".bn", training, stats_out))
 
 
-def _nb1d(x, P, p, d, training, stats_out, keep, taps=None):
+def _nb1d(x, P, p, d, training, stats_out, keep, taps=None, override=None):
     """non_bottleneck_1d.forward -- ERFNet.py:44-60.  ``keep`` = (N,C) scaled keep-mask or None."""
     t1 = F.relu(F.conv2d(x, P[p + ".conv3x1_1.weight"], P[p + ".conv3x1_1.bias"], padding=(1, 0)))
+    t1 = _tap(taps, override, p + "#0", t1)
     t2 = F.conv2d(t1, P[p + ".conv1x3_1.weight"], P[p + ".conv1x3_1.bias"], padding=(0, 1))
+    t2 = _tap(taps, override, p + "#1", t2)
     y = F.relu(_bn(t2, P, p + ".bn1", training, stats_out))
     t3 = F.relu(F.conv2d(y, P[p + ".conv3x1_2.weight"], P[p + ".conv3x1_2.bias"],
                          padding=(d, 0), dilation=(d, 1)))
+    t3 = _tap(taps, override, p + "#2", t3)
     t4 = F.conv2d(t3, P[p + ".conv1x3_2.weight"], P[p + ".conv1x3_2.bias"], padding=(0, d), dilation=(1, d))
-    if taps is not None:
-        taps[p + "#0"], taps[p + "#1"], taps[p + "#2"], taps[p + "#3"] = t1, t2, t3, t4
+    t4 = _tap(taps, override, p + "#3", t4)
     y = _bn(t4, P, p + ".bn2", training, stats_out)
     if keep is not None:
         y = y * keep[:, :, None, None].to(y.dtype)
     return F.relu(y + x)
 
 
-def _up(x, P, p, training, stats_out, taps=None):
+def _up(x, P, p, training, stats_out, taps=None, override=None):
     """UpsamplerBlock.forward -- ERFNet.py:104-107."""
     y = F.conv_transpose2d(x, P[p + ".conv.weight"], P[p + ".conv.bias"], stride=2, padding=1,
                            output_padding=1)
-    if taps is not None:
-        taps[p + "#0"] = y
+    y = _tap(taps, override, p + "#0", y)
     return F.relu(_bn(y, P, p + ".bn", training, stats_out))
 
 
 def erfnet_forward(x, P, training=True, keep_masks=None, head="output_conv", stats_out=None,
-                   taps=None):
+                   taps=None, override=None):
     """Net.forward(input, flag) -- ERFNet.py:151-157 -> (encoder_output, decoder_output).
 
     ``keep_masks``: dict prefix -> (N,C) tensor holding 0 or 1/(1-p) per (sample, channel),
@@ -182,6 +193,7 @@ def erfnet_forward(x, P, training=True, keep_masks=None, head="output_conv", sta
     ``head``: 'output_conv' or 'output_conv2' (Decoder.forward flag, :134-141).
     ``taps``: optional dict filled with every block output (key = prefix) and the tensors inside the
     block (key = prefix#slot: down/up pre-BN = #0; nb1d t1..t4 = #0..#3) for per-layer parity tests.
+    ``override``: dict with the same keys -> values substituted straight-through (see ``_tap``).
     """
     enc = None
     y = x
@@ -189,14 +201,13 @@ def erfnet_forward(x, P, training=True, keep_masks=None, head="output_conv", sta
         if prefix == "decoder.layers.0":
             enc = y
         if kind == "down":
-            y = _down(y, P, prefix, training, stats_out, taps)
+            y = _down(y, P, prefix, training, stats_out, taps, override)
         elif kind == "nb1d":
             keep = None if keep_masks is None else keep_masks.get(prefix)
-            y = _nb1d(y, P, prefix, d, training, stats_out, keep, taps)
+            y = _nb1d(y, P, prefix, d, training, stats_out, keep, taps, override)
         else:
-            y = _up(y, P, prefix, training, stats_out, taps)
-        if taps is not None:
-            taps[prefix] = y
+            y = _up(y, P, prefix, training, stats_out, taps, override)
+        y = _tap(taps, override, prefix, y)
     dec = F.conv_transpose2d(y, P["decoder.%s.weight" % head], P["decoder.%s.bias" % head], stride=2)
     return enc, dec
 
