@@ -213,4 +213,4 @@ def erfnet_forward(x, P, training=True, keep_masks=None, head="output_conv", sta
 
 
 def cast_params(P, dtype):
-    return OrderedDict((k, v.to(dtype) if v.is_floating_point() else v) for k, v in P.items())
+    return OrderedDict((k, v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in P.items())

@@ -44,10 +44,17 @@ def test_wls_bev_vs_golden(lf, golden_fit, order, reg):
     e64 = relerr(beta.detach().cpu(), golden_fit[key + "f64_beta"])
     e32 = relerr(beta.detach().cpu(), golden_fit[key + "f32_beta"])
     floor = relerr(golden_fit[key + "f32_beta"], golden_fit[key + "f64_beta"])
-    print("order %d reg %g: |hip-ref64| %.2e  |hip-ref32| %.2e  |ref32-ref64| %.2e" % (order, reg, e64, e32, floor))
-    assert e64 < 1e-6
+    # sharp: the fp64 formula on the SAME fp32 grid values the kernel reads (the golden fp64 run rebuilt its
+    # grid in fp64, a 6e-8 relative change of every coordinate that cond(Z) ~ 1e3 turns into ~1e-6 on beta)
+    c = fit_oracle.wls_forward(o, grid.astype(np.float64), zr, order, reg, 1.0, "square")
+    e_same = relerr(beta.detach().cpu(), c["beta"])
+    print("order %d reg %g: |hip-oracle(same grid)| %.2e |hip-ref64| %.2e  |hip-ref32| %.2e  |ref32-ref64| %.2e"
+          % (order, reg, e_same, e64, e32, floor))
+    assert e_same < 2e-7
+    assert e64 < 1e-5
     assert e32 < 2 * floor + 1e-6
-    assert relerr(ot.grad.cpu(), golden_fit[key + "f64_grad"]) < 1e-5
+    assert relerr(ot.grad.cpu(), fit_oracle.wls_backward(c, gb)) < 2e-6
+    assert relerr(ot.grad.cpu(), golden_fit[key + "f64_grad"]) < 1e-4
     assert int(status.abs().sum()) == 0
     ref_masked = o.astype(np.float32) ** 2
     ref_masked[:, :, :zr] = 0
@@ -112,7 +119,7 @@ def test_wls_full_size_and_known_answers(lf):
     o2 = torch.from_numpy(inputs.lane_like_logits(N, K, H, W, seed=8)).cuda()
     b1, _, _ = lf.fit.fit_lanes(o2, grid, zr, 2, 0.0, 1.0, "square", return_masked=False)
     b2, _, _ = lf.fit.fit_lanes(o2 * 1.7, grid, zr, 2, 0.0, 1.0, "square", return_masked=False)
-    assert relerr(b2.cpu(), b1.cpu()) < 1e-9
+    assert relerr(b2.cpu(), b1.cpu()) < 1e-6      # fp32 logits * 1.7 round differently; weights scale by 1.7^4
     # determinism: identical bits on a second run
     b3, _, _ = lf.fit.fit_lanes(o2, grid, zr, 2, 0.0, 1.0, "square", return_masked=False)
     assert torch.equal(b1, b3)
@@ -147,7 +154,7 @@ def test_wls_module_surface(lf, golden_fit):
     b0, b1, b2, b3 = ls(dev(masked), grid)
     assert b2 is None and b3 is None and b0.shape == (N, 3, 1) and b0.dtype == torch.float32
     ref = golden_fit["bev_wls_o2_r0_f64_beta"]
-    assert relerr(torch.stack([b0, b1], 1)[..., 0].cpu(), ref) < 1e-6
+    assert relerr(torch.stack([b0, b1], 1)[..., 0].cpu(), ref) < 1e-5
 
 
 @pytest.mark.parametrize("order,wf", [(2, "none"), (2, "linear"), (2, "quadratic"), (1, "none")])
