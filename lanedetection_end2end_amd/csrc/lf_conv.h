@@ -66,8 +66,10 @@ int lf_tapwgrad_bias_rows(const LfTapGeom& g);
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st);
 
 // dst[k*sk + n*sn + tapidx[t]] = sum_s partial[s][t][k][n]
+// ... and, in the same launch, bias_grad[n] (+)= sum_r bias_rows[r][n] when bias_rows != null
 int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,
-                           const int* tapidx_host, hipStream_t st);
+                           const int* tapidx_host, const float* bias_rows, int n_bias_rows, float* bias_grad,
+                           int bias_accumulate, hipStream_t st);
 // dst[n] (+)= sum_r rows[r][n]
 int lf_rows_reduce_launch(const float* rows, int nrows, int C, float* dst, int accumulate, hipStream_t st);
 

@@ -43,21 +43,21 @@ template <int NT>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
-    const long npix = (long)g.N * g.Hl * g.Wl;
-    const long tile0 = ((long)blockIdx.x * WG_WAVES + wave) * (MT * 16);
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);       // < 2^31, checked by the launcher
+    const unsigned tile0 = (blockIdx.x * WG_WAVES + wave) * (MT * 16);
     const int cob = blockIdx.y * NT * 16;
 
     int pn[MT], pi[MT], pj[MT];
     bool pv[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const long p = tile0 + m * 16 + pl;
+    for (int m = 0; m < MT; ++m) {   // 32-bit divisions: the 64-bit ones expand to ~100 instructions each
+        const unsigned p = tile0 + m * 16 + pl;
         pv[m] = p < npix;
-        const long q = pv[m] ? p : 0;
-        pj[m] = (int)(q % g.Wl);
-        const long r = q / g.Wl;
-        pi[m] = (int)(r % g.Hl);
-        pn[m] = (int)(r / g.Hl);
+        const unsigned q = pv[m] ? p : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj[m] = (int)(q - r * (unsigned)g.Wl);
+        pn[m] = (int)(r / (unsigned)g.Hl);
+        pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
     }
 
     f32x4 acc[NT][MT];
@@ -69,48 +69,55 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
     const int ncg = g.Cs >> 4;
     const int nsteps = g.ntaps * ncg;
 
-    f32x4 wa[NT], xb[MT], wa_n[NT], xb_n[MT];
-    auto load = [&](int t, int cg, f32x4(&w)[NT], f32x4(&x)[MT]) {
+    // Operand loads are UNCONDITIONAL (address clamped into the tensor, result masked at use): a branch
+    // around a load makes hipcc wait vmcnt(0) inside it, which serialises every load behind the last.
+    struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
+    auto load = [&](int t, int cg, Step& S) {
         const float* wpt = a.wp + ((long)(t * (g.Cs >> 2) + cg * 4 + kq) * g.Cd + cob + pl) * 4;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) w[n] = ldg4(wpt + n * 64);
+        for (int n = 0; n < NT; ++n) S.w[n] = ldg4(wpt + n * 64);
         const int dh = g.tdh[t], dw = g.tdw[t];
         const int ch = g.s_choff + cg * 16 + kq * 4;
-        f32x4 sc, sh;
-        if (pro == LF_PRO_BNRELU) { sc = ldg4(a.pro_sc + cg * 16 + kq * 4); sh = ldg4(a.pro_sh + cg * 16 + kq * 4); }
+        if (pro == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + cg * 16 + kq * 4); S.sh = ldg4(a.pro_sh + cg * 16 + kq * 4); }
+        unsigned ok = 0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
-            const bool ok = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-            f32x4 v = zero4();
-            if (ok) {
-                v = ldg4(a.src + ((long)(pn[m] * g.Hs + sy) * g.Ws + sx) * g.s_pix + ch);
-                if (pro == LF_PRO_BNRELU) v = max0(v * sc + sh);
-            }
-            x[m] = v;
+            const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+            S.x[m] = ldg4(a.src + ((long)(pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + ch);
+            ok |= (in ? 1u : 0u) << m;
+        }
+        S.ok = ok;
+    };
+    auto finish = [&](Step& S) {   // prologue + zero padding, applied when the operand is consumed
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v = S.x[m];
+            if (pro == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
+            const bool in = (S.ok >> m) & 1u;
+            v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+            S.x[m] = v;
         }
     };
 
+    Step cur, nxt;
     int t = 0, cg = 0;
-    load(0, 0, wa, xb);
+    load(0, 0, cur);
     for (int step = 0; step < nsteps; ++step) {
         int tn = t, cgn = cg + 1;
         if (cgn == ncg) { cgn = 0; tn = t + 1; }
         const bool more = step + 1 < nsteps;
-        if (more) load(tn, cgn, wa_n, xb_n);
+        if (more) load(tn, cgn, nxt);
+        finish(cur);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[n][s], xb[m][s], acc[n][m], 0, 0, 0);
-        if (more) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) wa[n] = wa_n[n];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) xb[m] = xb_n[m];
-        }
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.w[n][s], cur.x[m][s], acc[n][m], 0, 0, 0);
+        if (more) cur = nxt;
         t = tn; cg = cgn;
     }
 
@@ -143,18 +150,24 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
             if (epi & LF_EPI_STATS_XHAT) { s1[n] += v; s2[n] += v * (ax * asc + ash); }
         }
     }
-    if (stats) {
-        const long row = (long)blockIdx.x * WG_WAVES + wave;
+    if (stats) {   // one partial row per WORKGROUP: 16-lane shuffles, then the 4 waves through LDS
+        __shared__ float sred[WG_WAVES][NT][4][8];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             f32x4 r1, r2;
             r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w);
             r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w);
             if (pl == 0) {
-                const int co = cob + n * 16 + kq * 4;
-                *reinterpret_cast<f32x4*>(a.stats + (row * 2 + 0) * g.Cd + co) = r1;
-                *reinterpret_cast<f32x4*>(a.stats + (row * 2 + 1) * g.Cd + co) = r2;
+                float* d = sred[wave][n][kq];
+                d[0] = r1.x; d[1] = r1.y; d[2] = r1.z; d[3] = r1.w; d[4] = r2.x; d[5] = r2.y; d[6] = r2.z; d[7] = r2.w;
             }
+        }
+        __syncthreads();
+        if (threadIdx.x < NT * 4 * 8) {
+            const int j = threadIdx.x & 7, q = (threadIdx.x >> 3) & 3, n = threadIdx.x >> 5;
+            const float v = sred[0][n][q][j] + sred[1][n][q][j] + sred[2][n][q][j] + sred[3][n][q][j];
+            const int co = cob + n * 16 + q * 4 + (j & 3);
+            a.stats[((long)blockIdx.x * 2 + (j >> 2)) * g.Cd + co] = v;
         }
     }
 }
@@ -171,7 +184,7 @@ int pick_nt(int Cd) {
 
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;
-    return lf_cdiv(npix, PIX_PER_WG) * WG_WAVES;
+    return lf_cdiv(npix, PIX_PER_WG);
 }
 
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st) {
@@ -179,6 +192,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     LF_REQUIRE(g.s_pix % 4 == 0 && g.s_choff % 4 == 0 && g.d_pix % 4 == 0 && g.d_choff % 4 == 0, "tapgemm: unaligned channel layout");
     LF_REQUIRE(g.ntaps >= 1 && g.ntaps <= LF_MAX_TAPS, "tapgemm: bad tap count %d", g.ntaps);
     const long npix = (long)g.N * g.Hl * g.Wl;
+    LF_REQUIRE(npix < (1L << 30), "tapgemm: too many pixels (%ld)", npix);
     const int nt = pick_nt(g.Cd);
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
     switch (nt) {
@@ -228,11 +242,11 @@ __global__ __launch_bounds__(256) void tapwgrad_kernel(const LfTapGeom g, const 
     long p = p_begin + kq;
     int pj, pi, pn;
     {
-        const long q = p < npix ? p : 0;
-        pj = (int)(q % g.Wl);
-        const long r = q / g.Wl;
-        pi = (int)(r % g.Hl);
-        pn = (int)(r / g.Hl);
+        const unsigned q = p < npix ? (unsigned)p : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj = (int)(q - r * (unsigned)g.Wl);
+        pn = (int)(r / (unsigned)g.Hl);
+        pi = (int)(r - (unsigned)pn * (unsigned)g.Hl);
     }
     const int dh = g.tdh[t], dw = g.tdw[t];
     const int xch = g.s_choff + cib * XB + (XV ? 4 * pl : pl);
@@ -247,37 +261,62 @@ __global__ __launch_bounds__(256) void tapwgrad_kernel(const LfTapGeom g, const 
         }
     }
 
-    for (; p - kq < p_end; p += 4) {
-        const bool valid = p < p_end;
+    // raw operand loads for the pixel group starting at p - kq (unconditional, clamped; masked at use)
+    struct WStep { f32x4 x4, g4; float xs[XTiles], gs[GTiles]; bool valid, xin; };
+    auto wload = [&](WStep& S, long pp, int n_, int i_, int j_) {
+        S.valid = pp < p_end;
+        const int nn = S.valid ? n_ : 0, ii = S.valid ? i_ : 0, jj = S.valid ? j_ : 0;
+        const float* gp = a.g + ((long)(nn * g.Hd + ii * g.dsh + g.dah) * g.Wd + jj * g.dsw + g.daw) * g.d_pix + gch;
+        if constexpr (GV) S.g4 = ldg4(gp);
+        else {
+#pragma unroll
+            for (int q = 0; q < GTiles; ++q) S.gs[q] = gp[q * 16];
+        }
+        const int sy = ii * g.ssh + dh, sx = jj * g.ssw + dw;
+        S.xin = S.valid && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+        const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+        const float* xp = a.x + ((long)(nn * g.Hs + syc) * g.Ws + sxc) * g.s_pix + xch;
+        if constexpr (XV) S.x4 = ldg4(xp);
+        else {
+#pragma unroll
+            for (int r = 0; r < XTiles; ++r) S.xs[r] = xp[r * 16];
+        }
+    };
+    auto advance = [&]() {
+        p += 4;
+        pj += 4;
+        if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
+    };
+
+    WStep cur, nxt;
+    wload(cur, p, pn, pi, pj);
+    bool more = p - kq < p_end;          // wave-uniform: p - kq is the same in every lane
+    while (more) {
+        advance();
+        more = p - kq < p_end;
+        if (more) wload(nxt, p, pn, pi, pj);
         float xv[XTiles], gv[GTiles];
+        if constexpr (GV) { gv[0] = cur.g4.x; gv[1] = cur.g4.y; gv[2] = cur.g4.z; gv[3] = cur.g4.w; }
+        else {
 #pragma unroll
-        for (int r = 0; r < XTiles; ++r) xv[r] = 0.f;
+            for (int q = 0; q < GTiles; ++q) gv[q] = cur.gs[q];
+        }
 #pragma unroll
-        for (int q = 0; q < GTiles; ++q) gv[q] = 0.f;
-        if (valid) {
-            const float* gp = a.g + ((long)(pn * g.Hd + pi * g.dsh + g.dah) * g.Wd + pj * g.dsw + g.daw) * g.d_pix + gch;
-            if constexpr (GV) { const f32x4 v = ldg4(gp); gv[0] = v.x; gv[1] = v.y; gv[2] = v.z; gv[3] = v.w; }
-            else {
+        for (int q = 0; q < GTiles; ++q) gv[q] = cur.valid ? gv[q] : 0.f;
+        if constexpr (XV) {
+            f32x4 v = cur.x4;
+            if (pro == LF_PRO_BNRELU) v = max0(v * psc + psh);
+            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+        } else {
 #pragma unroll
-                for (int q = 0; q < GTiles; ++q) gv[q] = gp[q * 16];
-            }
-            const int sy = pi * g.ssh + dh, sx = pj * g.ssw + dw;
-            if (sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws) {
-                const float* xp = a.x + ((long)(pn * g.Hs + sy) * g.Ws + sx) * g.s_pix + xch;
-                if constexpr (XV) {
-                    f32x4 v = ldg4(xp);
-                    if (pro == LF_PRO_BNRELU) v = max0(v * psc + psh);
-                    xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < XTiles; ++r) {
-                        float v = xp[r * 16];
-                        if (pro == LF_PRO_BNRELU) v = fmaxf(v * psc1[r] + psh1[r], 0.f);
-                        xv[r] = v;
-                    }
-                }
+            for (int r = 0; r < XTiles; ++r) {
+                float v = cur.xs[r];
+                if (pro == LF_PRO_BNRELU) v = fmaxf(v * psc1[r] + psh1[r], 0.f);
+                xv[r] = v;
             }
         }
+#pragma unroll
+        for (int r = 0; r < XTiles; ++r) xv[r] = cur.xin ? xv[r] : 0.f;
 #pragma unroll
         for (int r = 0; r < XTiles; ++r)
 #pragma unroll
@@ -285,8 +324,7 @@ __global__ __launch_bounds__(256) void tapwgrad_kernel(const LfTapGeom g, const 
                 acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r], gv[q], acc[r][q], 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < GTiles; ++q) bsum[q] += gv[q];
-        pj += 4;
-        if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
+        if (more) cur = nxt;
     }
 
     // ---- reduce the 4 waves of the workgroup through LDS, wave 0 writes one partial row
@@ -397,25 +435,56 @@ struct TapIdx { int v[LF_MAX_TAPS]; };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int ntaps,
                                                           int Cs, int Cd, float* __restrict__ grad, long sk, long sn,
-                                                          TapIdx ti) {
+                                                          TapIdx ti, int wblocks, const float* __restrict__ brows,
+                                                          int nbrows, float* __restrict__ bgrad, int baccum) {
+    if ((int)blockIdx.x >= wblocks) {   // trailing blocks: bias gradient = column sums of the bias partial rows
+        const int c = (blockIdx.x - wblocks) * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+        __shared__ float sb[4][64];
+        float s = 0.f;
+        if (c < Cd)
+            for (int r = rg; r < nbrows; r += 4) s += brows[(long)r * Cd + c];
+        sb[rg][threadIdx.x & 63] = s;
+        __syncthreads();
+        if (rg == 0 && c < Cd) {
+            const float v = (sb[0][threadIdx.x] + sb[1][threadIdx.x]) + (sb[2][threadIdx.x] + sb[3][threadIdx.x]);
+            bgrad[c] = baccum ? bgrad[c] + v : v;
+        }
+        return;
+    }
     const long per = (long)ntaps * Cs * Cd;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
-        double s = 0.0;
-        for (int r = 0; r < splits; ++r) s += (double)partial[r * per + i];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)wblocks * 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = 0;
+        for (; r + 4 <= splits; r += 4) {   // independent loads in flight, fixed summation order
+            s0 += partial[(long)r * per + i];
+            s1 += partial[(long)(r + 1) * per + i];
+            s2 += partial[(long)(r + 2) * per + i];
+            s3 += partial[(long)(r + 3) * per + i];
+        }
+        for (; r < splits; ++r) s0 += partial[(long)r * per + i];
         const int n = (int)(i % Cd);
         const long r2 = i / Cd;
         const int k = (int)(r2 % Cs), t = (int)(r2 / Cs);
-        grad[k * sk + n * sn + ti.v[t]] = (float)s;
+        grad[k * sk + n * sn + ti.v[t]] = (s0 + s1) + (s2 + s3);
     }
 }
 
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ rows, int nrows, int C,
                                                          float* __restrict__ dst, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int r = 0; r < nrows; ++r) s += (double)rows[(long)r * C + c];
-    dst[c] = accumulate ? dst[c] + (float)s : (float)s;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    __shared__ float sb[4][64];
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int r = rg;
+        for (; r + 4 < nrows; r += 8) { s0 += rows[(long)r * C + c]; s1 += rows[(long)(r + 4) * C + c]; }
+        for (; r < nrows; r += 4) s0 += rows[(long)r * C + c];
+    }
+    sb[rg][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const float v = (sb[0][threadIdx.x] + sb[1][threadIdx.x]) + (sb[2][threadIdx.x] + sb[3][threadIdx.x]);
+        dst[c] = accumulate ? dst[c] + v : v;
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const LfPackEntry* __restrict__ entries,
@@ -440,19 +509,22 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const LfPackEntry* __
 }  // namespace
 
 int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,
-                           const int* tapidx_host, hipStream_t st) {
+                           const int* tapidx_host, const float* bias_rows, int n_bias_rows, float* bias_grad,
+                           int bias_accumulate, hipStream_t st) {
     TapIdx ti;
     for (int i = 0; i < LF_MAX_TAPS; ++i) ti.v[i] = i < ntaps ? tapidx_host[i] : 0;
     const long per = (long)ntaps * Cs * Cd;
-    int grid = lf_cdiv(per, 256);
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, partial, splits, ntaps, Cs, Cd, grad, sk, sn, ti);
+    int wblocks = lf_cdiv(per, 256);
+    if (wblocks > 2048) wblocks = 2048;
+    const int bblocks = (bias_rows && bias_grad) ? lf_cdiv(Cd, 64) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, partial, splits, ntaps, Cs, Cd, grad,
+                       sk, sn, ti, wblocks, bias_rows, n_bias_rows, bias_grad, bias_accumulate);
     LF_CHECK_LAUNCH("wgrad_reduce");
     return 0;
 }
 
 int lf_rows_reduce_launch(const float* rows, int nrows, int C, float* dst, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3(lf_cdiv(C, 256)), dim3(256), 0, st, rows, nrows, C, dst, accumulate);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3(lf_cdiv(C, 64)), dim3(256), 0, st, rows, nrows, C, dst, accumulate);
     LF_CHECK_LAUNCH("rows_reduce");
     return 0;
 }

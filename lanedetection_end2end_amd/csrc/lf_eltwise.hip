@@ -38,21 +38,28 @@ __device__ __forceinline__ void block_reduce_quads(f32x4& a1, f32x4& a2, int Q, 
 
 struct StatParts { LfStatPart p[2]; int n; };
 
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
+__global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ rmean, float* __restrict__ rvar,
                                                              float momentum, float eps, int training,
                                                              float* __restrict__ scale, float* __restrict__ shift,
                                                              float* __restrict__ asc, float* __restrict__ ash) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
-    __shared__ double sm[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;   // 16 channels x 64 row groups
+    __shared__ double sm[64][16][2];
     double s1 = 0.0, s2 = 0.0;
     if (training && c < C) {
         for (int k = 0; k < sp.n; ++k) {
             const LfStatPart& q = sp.p[k];
             const int cc = c - q.ch_off;
             if (cc < 0 || cc >= q.C) continue;
-            for (int r = rg; r < q.nrows; r += 16) {
+            int r = rg;
+            for (; r + 64 < q.nrows; r += 128) {
+                const float a0 = q.rows[((long)r * 2 + 0) * q.C + cc], a1 = q.rows[((long)r * 2 + 1) * q.C + cc];
+                const float b0 = q.rows[((long)(r + 64) * 2 + 0) * q.C + cc], b1 = q.rows[((long)(r + 64) * 2 + 1) * q.C + cc];
+                s1 += (double)a0 + (double)b0;
+                s2 += (double)a1 + (double)b1;
+            }
+            for (; r < q.nrows; r += 64) {
                 s1 += (double)q.rows[((long)r * 2 + 0) * q.C + cc];
                 s2 += (double)q.rows[((long)r * 2 + 1) * q.C + cc];
             }
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(StatParts sp, int 
         double mean, var;
         if (training) {
             s1 = 0.0; s2 = 0.0;
-            for (int r = 0; r < 16; ++r) { s1 += sm[r][threadIdx.x][0]; s2 += sm[r][threadIdx.x][1]; }
+            for (int r = 0; r < 64; ++r) { s1 += sm[r][threadIdx.x][0]; s2 += sm[r][threadIdx.x][1]; }
             mean = s1 / count;
             var = s2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -128,18 +135,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int C, double count, float* __restrict__ c1,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(StatParts sp, int C, double count, float* __restrict__ c1,
                                                              float* __restrict__ c2, float* __restrict__ ggamma,
                                                              float* __restrict__ gbeta) {
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
-    __shared__ double sm[16][16][2];
+    __shared__ double sm[64][16][2];
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         for (int k = 0; k < sp.n; ++k) {
             const LfStatPart& q = sp.p[k];
             const int cc = c - q.ch_off;
             if (cc < 0 || cc >= q.C) continue;
-            for (int r = rg; r < q.nrows; r += 16) {
+            int r = rg;
+            for (; r + 64 < q.nrows; r += 128) {
+                const float a0 = q.rows[((long)r * 2 + 0) * q.C + cc], a1 = q.rows[((long)r * 2 + 1) * q.C + cc];
+                const float b0 = q.rows[((long)(r + 64) * 2 + 0) * q.C + cc], b1 = q.rows[((long)(r + 64) * 2 + 1) * q.C + cc];
+                s1 += (double)a0 + (double)b0;
+                s2 += (double)a1 + (double)b1;
+            }
+            for (; r < q.nrows; r += 64) {
                 s1 += (double)q.rows[((long)r * 2 + 0) * q.C + cc];
                 s2 += (double)q.rows[((long)r * 2 + 1) * q.C + cc];
             }
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int 
     __syncthreads();
     if (rg == 0 && c < C) {
         s1 = 0.0; s2 = 0.0;
-        for (int r = 0; r < 16; ++r) { s1 += sm[r][threadIdx.x][0]; s2 += sm[r][threadIdx.x][1]; }
+        for (int r = 0; r < 64; ++r) { s1 += sm[r][threadIdx.x][0]; s2 += sm[r][threadIdx.x][1]; }
         c1[c] = (float)(s1 / count);
         c2[c] = (float)(s2 / count);
         ggamma[c] = (float)s2;
@@ -493,7 +507,7 @@ int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count,
     StatParts sp;
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(lf_cdiv(C, 16)), dim3(256), 0, st, sp, C, count, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(lf_cdiv(C, 16)), dim3(1024), 0, st, sp, C, count, gamma, beta,
                        running_mean, running_var, momentum, eps, training, scale, shift, asc, ash);
     LF_CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
@@ -526,7 +540,7 @@ int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count,
     StatParts sp;
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 16)), dim3(256), 0, st, sp, C, count, c1, c2, ggamma, gbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 16)), dim3(1024), 0, st, sp, C, count, c1, c2, ggamma, gbeta);
     LF_CHECK_LAUNCH("bn_bwd_finalize");
     return 0;
 }

@@ -467,10 +467,8 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     }
     const LfPackEntry& e = P->packs[op.pack];
     LF_TRY(lf_wgrad_reduce_launch(a.partial, lf_tapwgrad_splits(op.geom), op.geom.ntaps, op.geom.Cs, op.geom.Cd,
-                                  c.grads[cv.p_w], e.sk, e.sn, e.tapidx, c.st));
-    if (a.bias_partial)
-        LF_TRY(lf_rows_reduce_launch(a.bias_partial, lf_tapwgrad_bias_rows(op.geom), op.geom.Cd, c.grads[cv.p_b],
-                                     bias_accumulate, c.st));
+                                  c.grads[cv.p_w], e.sk, e.sn, e.tapidx, a.bias_partial, lf_tapwgrad_bias_rows(op.geom),
+                                  c.grads[cv.p_b], bias_accumulate, c.st));
     return 0;
 }
 
