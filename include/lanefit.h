@@ -145,6 +145,23 @@ int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, vo
 int lf_erfnet_profile(const lf_erfnet_plan* plan, int enable);
 int lf_erfnet_profile_read(const lf_erfnet_plan* plan, double* out6_host);
 
+/* ------------------------------------------------------------------------------------
+ * Kernel-level entry points: one factorised convolution of non_bottleneck_1d
+ * (nn.Conv2d(C, C, (3,1)|(1,3), padding = dilation = d), BEV/Networks/ERFNet.py:29-37) on NHWC fp32
+ * tensors, outside the plan: forward, data gradient (optionally times the ReLU mask of mask_src),
+ * weight + bias gradient.  w / gw use the nn.Conv2d layout (C, C, 3) flattened; axis 0 = 3x1 (along H),
+ * 1 = 1x3 (along W); C a multiple of 16; scratch >= lf_conv1d_scratch_floats() floats.
+ * ---------------------------------------------------------------------------------- */
+long lf_conv1d_scratch_floats(int N, int H, int W, int C);
+int lf_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C,
+                  int axis, int dilation, int relu, float* scratch, void* stream);
+int lf_conv1d_bwd_data(const float* gy, const float* w, const float* mask_src, float* gx, int N, int H, int W,
+                       int C, int axis, int dilation, float* scratch, void* stream);
+int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, int N, int H, int W, int C,
+                         int axis, int dilation, float* scratch, void* stream);
+/* kernel A/B switch used by tools/kbench.py only (0 = simple loop, 1 = default schedule) */
+void lf_debug_set_tapgemm_variant(int v);
+
 #ifdef __cplusplus
 }
 #endif

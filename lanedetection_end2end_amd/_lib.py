@@ -44,6 +44,11 @@ def _declare(lib):
         "lf_erfnet_forward": (I, [P, P, P, P, P, P, I, I, P, P, c_size_t, P]),
         "lf_erfnet_backward": (I, [P, P, P, P, P, P, I, P, c_size_t, P]),
         "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
+        "lf_conv1d_scratch_floats": (L, [I, I, I, I]),
+        "lf_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
+        "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+        "lf_conv1d_bwd_weight": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+        "lf_debug_set_tapgemm_variant": (None, [I]),
         "lf_erfnet_profile": (I, [P, I]),
         "lf_erfnet_profile_read": (I, [P, P]),
     }

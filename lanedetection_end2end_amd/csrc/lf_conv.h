@@ -49,6 +49,7 @@ struct LfTapArgs {
     float* stats;           // [rows][2][Cd] per-wave partial sums, rows = lf_tapgemm_stat_rows()
 };
 
+void lf_tapgemm_set_variant(int v);   // kernel A/B switch for tools/kbench.py (0 = simple loop, 1 = default)
 int lf_tapgemm_stat_rows(const LfTapGeom& g);
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);
 

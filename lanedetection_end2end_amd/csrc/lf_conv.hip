@@ -39,7 +39,7 @@ __device__ __forceinline__ float sum16(float v) {
     return v;
 }
 
-template <int NT>
+template <int NT, int VAR>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
@@ -69,56 +69,122 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
     const int ncg = g.Cs >> 4;
     const int nsteps = g.ntaps * ncg;
 
+    if constexpr (VAR == 0) {
     // Operand loads are UNCONDITIONAL (address clamped into the tensor, result masked at use): a branch
-    // around a load makes hipcc wait vmcnt(0) inside it, which serialises every load behind the last.
-    struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
-    auto load = [&](int t, int cg, Step& S) {
-        const float* wpt = a.wp + ((long)(t * (g.Cs >> 2) + cg * 4 + kq) * g.Cd + cob + pl) * 4;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) S.w[n] = ldg4(wpt + n * 64);
-        const int dh = g.tdh[t], dw = g.tdw[t];
-        const int ch = g.s_choff + cg * 16 + kq * 4;
-        if (pro == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + cg * 16 + kq * 4); S.sh = ldg4(a.pro_sh + cg * 16 + kq * 4); }
-        unsigned ok = 0;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
-            const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-            const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-            S.x[m] = ldg4(a.src + ((long)(pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + ch);
-            ok |= (in ? 1u : 0u) << m;
+        // around a load makes hipcc wait vmcnt(0) inside it, which serialises every load behind the last.
+        struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
+        auto load = [&](int t, int cg, Step& S) {
+            const float* wpt = a.wp + ((long)(t * (g.Cs >> 2) + cg * 4 + kq) * g.Cd + cob + pl) * 4;
+    #pragma unroll
+            for (int n = 0; n < NT; ++n) S.w[n] = ldg4(wpt + n * 64);
+            const int dh = g.tdh[t], dw = g.tdw[t];
+            const int ch = g.s_choff + cg * 16 + kq * 4;
+            if (pro == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + cg * 16 + kq * 4); S.sh = ldg4(a.pro_sh + cg * 16 + kq * 4); }
+            unsigned ok = 0;
+    #pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+                const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+                const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+                S.x[m] = ldg4(a.src + ((long)(pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + ch);
+                ok |= (in ? 1u : 0u) << m;
+            }
+            S.ok = ok;
+        };
+        auto finish = [&](Step& S) {   // prologue + zero padding, applied when the operand is consumed
+    #pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = S.x[m];
+                if (pro == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
+                const bool in = (S.ok >> m) & 1u;
+                v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+                S.x[m] = v;
+            }
+        };
+    
+        Step cur, nxt;
+        int t = 0, cg = 0;
+        load(0, 0, cur);
+        for (int step = 0; step < nsteps; ++step) {
+            int tn = t, cgn = cg + 1;
+            if (cgn == ncg) { cgn = 0; tn = t + 1; }
+            const bool more = step + 1 < nsteps;
+            if (more) load(tn, cgn, nxt);
+            finish(cur);
+    #pragma unroll
+            for (int s = 0; s < 4; ++s)
+    #pragma unroll
+                for (int n = 0; n < NT; ++n)
+    #pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.w[n][s], cur.x[m][s], acc[n][m], 0, 0, 0);
+            if (more) cur = nxt;
+            t = tn; cg = cgn;
         }
-        S.ok = ok;
-    };
-    auto finish = [&](Step& S) {   // prologue + zero padding, applied when the operand is consumed
+    } else {
+        // VAR 1: per-tap address setup (once per tap instead of once per 16 channels), pointer-increment
+        // operand streams, two named register sets (no copy), next step's loads issued behind the first
+        // quarter of the current step's MFMAs so that a single wave keeps the matrix pipe fed.
+        struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
+        unsigned xoff[MT];      // element offset of (pixel, tap) channel group 0 for the tap being loaded
+        unsigned okbits = 0;
+        auto tap_setup = [&](int t) {
+            const int dh = g.tdh[t], dw = g.tdw[t];
+            okbits = 0;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            f32x4 v = S.x[m];
-            if (pro == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
-            const bool in = (S.ok >> m) & 1u;
-            v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
-            S.x[m] = v;
-        }
-    };
-
-    Step cur, nxt;
-    int t = 0, cg = 0;
-    load(0, 0, cur);
-    for (int step = 0; step < nsteps; ++step) {
-        int tn = t, cgn = cg + 1;
-        if (cgn == ncg) { cgn = 0; tn = t + 1; }
-        const bool more = step + 1 < nsteps;
-        if (more) load(tn, cgn, nxt);
-        finish(cur);
+            for (int m = 0; m < MT; ++m) {
+                const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+                const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+                const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+                xoff[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4);
+                okbits |= (in ? 1u : 0u) << m;
+            }
+        };
+        const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;     // + 16*Cd floats per 16-channel step
+        const long wstep = (long)g.Cd * 16;
+        int t_ld = 0, cg_ld = 0;
+        tap_setup(0);
+        auto issue = [&](Step& S) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int n = 0; n < NT; ++n) S.w[n] = ldg4(wp + n * 64);
+            wp += wstep;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) S.x[m] = ldg4(a.src + xoff[m] + cg_ld * 16);
+            if (pro == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + cg_ld * 16 + kq * 4); S.sh = ldg4(a.pro_sh + cg_ld * 16 + kq * 4); }
+            S.ok = okbits;
+            if (++cg_ld == ncg) { cg_ld = 0; if (++t_ld < g.ntaps) tap_setup(t_ld); }
+        };
+        auto finish = [&](Step& S) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = S.x[m];
+                if (pro == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
+                const bool in = (S.ok >> m) & 1u;
+                v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+                S.x[m] = v;
+            }
+        };
+        auto mma = [&](const Step& S, int s) {
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.w[n][s], cur.x[m][s], acc[n][m], 0, 0, 0);
-        if (more) cur = nxt;
-        t = tn; cg = cgn;
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
+        };
+        Step A, B;
+        issue(A);
+        for (int step = 0; step < nsteps; step += 2) {
+            finish(A);
+            mma(A, 0);
+            if (step + 1 < nsteps) issue(B);
+            mma(A, 1); mma(A, 2); mma(A, 3);
+            if (step + 1 < nsteps) {
+                finish(B);
+                mma(B, 0);
+                if (step + 2 < nsteps) issue(A);
+                mma(B, 1); mma(B, 2); mma(B, 3);
+            }
+        }
     }
 
     // ---- epilogue: lane holds channels co = cob + n*16 + 4*kq + (0..3) of pixel (tile m, pl)
@@ -172,6 +238,8 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
     }
 }
 
+int g_tapgemm_variant = 1;
+
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
     if (tiles % 4 == 0) return 4;
@@ -181,6 +249,8 @@ int pick_nt(int Cd) {
 }
 
 }  // namespace
+
+void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
 
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;
@@ -195,12 +265,19 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     LF_REQUIRE(npix < (1L << 30), "tapgemm: too many pixels (%ld)", npix);
     const int nt = pick_nt(g.Cd);
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
+    LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31), "tapgemm: source tensor too large for 32-bit offsets");
+#define LF_TG(NTV)                                                                                             \
+    do {                                                                                                       \
+        if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), 0, st, g, a, pro, epi);           \
+    } while (0)
     switch (nt) {
-        case 4: hipLaunchKernelGGL(tapgemm_kernel<4>, grid, dim3(256), 0, st, g, a, pro, epi); break;
-        case 3: hipLaunchKernelGGL(tapgemm_kernel<3>, grid, dim3(256), 0, st, g, a, pro, epi); break;
-        case 2: hipLaunchKernelGGL(tapgemm_kernel<2>, grid, dim3(256), 0, st, g, a, pro, epi); break;
-        default: hipLaunchKernelGGL(tapgemm_kernel<1>, grid, dim3(256), 0, st, g, a, pro, epi); break;
+        case 4: LF_TG(4); break;
+        case 3: LF_TG(3); break;
+        case 2: LF_TG(2); break;
+        default: LF_TG(1); break;
     }
+#undef LF_TG
     LF_CHECK_LAUNCH("tapgemm");
     return 0;
 }

@@ -1,0 +1,89 @@
+// Kernel-level C-ABI entry points: one factorised 1-D convolution (forward, data gradient, weight
+// gradient) on NHWC fp32 tensors, outside the ERFNet plan.  Used by the kernel-level parity tests
+// and by tools/kbench.py (roofline micro-benchmarks, kernel A/B switches).
+// Replaces nn.Conv2d(C, C, (3,1)|(1,3), padding=d, dilation=d) of non_bottleneck_1d (ERFNet.py:29-37).
+#include "lf_conv.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__ w, float* __restrict__ dst, int Kc, int Nc,
+                                                      int ntaps, long sk, long sn, int flip) {
+    const long total = (long)ntaps * Kc * Nc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k4 = (int)(i & 3);
+        long r = i >> 2;
+        const int n = (int)(r % Nc);
+        r /= Nc;
+        const int kb = (int)(r % (Kc >> 2));
+        const int t = (int)(r / (Kc >> 2));
+        dst[i] = w[(kb * 4 + k4) * sk + n * sn + (flip ? ntaps - 1 - t : t)];
+    }
+}
+
+LfTapGeom conv1d_geom(int N, int H, int W, int C, int axis, int d) {
+    LfTapGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.Hl = H; g.Wl = W; g.Hs = H; g.Ws = W; g.s_pix = C; g.ssh = 1; g.ssw = 1;
+    g.Hd = H; g.Wd = W; g.d_pix = C; g.dsh = 1; g.dsw = 1; g.Cs = C; g.Cd = C; g.ntaps = 3;
+    for (int t = 0; t < 3; ++t) { g.tdh[t] = axis == 0 ? (t - 1) * d : 0; g.tdw[t] = axis == 1 ? (t - 1) * d : 0; }
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+void lf_debug_set_tapgemm_variant(int v) { lf_tapgemm_set_variant(v); }
+
+// scratch floats needed by the three calls below (packed weights / split-K partials)
+long lf_conv1d_scratch_floats(int N, int H, int W, int C) {
+    const LfTapGeom g = conv1d_geom(N, H, W, C, 0, 1);
+    long a = 3L * C * C;
+    long b = (long)lf_tapwgrad_splits(g) * 3 * C * C + (long)lf_tapwgrad_bias_rows(g) * C;
+    return a > b ? a : b;
+}
+
+// y = [relu](conv1d(x) + bias); x,y (N,H,W,C) NHWC; w in the nn.Conv2d layout (C,C,3) flattened; axis 0 = 3x1, 1 = 1x3
+int lf_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int axis,
+                  int dilation, int relu, float* scratch, void* stream) {
+    LF_REQUIRE(x && w && y && scratch, "lf_conv1d_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, 3L, 3L * C, 0);
+    LfTapArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = x; a.wp = scratch; a.bias = bias; a.dst = y;
+    return lf_tapgemm_launch(g, a, LF_PRO_NONE, relu ? LF_EPI_RELU : 0, st);
+}
+
+// gx = conv1d^T(gy) [* (mask_src > 0)]
+int lf_conv1d_bwd_data(const float* gy, const float* w, const float* mask_src, float* gx, int N, int H, int W, int C,
+                       int axis, int dilation, float* scratch, void* stream) {
+    LF_REQUIRE(gy && w && gx && scratch, "lf_conv1d_bwd_data: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, 3L * C, 3L, 1);
+    LfTapArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = gy; a.wp = scratch; a.dst = gx; a.mask_src = mask_src;
+    return lf_tapgemm_launch(g, a, LF_PRO_NONE, mask_src ? LF_EPI_MASK : 0, st);
+}
+
+// gw (C,C,3) and gb (C) from x and gy
+int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, int N, int H, int W, int C, int axis,
+                         int dilation, float* scratch, void* stream) {
+    LF_REQUIRE(x && gy && gw && scratch, "lf_conv1d_bwd_weight: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    LfWgradArgs a;
+    a.x = x; a.g = gy; a.pro_sc = nullptr; a.pro_sh = nullptr;
+    a.partial = scratch;
+    a.bias_partial = gb ? scratch + (long)lf_tapwgrad_splits(g) * 3 * C * C : nullptr;
+    int rc = lf_tapwgrad_launch(g, a, LF_PRO_NONE, st);
+    if (rc) return rc;
+    const int idx[3] = {0, 1, 2};
+    return lf_wgrad_reduce_launch(a.partial, lf_tapwgrad_splits(g), 3, C, C, gw, 3L, 3L * C, idx, a.bias_partial,
+                                  lf_tapwgrad_bias_rows(g), gb, 0, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmark: one factorised conv (fwd / dgrad / wgrad) of each ERFNet stage at batch 32,
+HIP-event timed, as TFLOP/s against the fp32 MFMA peak.  Also checks each result against torch (on the
+GPU, fp32) so that a faster variant that is wrong is caught immediately.
+
+    python tools/kbench.py [--variants 0 1] [--iters 30]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lanedetection_end2end_amd import _lib  # noqa: E402
+
+PEAK = 157.3
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", type=int, nargs="+", default=[0, 1])
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=32)
+    a = ap.parse_args()
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    shapes = [(128, 32, 64, 0, 4), (128, 32, 64, 1, 16), (64, 64, 128, 0, 1), (64, 64, 128, 1, 1), (16, 128, 256, 1, 1)]
+    N = a.batch
+    for C, H, W, axis, d in shapes:
+        torch.manual_seed(0)
+        x = torch.randn(N, H, W, C, device="cuda")
+        gy = torch.randn(N, H, W, C, device="cuda")
+        w = torch.randn(C, C, 3, device="cuda") * (2.0 / (3 * C)) ** 0.5
+        b = torch.randn(C, device="cuda")
+        y, gx = torch.empty_like(x), torch.empty_like(x)
+        gw, gb = torch.empty_like(w), torch.empty_like(b)
+        scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C), device="cuda")
+        flops = 2.0 * N * H * W * C * C * 3
+        w4 = w.view(C, C, 3, 1) if axis == 0 else w.view(C, C, 1, 3)
+        pad, dil = ((d, 0), (d, 1)) if axis == 0 else ((0, d), (1, d))
+        xn = x.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        wn = w4.clone().requires_grad_(True)
+        bn = b.clone().requires_grad_(True)
+        yr = F.conv2d(xn, wn, bn, padding=pad, dilation=dil)
+        yr.backward(gy.permute(0, 3, 1, 2))
+        for v in a.variants:
+            lib.lf_debug_set_tapgemm_variant(v)
+            f = lambda: _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 0, P(scratch), st), "fwd")
+            tf = timeit(f, a.iters)
+            e1 = float((y.permute(0, 3, 1, 2) - yr).abs().max() / yr.abs().max())
+            g = lambda: _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), None, P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
+            td = timeit(g, a.iters)
+            e2 = float((gx.permute(0, 3, 1, 2) - xn.grad).abs().max() / xn.grad.abs().max())
+            h = lambda: _lib.check(lib.lf_conv1d_bwd_weight(P(x), P(gy), P(gw), P(gb), N, H, W, C, axis, d, P(scratch), st), "wgrad")
+            tw = timeit(h, a.iters)
+            e3 = float((gw.view_as(wn.grad) - wn.grad).abs().max() / wn.grad.abs().max())
+            e4 = float((gb - bn.grad).abs().max() / bn.grad.abs().max())
+            print("C=%3d %3dx%3d axis %d dil %2d var %d | fwd %6.1f us %5.1f TF (%4.1f%%) err %.1e | dgrad %6.1f us %5.1f TF err %.1e | "
+                  "wgrad(+reduce) %6.1f us %5.1f TF err %.1e %.1e"
+                  % (C, H, W, axis, d, v, tf * 1e6, flops / tf / 1e12, 100 * flops / tf / 1e12 / PEAK, e1, td * 1e6,
+                     flops / td / 1e12, e2, tw * 1e6, flops / tw / 1e12, e3, e4), flush=True)
+
+
+if __name__ == "__main__":
+    main()
