@@ -2,9 +2,9 @@
 import torch
 import torch.nn as nn
 
-from ... import geometry
-from ...fit import WeightedLeastSquares
-from ...lsq import BEVNet as Net, activation_layer  # noqa: F401
+from lanedetection_end2end_amd import geometry
+from lanedetection_end2end_amd.fit import WeightedLeastSquares
+from lanedetection_end2end_amd.lsq import BEVNet as Net, activation_layer  # noqa: F401
 
 
 def Init_Projective_transform(nclasses, batch_size, resize):

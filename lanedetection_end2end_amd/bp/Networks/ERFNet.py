@@ -1,4 +1,4 @@
 """``Networks.ERFNet`` of the BP tree: forward returns (encoder_output, decoder_output, output_seg)
 (BP/Networks/ERFNet.py:170-176; the second decoder is never built there, so output_seg is None)."""
-from ...erfnet import Decoder, DownsamplerBlock, Encoder, UpsamplerBlock, non_bottleneck_1d  # noqa: F401
-from ...lsq import _BPBackbone as Net  # noqa: F401
+from lanedetection_end2end_amd.erfnet import Decoder, DownsamplerBlock, Encoder, UpsamplerBlock, non_bottleneck_1d  # noqa: F401
+from lanedetection_end2end_amd.lsq import _BPBackbone as Net  # noqa: F401

@@ -1,10 +1,10 @@
 """``Networks.LSQ_layer`` of the BP tree (BP/Networks/LSQ_layer.py): same public names."""
 import torch
 
-from ... import geometry
-from ...fit import WeightedLeastSquares
-from ...geometry import get_homography  # noqa: F401
-from ...lsq import BPNet as Net, activation_layer  # noqa: F401
+from lanedetection_end2end_amd import geometry
+from lanedetection_end2end_amd.fit import WeightedLeastSquares
+from lanedetection_end2end_amd.geometry import get_homography  # noqa: F401
+from lanedetection_end2end_amd.lsq import BPNet as Net, activation_layer  # noqa: F401
 
 
 def ProjectiveGridGenerator(size, theta, no_cuda):

@@ -1,5 +1,5 @@
 """Backbone registry -- same surface as BP/Networks/__init__.py."""
-from ..._refpath import extend as _extend
+from lanedetection_end2end_amd._refpath import extend as _extend
 from .ERFNet import Net
 
 model_dict = {'erfnet': Net}

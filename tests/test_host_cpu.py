@@ -124,3 +124,29 @@ def test_trapezoid_cpu(golden_fit):
     g = torch.tensor([[0.05, -0.1, 0.45], [0.01, 0.2, 0.5]], dtype=torch.float64)
     tz = polynomial(b.unsqueeze(2)).trapezoidal(polynomial(g))
     assert np.allclose(tz.numpy(), golden_fit["trapezoid_survey"], atol=1e-12)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Birds_Eye_View_Loss"), reason="reference tree not present")
+@pytest.mark.parametrize("tree,d", [("bev", "Birds_Eye_View_Loss"), ("bp", "Backprojection_Loss")])
+def test_mirror_shadows_reference_imports(tree, d):
+    """The reference's own import statements resolve to this package when the mirror tree precedes the
+    reference tree on sys.path, while Networks.utils still comes from the reference."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, types
+sys.path.insert(0, %r)
+sys.modules["cv2"] = types.ModuleType("cv2")
+os.environ["LANEFIT_REFERENCE_ROOT"] = "/root/reference"
+sys.path.insert(0, "/root/reference/%s")
+sys.path.insert(0, %r)
+import Networks
+from Networks.LSQ_layer import Net
+from Networks.utils import define_args
+from Loss_crit import define_loss_crit, polynomial
+assert Net.__module__ == "lanedetection_end2end_amd.lsq" and define_args.__module__ == "Networks.utils"
+assert Networks.model_dict["erfnet"].__module__.startswith("lanedetection_end2end_amd")
+print("ok")
+''' % (ROOT, d, os.path.join(ROOT, "lanedetection_end2end_amd", tree))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-800:]
