@@ -290,8 +290,8 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
 // ---------------------------------------------------------------------------------------
 namespace {
 
-template <bool XV, bool GV, int XT, int GT>
-__global__ __launch_bounds__(256) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
+template <bool XV, bool GV, int XT, int GT, int U>
+__global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
                                                       const long pps, const int write_bias) {
     constexpr int XTiles = XV ? 4 : XT, GTiles = GV ? 4 : GT;
     constexpr int XB = XTiles * 16, GB = GTiles * 16;
@@ -338,70 +338,99 @@ __global__ __launch_bounds__(256) void tapwgrad_kernel(const LfTapGeom g, const 
         }
     }
 
-    // raw operand loads for the pixel group starting at p - kq (unconditional, clamped; masked at use)
-    struct WStep { f32x4 x4, g4; float xs[XTiles], gs[GTiles]; bool valid, xin; };
-    auto wload = [&](WStep& S, long pp, int n_, int i_, int j_) {
-        S.valid = pp < p_end;
-        const int nn = S.valid ? n_ : 0, ii = S.valid ? i_ : 0, jj = S.valid ? j_ : 0;
-        const float* gp = a.g + ((long)(nn * g.Hd + ii * g.dsh + g.dah) * g.Wd + jj * g.dsw + g.daw) * g.d_pix + gch;
-        if constexpr (GV) S.g4 = ldg4(gp);
-        else {
-#pragma unroll
-            for (int q = 0; q < GTiles; ++q) S.gs[q] = gp[q * 16];
-        }
-        const int sy = ii * g.ssh + dh, sx = jj * g.ssw + dw;
-        S.xin = S.valid && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-        const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-        const float* xp = a.x + ((long)(nn * g.Hs + syc) * g.Ws + sxc) * g.s_pix + xch;
-        if constexpr (XV) S.x4 = ldg4(xp);
-        else {
-#pragma unroll
-            for (int r = 0; r < XTiles; ++r) S.xs[r] = xp[r * 16];
-        }
+    // One iteration = U k-steps = 4*U consecutive pixels of ONE image row (the launcher guarantees
+    // Wl % (4U) == 0 and pps % (4U) == 0), so a single (n,i,j) -> address computation serves U loads per
+    // operand.  Loads are unconditional (clamped address, masked at use) and double-buffered in two named
+    // register sets: the next iteration's 2U loads are in flight during the current 16*U MFMAs.
+    struct WStep {
+        f32x4 x4[XV ? U : 1], g4[GV ? U : 1];
+        float xs[XV ? 1 : U][XTiles], gs[GV ? 1 : U][GTiles];
+        unsigned vmask, xmask;
     };
-    auto advance = [&]() {
-        p += 4;
-        pj += 4;
-        if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
-    };
-
-    WStep cur, nxt;
-    wload(cur, p, pn, pi, pj);
-    bool more = p - kq < p_end;          // wave-uniform: p - kq is the same in every lane
-    while (more) {
-        advance();
-        more = p - kq < p_end;
-        if (more) wload(nxt, p, pn, pi, pj);
-        float xv[XTiles], gv[GTiles];
-        if constexpr (GV) { gv[0] = cur.g4.x; gv[1] = cur.g4.y; gv[2] = cur.g4.z; gv[3] = cur.g4.w; }
-        else {
+    auto wload = [&](WStep& S) {
+        unsigned vm = 0, xm = 0;
+        const bool rowv = (p - kq) < p_end;                  // whole group valid or not (p_end is a multiple of 4U or npix)
+        const int nn = rowv ? pn : 0, ii = rowv ? pi : 0, jj = rowv ? pj : 0;
+        // 32-bit element offsets from the (uniform) base pointers: one VGPR per address
+        const unsigned gofs = (unsigned)(((nn * g.Hd + ii * g.dsh + g.dah) * g.Wd + jj * g.dsw + g.daw) * g.d_pix + gch);
+        const unsigned gstep = (unsigned)(4 * g.dsw * g.d_pix);
+        const int sy = ii * g.ssh + dh;
+        const bool yin = sy >= 0 && sy < g.Hs;
+        const int syc = min(max(sy, 0), g.Hs - 1);
+        const unsigned xrow = (unsigned)((nn * g.Hs + syc) * g.Ws * g.s_pix + xch);
 #pragma unroll
-            for (int q = 0; q < GTiles; ++q) gv[q] = cur.gs[q];
-        }
+        for (int u = 0; u < U; ++u) {
+            const bool v = rowv && (p + 4 * u) < p_end;
+            vm |= (v ? 1u : 0u) << u;
+            const unsigned go = v ? gofs + u * gstep : gofs;
+            if constexpr (GV) S.g4[u] = ldg4(a.g + go);
+            else {
 #pragma unroll
-        for (int q = 0; q < GTiles; ++q) gv[q] = cur.valid ? gv[q] : 0.f;
-        if constexpr (XV) {
-            f32x4 v = cur.x4;
-            if (pro == LF_PRO_BNRELU) v = max0(v * psc + psh);
-            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
-        } else {
+                for (int q = 0; q < GTiles; ++q) S.gs[u][q] = a.g[go + q * 16];
+            }
+            const int sx = (jj + 4 * u) * g.ssw + dw;
+            const bool xin = v && yin && sx >= 0 && sx < g.Ws;
+            xm |= (xin ? 1u : 0u) << u;
+            const unsigned xo = xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix);
+            if constexpr (XV) S.x4[u] = ldg4(a.x + xo);
+            else {
 #pragma unroll
-            for (int r = 0; r < XTiles; ++r) {
-                float v = cur.xs[r];
-                if (pro == LF_PRO_BNRELU) v = fmaxf(v * psc1[r] + psh1[r], 0.f);
-                xv[r] = v;
+                for (int r = 0; r < XTiles; ++r) S.xs[u][r] = a.x[xo + r * 16];
             }
         }
+        S.vmask = vm; S.xmask = xm;
+    };
+    auto advance = [&]() {
+        p += 4 * U;
+        pj += 4 * U;
+        if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
+    };
+    auto compute = [&](const WStep& S) {
 #pragma unroll
-        for (int r = 0; r < XTiles; ++r) xv[r] = cur.xin ? xv[r] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            float xv[XTiles], gv[GTiles];
+            const bool v = (S.vmask >> u) & 1u, xin = (S.xmask >> u) & 1u;
+            if constexpr (GV) { gv[0] = S.g4[u].x; gv[1] = S.g4[u].y; gv[2] = S.g4[u].z; gv[3] = S.g4[u].w; }
+            else {
 #pragma unroll
-        for (int r = 0; r < XTiles; ++r)
+                for (int q = 0; q < GTiles; ++q) gv[q] = S.gs[u][q];
+            }
 #pragma unroll
-            for (int q = 0; q < GTiles; ++q)
-                acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r], gv[q], acc[r][q], 0, 0, 0);
+            for (int q = 0; q < GTiles; ++q) gv[q] = v ? gv[q] : 0.f;
+            if constexpr (XV) {
+                f32x4 t4 = S.x4[u];
+                if (pro == LF_PRO_BNRELU) t4 = max0(t4 * psc + psh);
+                xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
+            } else {
 #pragma unroll
-        for (int q = 0; q < GTiles; ++q) bsum[q] += gv[q];
-        if (more) cur = nxt;
+                for (int r = 0; r < XTiles; ++r) {
+                    float t1 = S.xs[u][r];
+                    if (pro == LF_PRO_BNRELU) t1 = fmaxf(t1 * psc1[r] + psh1[r], 0.f);
+                    xv[r] = t1;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < XTiles; ++r) xv[r] = xin ? xv[r] : 0.f;
+#pragma unroll
+            for (int r = 0; r < XTiles; ++r)
+#pragma unroll
+                for (int q = 0; q < GTiles; ++q)
+                    acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r], gv[q], acc[r][q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < GTiles; ++q) bsum[q] += gv[q];
+        }
+    };
+
+    WStep A, B;
+    wload(A);
+    while (p - kq < p_end) {           // wave-uniform: p - kq is the same in every lane
+        advance();
+        wload(B);                      // past the end: clamped, fully masked loads
+        compute(A);
+        if (!(p - kq < p_end)) break;
+        advance();
+        wload(A);
+        compute(B);
     }
 
     // ---- reduce the 4 waves of the workgroup through LDS, wave 0 writes one partial row
@@ -452,7 +481,7 @@ __global__ __launch_bounds__(256) void tapwgrad_kernel(const LfTapGeom g, const 
     }
 }
 
-struct WgradCfg { int xv, gv, xt, gt, gx; long pps; };
+struct WgradCfg { int xv, gv, xt, gt, gx, u; long pps; };
 
 WgradCfg wgrad_cfg(const LfTapGeom& g) {
     WgradCfg c;
@@ -468,8 +497,10 @@ WgradCfg wgrad_cfg(const LfTapGeom& g) {
     const long maxgx = (npix + 64 * WG_WAVES - 1) / (64 * WG_WAVES);   // at least 64 pixels per wave
     if (gx > maxgx) gx = (int)maxgx;
     if (gx < 1) gx = 1;
+    c.u = (g.Wl % 16 == 0) ? 4 : 1;           // k-steps per loop iteration (16 pixels of one row)
+    const int gran = 4 * c.u;
     long pps = (npix + (long)gx * WG_WAVES - 1) / ((long)gx * WG_WAVES);
-    pps = (pps + 3) / 4 * 4;
+    pps = (pps + gran - 1) / gran * gran;
     c.gx = (int)((npix + pps * WG_WAVES - 1) / (pps * WG_WAVES));
     c.pps = pps;
     return c;
@@ -483,12 +514,17 @@ int lf_tapwgrad_bias_rows(const LfTapGeom& g) { return wgrad_cfg(g).gx; }
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st) {
     LF_REQUIRE(g.Cs % 16 == 0 && g.Cd % 16 == 0, "tapwgrad: channels must be multiples of 16");
     LF_REQUIRE(g.Wl % 4 == 0, "tapwgrad: logical width %d must be a multiple of 4", g.Wl);
+    LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31) && (long)g.N * g.Hd * g.Wd * g.d_pix < (1L << 31),
+               "tapwgrad: tensor too large for 32-bit offsets");
     const WgradCfg c = wgrad_cfg(g);
     const int xb = c.xt * 16, gb = c.gt * 16;
     dim3 grid(c.gx, g.ntaps, (g.Cs / xb) * (g.Cd / gb));
     const int wb = a.bias_partial != nullptr;
-#define LF_WG(XV, GV, XT, GT) \
-    hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb)
+#define LF_WG(XV, GV, XT, GT)                                                                                     \
+    do {                                                                                                          \
+        if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb); \
+        else hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb);        \
+    } while (0)
     if (c.xv && c.gv) LF_WG(true, true, 4, 4);
     else if (c.xv && c.gt == 1) LF_WG(true, false, 4, 1);
     else if (c.xv && c.gt == 3) LF_WG(true, false, 4, 3);

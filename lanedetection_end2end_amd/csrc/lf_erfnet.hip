@@ -10,6 +10,8 @@
 // (2 M floats).  Train-mode BatchNorm = per-wave partial sums written by the producing conv's
 // epilogue + a tiny finalise kernel; the apply is fused into the next conv's operand load where
 // the dataflow allows (conv3x1_2) and into the residual/ReLU pass otherwise.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "lf_conv.h"
@@ -62,7 +64,8 @@ struct lf_erfnet_plan {
     long drop_floats;
     // optional per-kernel-family timing (bench.py roofline): HIP events around every MFMA launch
     mutable int prof_on = 0;
-    struct ProfRec { hipEvent_t a, b; int family; double flops; };
+    struct ProfRec { hipEvent_t a, b; int family; double flops; int layer; int Cs, Cd, ntaps; long npix; int epi; };
+    mutable int prof_layer = -1;
     mutable std::vector<ProfRec> prof;
 };
 
@@ -358,10 +361,11 @@ double gemm_flops(const LfTapGeom& g) { return 2.0 * (double)g.N * g.Hl * g.Wl *
 
 struct ProfScope {   // records a HIP event pair on the launch stream around one kernel when profiling is on
     const Ctx& c; int idx = -1;
-    ProfScope(const Ctx& ctx, int family, double flops) : c(ctx) {
+    ProfScope(const Ctx& ctx, int family, const LfTapGeom& g, int epi) : c(ctx) {
         if (!c.P->prof_on) return;
         lf_erfnet_plan::ProfRec r;
-        r.family = family; r.flops = flops;
+        r.family = family; r.flops = gemm_flops(g);
+        r.layer = c.P->prof_layer; r.Cs = g.Cs; r.Cd = g.Cd; r.ntaps = g.ntaps; r.npix = (long)g.N * g.Hl * g.Wl; r.epi = epi;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
         (void)hipEventRecord(r.a, c.st);
         c.P->prof.push_back(r);
@@ -373,7 +377,7 @@ struct ProfScope {   // records a HIP event pair on the launch stream around one
 int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const float* bias, int pro, int epi,
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
-    ProfScope ps(c, 0, gemm_flops(op.geom));
+    ProfScope ps(c, 0, op.geom, epi | (pro << 8));
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
 }
 
@@ -390,7 +394,9 @@ int forward_layers(const Ctx& c, const float* img) {
     const int N = P->N;
     float* stat0 = c.at(P->off_stat0);
     float* stat1 = c.at(P->off_stat1);
+    int layer_idx = 0;
     for (const Layer& L : P->layers) {
+        P->prof_layer = layer_idx++;
         const long npo = (long)N * L.Hout * L.Wout;
         if (L.kind == K_DOWN) {
             LfStatPart parts[2];
@@ -462,7 +468,7 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     a.partial = c.at(P->off_wpart);
     a.bias_partial = c.grads[cv.p_b] ? c.at(P->off_bpart) : nullptr;
     {
-        ProfScope ps(c, 1, gemm_flops(op.geom));
+        ProfScope ps(c, 1, op.geom, 0);
         LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, c.st));
     }
     const LfPackEntry& e = P->packs[op.pack];
@@ -485,6 +491,7 @@ int backward_layers(const Ctx& c, const float* img, float* gA, float* gB, float*
     float* stat0 = c.at(P->off_stat0);
     for (int li = (int)P->layers.size() - 1; li >= 0; --li) {
         const Layer& L = P->layers[li];
+        P->prof_layer = 100 + li;
         const long npo = (long)N * L.Hout * L.Wout;
         const long ppi = (long)L.Hout * L.Wout;
         if (L.kind == K_NB) {
@@ -620,13 +627,21 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
 int lf_erfnet_profile(const lf_erfnet_plan* P, int enable) { P->prof_on = enable; return 0; }
 int lf_erfnet_profile_read(const lf_erfnet_plan* P, double* out6) {
     for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+    FILE* f = nullptr;
+    if (const char* path = getenv("LF_PROFILE_CSV")) {
+        f = fopen(path, "w");
+        if (f) fprintf(f, "family,layer,Cs,Cd,ntaps,npix,epi,us,tflops\n");
+    }
     for (auto& r : P->prof) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             out6[r.family * 3 + 0] += ms; out6[r.family * 3 + 1] += r.flops; out6[r.family * 3 + 2] += 1.0;
+            if (f) fprintf(f, "%d,%d,%d,%d,%d,%ld,%d,%.2f,%.2f\n", r.family, r.layer, r.Cs, r.Cd, r.ntaps, r.npix, r.epi,
+                           ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
+    if (f) fclose(f);
     P->prof.clear();
     return 0;
 }
