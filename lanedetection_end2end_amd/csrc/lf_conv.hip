@@ -39,7 +39,7 @@ __device__ __forceinline__ float sum16(float v) {
     return v;
 }
 
-template <int NT, int VAR>
+template <int NT, int VAR, int PROC>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
             if (more) cur = nxt;
             t = tn; cg = cgn;
         }
-    } else {
+    } else if constexpr (VAR == 1) {
         // VAR 1: per-tap address setup (once per tap instead of once per 16 channels), pointer-increment
         // operand streams, two named register sets (no copy), next step's loads issued behind the first
         // quarter of the current step's MFMAs so that a single wave keeps the matrix pipe fed.
@@ -185,6 +185,86 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
                 mma(B, 1); mma(B, 2); mma(B, 3);
             }
         }
+    } else {
+        // VAR 2 (default): branch-free main loop.  Per-tap source offsets and validity bits are computed ONCE
+        // into an LDS table (one 16-byte row per lane and tap); the loop body is one basic block of two
+        // K-steps (128 MFMAs + ~20 loads) with scalar selects for the (tap, channel-group) counters, so the
+        // accumulators stay in place and the scheduler is free to sink loads between MFMAs.  Steps past the
+        // end (odd step counts) are issued with clamped addresses and a zero mask.
+        struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
+        __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
+        __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int dh = g.tdh[t], dw = g.tdw[t];
+            unsigned o[MT], okb = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+                const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+                const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+                o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4);
+                okb |= (in ? 1u : 0u) << m;
+            }
+            tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+            tab_ok[wave][t][lane] = okb;
+        }
+        // (each lane reads back only what it wrote: no barrier needed)
+        const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;
+        const int wstep = g.Cd * 16;                       // floats per 16-channel step
+        const int ntaps = g.ntaps;
+        int t_ld = 0, cg_ld = 0, wofs = 0;
+        auto issue = [&](Step& S) {
+            const bool live = t_ld < ntaps;
+            const int tc = live ? t_ld : ntaps - 1;
+            const uint4 o = tab_off[wave][tc][lane];
+            const unsigned okb = tab_ok[wave][tc][lane];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) S.w[n] = ldg4(wp + wofs + n * 64);
+            const int c16 = cg_ld * 16;
+            S.x[0] = ldg4(a.src + o.x + c16);
+            S.x[1] = ldg4(a.src + o.y + c16);
+            S.x[2] = ldg4(a.src + o.z + c16);
+            S.x[3] = ldg4(a.src + o.w + c16);
+            if constexpr (PROC == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + c16 + kq * 4); S.sh = ldg4(a.pro_sh + c16 + kq * 4); }
+            S.ok = live ? okb : 0u;
+            // advance (scalar selects, no branches); a dead step re-reads the last live operands
+            const int cgn = cg_ld + 1;
+            const bool wrap = cgn == ncg;
+            wofs = live ? wofs + wstep : wofs;
+            cg_ld = live ? (wrap ? 0 : cgn) : cg_ld;
+            t_ld = (live && wrap) ? t_ld + 1 : t_ld;
+        };
+        auto finish = [&](Step& S) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = S.x[m];
+                if constexpr (PROC == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
+                const bool in = (S.ok >> m) & 1u;
+                v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+                S.x[m] = v;
+            }
+        };
+        auto mma = [&](const Step& S, int s) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
+        };
+        static_assert(MT == 4, "tab_off packs 4 pixel tiles");
+        Step A, B;
+        issue(A);
+        const int npairs = (nsteps + 1) >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            finish(A);
+            mma(A, 0);
+            issue(B);
+            mma(A, 1); mma(A, 2); mma(A, 3);
+            finish(B);
+            mma(B, 0);
+            issue(A);
+            mma(B, 1); mma(B, 2); mma(B, 3);
+        }
     }
 
     // ---- epilogue: lane holds channels co = cob + n*16 + 4*kq + (0..3) of pixel (tile m, pl)
@@ -238,7 +318,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
     }
 }
 
-int g_tapgemm_variant = 1;
+int g_tapgemm_variant = 2;
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -266,10 +346,12 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     const int nt = pick_nt(g.Cd);
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31), "tapgemm: source tensor too large for 32-bit offsets");
-#define LF_TG(NTV)                                                                                             \
-    do {                                                                                                       \
-        if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), 0, st, g, a, pro, epi);           \
+#define LF_TG(NTV)                                                                                                       \
+    do {                                                                                                                 \
+        if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else if (g_tapgemm_variant == 1) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
     switch (nt) {
         case 4: LF_TG(4); break;
