@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);       // < 2^31, checked by the launcher
-    const unsigned tile0 = (blockIdx.x * WG_WAVES + wave) * (MT * 16);
+    // Workgroup b runs on XCD b % 8 (observed dispatch order).  Give every XCD a CONTIGUOUS range of pixel
+    // tiles so that the halo rows neighbouring tiles share (and both halves of blockIdx.y) meet in one L2.
+    unsigned bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
     const int cob = blockIdx.y * NT * 16;
 
     int pn[MT], pi[MT], pj[MT];
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
             const int j = threadIdx.x & 7, q = (threadIdx.x >> 3) & 3, n = threadIdx.x >> 5;
             const float v = sred[0][n][q][j] + sred[1][n][q][j] + sred[2][n][q][j] + sred[3][n][q][j];
             const int co = cob + n * 16 + q * 4 + (j & 3);
-            a.stats[((long)blockIdx.x * 2 + (j >> 2)) * g.Cd + co] = v;
+            a.stats[((long)bx * 2 + (j >> 2)) * g.Cd + co] = v;
         }
     }
 }
@@ -346,10 +350,12 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     const int nt = pick_nt(g.Cd);
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31), "tapgemm: source tensor too large for 32-bit offsets");
+    const int nsteps = g.ntaps * (g.Cs / 16);      // short loops: the LDS tap table of VAR 2 does not pay off
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
         if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (g_tapgemm_variant == 1) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else if (nsteps < 8) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi);    \
         else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
@@ -574,7 +580,7 @@ WgradCfg wgrad_cfg(const LfTapGeom& g) {
     const int xb = c.xt * 16, gb = c.gt * 16;
     const int jobs = g.ntaps * (g.Cs / xb) * (g.Cd / gb);
     const long npix = (long)g.N * g.Hl * g.Wl;
-    int gx = 3072 / (jobs * WG_WAVES);          // ~3 waves per SIMD over 256 CUs
+    int gx = 2048 / (jobs * WG_WAVES);          // 2 waves per SIMD (254 VGPRs) over 256 CUs: one full round
     if (gx < 1) gx = 1;
     const long maxgx = (npix + 64 * WG_WAVES - 1) / (64 * WG_WAVES);   // at least 64 pixels per wave
     if (gx > maxgx) gx = (int)maxgx;
@@ -647,20 +653,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         return;
     }
     const long per = (long)ntaps * Cs * Cd;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)wblocks * 256) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int r = 0;
-        for (; r + 4 <= splits; r += 4) {   // independent loads in flight, fixed summation order
-            s0 += partial[(long)r * per + i];
-            s1 += partial[(long)(r + 1) * per + i];
-            s2 += partial[(long)(r + 2) * per + i];
-            s3 += partial[(long)(r + 3) * per + i];
+    __shared__ float sw[4][64];
+    const int og = threadIdx.x & 63, sg = threadIdx.x >> 6;      // 64 outputs x 4 split groups
+    for (long base = (long)blockIdx.x * 64; base < per; base += (long)wblocks * 64) {
+        const long i = base + og;
+        float s0 = 0.f, s1 = 0.f;
+        if (i < per) {
+            int r = sg;
+            for (; r + 4 < splits; r += 8) { s0 += partial[(long)r * per + i]; s1 += partial[(long)(r + 4) * per + i]; }
+            for (; r < splits; r += 4) s0 += partial[(long)r * per + i];
         }
-        for (; r < splits; ++r) s0 += partial[(long)r * per + i];
-        const int n = (int)(i % Cd);
-        const long r2 = i / Cd;
-        const int k = (int)(r2 % Cs), t = (int)(r2 / Cs);
-        grad[k * sk + n * sn + ti.v[t]] = (s0 + s1) + (s2 + s3);
+        sw[sg][og] = s0 + s1;
+        __syncthreads();
+        if (sg == 0 && i < per) {
+            const float v = (sw[0][og] + sw[1][og]) + (sw[2][og] + sw[3][og]);
+            const int n = (int)(i % Cd);
+            const long r2 = i / Cd;
+            const int k = (int)(r2 % Cs), t = (int)(r2 / Cs);
+            grad[k * sk + n * sn + ti.v[t]] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -709,8 +721,8 @@ int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, 
     TapIdx ti;
     for (int i = 0; i < LF_MAX_TAPS; ++i) ti.v[i] = i < ntaps ? tapidx_host[i] : 0;
     const long per = (long)ntaps * Cs * Cd;
-    int wblocks = lf_cdiv(per, 256);
-    if (wblocks > 2048) wblocks = 2048;
+    int wblocks = lf_cdiv(per, 64);
+    if (wblocks > 4096) wblocks = 4096;
     const int bblocks = (bias_rows && bias_grad) ? lf_cdiv(Cd, 64) : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, partial, splits, ntaps, Cs, Cd, grad,
                        sk, sn, ti, wblocks, bias_rows, n_bias_rows, bias_grad, bias_accumulate);
