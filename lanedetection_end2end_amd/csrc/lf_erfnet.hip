@@ -66,6 +66,9 @@ struct lf_erfnet_plan {
     mutable int prof_on = 0;
     struct ProfRec { hipEvent_t a, b; int family; double flops; int layer; int Cs, Cd, ntaps; long npix; int epi; };
     mutable int prof_layer = -1;
+    // side stream for weight gradients (they only READ the gradient buffers the main stream ping-pongs)
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_main = nullptr, ev_side = nullptr;
     mutable std::vector<ProfRec> prof;
 };
 
@@ -307,7 +310,13 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     return P;
 }
 
-void lf_erfnet_plan_destroy(lf_erfnet_plan* P) { delete P; }
+void lf_erfnet_plan_destroy(lf_erfnet_plan* P) {
+    if (!P) return;
+    if (P->side) (void)hipStreamDestroy(P->side);
+    if (P->ev_main) (void)hipEventDestroy(P->ev_main);
+    if (P->ev_side) (void)hipEventDestroy(P->ev_side);
+    delete P;
+}
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)P->total_floats * sizeof(float); }
 int lf_erfnet_num_params(const lf_erfnet_plan* P) { return P->n_params; }
 int lf_erfnet_num_bn(const lf_erfnet_plan* P) { return P->n_bn; }
@@ -347,6 +356,22 @@ struct Ctx {
     const float* dropmask;           // device buffer or null
     int training;
     hipStream_t st;
+    hipStream_t side = nullptr;          // null: everything on st
+    mutable unsigned side_reads = 0;     // gradient buffers (bit 0 gA, 1 gB, 2 gC) an in-flight side-stream kernel reads
+    // side stream may start once everything enqueued on the main stream so far has finished
+    void fork() const {
+        if (!side) return;
+        (void)hipEventRecord(P->ev_main, st);
+        (void)hipStreamWaitEvent(side, P->ev_main, 0);
+    }
+    // main stream waits for everything enqueued on the side stream so far
+    void join() const {
+        if (!side) return;
+        (void)hipEventRecord(P->ev_side, side);
+        (void)hipStreamWaitEvent(st, P->ev_side, 0);
+        side_reads = 0;
+    }
+    void before_write(unsigned bufs) const { if (side_reads & bufs) join(); }
     float* at(long off) const { return ws + off; }
     const float* packed(int pack) const { return ws + P->off_packed + P->packs[pack].dst_off; }
 };
@@ -361,23 +386,24 @@ double gemm_flops(const LfTapGeom& g) { return 2.0 * (double)g.N * g.Hl * g.Wl *
 
 struct ProfScope {   // records a HIP event pair on the launch stream around one kernel when profiling is on
     const Ctx& c; int idx = -1;
-    ProfScope(const Ctx& ctx, int family, const LfTapGeom& g, int epi) : c(ctx) {
+    hipStream_t pst;
+    ProfScope(const Ctx& ctx, int family, const LfTapGeom& g, int epi, hipStream_t stream) : c(ctx), pst(stream) {
         if (!c.P->prof_on) return;
         lf_erfnet_plan::ProfRec r;
         r.family = family; r.flops = gemm_flops(g);
         r.layer = c.P->prof_layer; r.Cs = g.Cs; r.Cd = g.Cd; r.ntaps = g.ntaps; r.npix = (long)g.N * g.Hl * g.Wl; r.epi = epi;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-        (void)hipEventRecord(r.a, c.st);
+        (void)hipEventRecord(r.a, pst);
         c.P->prof.push_back(r);
         idx = (int)c.P->prof.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c.P->prof[idx].b, c.st); }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c.P->prof[idx].b, pst); }
 };
 
 int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const float* bias, int pro, int epi,
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
-    ProfScope ps(c, 0, op.geom, epi | (pro << 8));
+    ProfScope ps(c, 0, op.geom, epi | (pro << 8), c.st);
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
 }
 
@@ -458,23 +484,27 @@ int forward_layers(const Ctx& c, const float* img) {
     return 0;
 }
 
-// weight + bias gradient of one forward-geometry GEMM
+// weight + bias gradient of one forward-geometry GEMM; runs on the side stream (concurrently with the data
+// gradient of the same layer).  gbuf = bit of the gradient buffer it reads (see Ctx::side_reads).
 int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x, const float* g, const float* pro_sc,
-              const float* pro_sh, int bias_accumulate) {
+              const float* pro_sh, int bias_accumulate, unsigned gbuf) {
     const lf_erfnet_plan* P = c.P;
     if (!c.grads[cv.p_w]) return 0;
+    hipStream_t ws = c.side ? c.side : c.st;
+    c.fork();
+    c.side_reads |= gbuf;
     LfWgradArgs a;
     a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh;
     a.partial = c.at(P->off_wpart);
     a.bias_partial = c.grads[cv.p_b] ? c.at(P->off_bpart) : nullptr;
     {
-        ProfScope ps(c, 1, op.geom, 0);
-        LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, c.st));
+        ProfScope ps(c, 1, op.geom, 0, ws);
+        LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, ws));
     }
     const LfPackEntry& e = P->packs[op.pack];
     LF_TRY(lf_wgrad_reduce_launch(a.partial, lf_tapwgrad_splits(op.geom), op.geom.ntaps, op.geom.Cs, op.geom.Cd,
                                   c.grads[cv.p_w], e.sk, e.sn, e.tapidx, a.bias_partial, lf_tapwgrad_bias_rows(op.geom),
-                                  c.grads[cv.p_b], bias_accumulate, c.st));
+                                  c.grads[cv.p_b], bias_accumulate, ws));
     return 0;
 }
 
@@ -483,6 +513,8 @@ int bn_bwd_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int n
     if (!c.grads[b.p_g] || !c.grads[b.p_b]) return lf_fail("erfnet backward: BatchNorm weight/bias must both require grad");
     return lf_bn_bwd_finalize(parts, nparts, b.C, count, c.at(b.c1), c.at(b.c2), c.grads[b.p_g], c.grads[b.p_b], c.st);
 }
+
+enum { GA_ = 1u, GB_ = 2u, GC_ = 4u };
 
 int backward_layers(const Ctx& c, const float* img, float* gA, float* gB, float* gC) {
     // on entry gA holds d loss / d (output of the last block), NHWC
@@ -504,32 +536,38 @@ int backward_layers(const Ctx& c, const float* img, float* gA, float* gB, float*
             LF_TRY(lf_bn_bwd_reduce(gA, out, t4, c.at(b2.asc), c.at(b2.ash), dm, stat0, npo, L.Cout, ppi, c.st));
             LfStatPart rp = {stat0, rrows, L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, b2, &rp, 1, (double)npo));
+            c.before_write(GB_ | GC_);
             LF_TRY(lf_bn_bwd_apply(gA, out, t4, c.at(b2.asc), c.at(b2.ash), c.params[b2.p_g], c.at(b2.c1), c.at(b2.c2), dm,
                                    gB /*g_t4*/, gC /*g_z*/, npo, L.Cout, ppi, c.st));
-            // conv1x3_2: wgrad(t3, g_t4), dgrad -> g_t3 = (.) * [t3 > 0]
-            LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, gB, nullptr, nullptr, 0));
+            // conv1x3_2: wgrad(t3, g_t4) on the side stream, dgrad -> g_t3 = (.) * [t3 > 0]
+            LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, gB, nullptr, nullptr, 0, GB_));
             LfTapArgs a = no_args();
             a.mask_src = t3;
+            c.before_write(GA_);
             LF_TRY(run_gemm(c, L.cv[3].dg[0], gB, gA, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
             // conv3x1_2: input a = relu(bn1(t2)) recomputed on the fly
-            LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, gA, c.at(b1.sc), c.at(b1.sh), 0));
+            LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, gA, c.at(b1.sc), c.at(b1.sh), 0, GA_));
             a = no_args();
             a.aux = t2; a.msc = c.at(b1.sc); a.msh = c.at(b1.sh); a.asc = c.at(b1.asc); a.ash = c.at(b1.ash);
             a.stats = stat0;
+            c.before_write(GB_);
             LF_TRY(run_gemm(c, L.cv[2].dg[0], gA, gB /*g_y1*/, nullptr, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, a));
             LfStatPart sp = {stat0, lf_tapgemm_stat_rows(L.cv[2].dg[0].geom), L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, b1, &sp, 1, (double)npo));
+            c.before_write(GA_);
             LF_TRY(lf_bn_bwd_apply(gB, nullptr, t2, c.at(b1.asc), c.at(b1.ash), c.params[b1.p_g], c.at(b1.c1), c.at(b1.c2),
                                    nullptr, gA /*g_t2*/, nullptr, npo, L.Cout, ppi, c.st));
             // conv1x3_1
-            LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, gA, nullptr, nullptr, 0));
+            LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, gA, nullptr, nullptr, 0, GA_));
             a = no_args();
             a.mask_src = t1;
+            c.before_write(GB_);
             LF_TRY(run_gemm(c, L.cv[1].dg[0], gA, gB /*g_t1*/, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
             // conv3x1_1 (+ residual branch gradient g_z)
-            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, gB, nullptr, nullptr, 0));
+            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, gB, nullptr, nullptr, 0, GB_));
             a = no_args();
             a.add_src = gC;
+            c.before_write(GA_);
             LF_TRY(run_gemm(c, L.cv[0].dg[0], gB, gA, nullptr, LF_PRO_NONE, LF_EPI_ADD, a));
         } else {
             // y = relu(bn(cpre)); gA = g_y
@@ -538,13 +576,17 @@ int backward_layers(const Ctx& c, const float* img, float* gA, float* gB, float*
             LF_TRY(lf_bn_bwd_reduce(gA, y, cpre, c.at(b.asc), c.at(b.ash), nullptr, stat0, npo, L.Cout, ppi, c.st));
             LfStatPart rp = {stat0, lf_bn_bwd_reduce_rows(npo), L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, b, &rp, 1, (double)npo));
+            c.before_write(GB_);
             LF_TRY(lf_bn_bwd_apply(gA, y, cpre, c.at(b.asc), c.at(b.ash), c.params[b.p_g], c.at(b.c1), c.at(b.c2), nullptr,
                                    gB /*g_cpre*/, nullptr, npo, L.Cout, ppi, c.st));
             if (L.kind == K_UP) {
-                for (int ph = 0; ph < 4; ++ph) LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), gB, nullptr, nullptr, ph > 0));
+                for (int ph = 0; ph < 4; ++ph)
+                    LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), gB, nullptr, nullptr, ph > 0, GB_));
+                c.before_write(GA_);
                 LF_TRY(run_gemm(c, L.cv[0].dg[0], gB, gA, nullptr, LF_PRO_NONE, 0, no_args()));
             } else if (L.x < 0) {
-                // stem: weight gradient only (the image needs no gradient)
+                // stem: weight gradient only (the image needs no gradient); shares the split-K scratch -> join first
+                c.join();
                 const int Cc = 16 - L.Cin, rows = lf_stem_wgrad_rows(N, L.Hin, L.Win);
                 if (c.grads[L.cv[0].p_w]) {
                     LF_TRY(lf_stem_wgrad(img, gB, N, L.Cin, L.Hin, L.Win, c.at(P->off_wpart), c.at(P->off_bpart), c.st));
@@ -553,7 +595,8 @@ int backward_layers(const Ctx& c, const float* img, float* gA, float* gB, float*
                         LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, Cc, c.grads[L.cv[0].p_b], 0, c.st));
                 }
             } else {
-                LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], c.at(L.x), gB, nullptr, nullptr, 0));
+                LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], c.at(L.x), gB, nullptr, nullptr, 0, GB_));
+                c.before_write(GA_);
                 LF_TRY(lf_pool_bwd(c.at(L.x), gB, N, L.Hin, L.Win, L.Cin, L.Cout, L.Cout - L.Cin, gA, c.st));
                 for (int ph = 0; ph < 4; ++ph) {
                     LfTapArgs a = no_args();
@@ -607,6 +650,15 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
     LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_backward: workspace too small");
     LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_backward: head %d out of range", head);
     Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, 1, (hipStream_t)stream};
+    if (!getenv("LF_NO_SIDE_STREAM")) {
+        if (!P->side) {
+            if (hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&P->ev_main, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&P->ev_side, hipEventDisableTiming) != hipSuccess)
+                return lf_fail("lf_erfnet_backward: could not create the side stream");
+        }
+        c.side = P->side;
+    }
     float *gA = c.at(P->off_gA), *gB = c.at(P->off_gB), *gC = c.at(P->off_gC);
     const int h = P->H / 2, w = P->W / 2, K = P->Cout + head;
     const int pw = P->p_head_w[head], pb = P->p_head_b[head];
@@ -617,7 +669,9 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
         if (grads_host[pb]) LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, K, grads_host[pb], 0, c.st));
     }
     LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.st));
-    return backward_layers(c, img, gA, gB, gC);
+    LF_TRY(backward_layers(c, img, gA, gB, gC));
+    c.join();          // every gradient is complete once the caller's stream reaches this point
+    return 0;
 }
 
 // Per-kernel-family timing for the roofline report.  enable=1 starts recording a HIP event pair around
