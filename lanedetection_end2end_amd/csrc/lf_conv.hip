@@ -256,18 +256,41 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
                     acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
         };
         static_assert(MT == 4, "tab_off packs 4 pixel tiles");
-        Step A, B;
-        issue(A);
-        const int npairs = (nsteps + 1) >> 1;
-        for (int pr = 0; pr < npairs; ++pr) {
-            finish(A);
-            mma(A, 0);
-            issue(B);
-            mma(A, 1); mma(A, 2); mma(A, 3);
-            finish(B);
-            mma(B, 0);
+        if constexpr (VAR == 2) {
+            Step A, B;
             issue(A);
-            mma(B, 1); mma(B, 2); mma(B, 3);
+            const int npairs = (nsteps + 1) >> 1;
+            for (int pr = 0; pr < npairs; ++pr) {
+                finish(A);
+                mma(A, 0);
+                issue(B);
+                mma(A, 1); mma(A, 2); mma(A, 3);
+                finish(B);
+                mma(B, 0);
+                issue(A);
+                mma(B, 1); mma(B, 2); mma(B, 3);
+            }
+        } else {
+            // VAR 3: three register sets, loads issued TWO steps (~1.7 us of MFMA time) ahead of their use:
+            // an activation line that misses L2 takes ~1.4 us under load, more than one 64-MFMA step covers.
+            Step A, B, C;
+            issue(A);
+            issue(B);
+            const int ntrip = (nsteps + 2) / 3;
+            for (int tr = 0; tr < ntrip; ++tr) {
+                finish(A);
+                mma(A, 0);
+                issue(C);
+                mma(A, 1); mma(A, 2); mma(A, 3);
+                finish(B);
+                mma(B, 0);
+                issue(A);
+                mma(B, 1); mma(B, 2); mma(B, 3);
+                finish(C);
+                mma(C, 0);
+                issue(B);
+                mma(C, 1); mma(C, 2); mma(C, 3);
+            }
         }
     }
 
@@ -322,7 +345,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
     }
 }
 
-int g_tapgemm_variant = 2;
+int g_tapgemm_variant = 3;
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -356,8 +379,10 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (g_tapgemm_variant == 1) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (nsteps < 8) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi);    \
-        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
+        else if (g_tapgemm_variant == 2 && pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else if (g_tapgemm_variant == 2) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 3, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 3, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
     switch (nt) {
         case 4: LF_TG(4); break;
