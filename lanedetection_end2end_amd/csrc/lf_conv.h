@@ -46,7 +46,8 @@ struct LfTapArgs {
     const float* msh;
     const float* asc;       // [Cd] rstd, -mean*rstd (STATS_XHAT)
     const float* ash;
-    float* stats;           // [rows][2][Cd] per-wave partial sums, rows = lf_tapgemm_stat_rows()
+    float* stats;           // [rows][2][Cd] per-workgroup partial sums, rows = lf_tapgemm_stat_rows()
+    unsigned long long* dbg;  // optional: per-wave phase timestamps (s_memtime), 8 words per wave (tools/kbench.py --phases)
 };
 
 void lf_tapgemm_set_variant(int v);   // kernel A/B switch for tools/kbench.py (0 = simple loop, 1 = default)

@@ -43,6 +43,8 @@ template <int NT, int VAR, int PROC>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
+    unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
+    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memtime();
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);       // < 2^31, checked by the launcher
     // Workgroup b runs on XCD b % 8 (observed dispatch order).  Give every XCD a CONTIGUOUS range of pixel
     // tiles so that the halo rows neighbouring tiles share (and both halves of blockIdx.y) meet in one L2.
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
                     acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
         };
         static_assert(MT == 4, "tab_off packs 4 pixel tiles");
+        if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memtime();
         if constexpr (VAR == 2) {
             Step A, B;
             issue(A);
@@ -294,6 +297,10 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
         }
     }
 
+    if (a.dbg) {   // make the stamp wait for the last MFMA: touch one accumulator
+        asm volatile("" ::"v"(acc[0][0][0]));
+        tstamp[2] = __builtin_amdgcn_s_memtime();
+    }
     // ---- epilogue: lane holds channels co = cob + n*16 + 4*kq + (0..3) of pixel (tile m, pl)
     const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0;
     f32x4 s1[NT], s2[NT];
@@ -341,6 +348,14 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
             const float v = sred[0][n][q][j] + sred[1][n][q][j] + sred[2][n][q][j] + sred[3][n][q][j];
             const int co = cob + n * 16 + q * 4 + (j & 3);
             a.stats[((long)bx * 2 + (j >> 2)) * g.Cd + co] = v;
+        }
+    }
+    if (a.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp[3] = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WG_WAVES + wave) * 8;
+            d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
         }
     }
 }

@@ -35,6 +35,19 @@ extern "C" {
 
 void lf_debug_set_tapgemm_variant(int v) { lf_tapgemm_set_variant(v); }
 
+// same as lf_conv1d_fwd with per-wave phase timestamps: dbg receives 8 uint64 per wave
+// (start, tap table built, main loop done, stores retired); waves = ceil(N*H*W/256)*4*(C/64)
+int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C,
+                               int axis, int dilation, float* scratch, unsigned long long* dbg, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, 3L, 3L * C, 0);
+    LfTapArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = x; a.wp = scratch; a.bias = bias; a.dst = y; a.dbg = dbg;
+    return lf_tapgemm_launch(g, a, LF_PRO_NONE, 0, st);
+}
+
 // scratch floats needed by the three calls below (packed weights / split-K partials)
 long lf_conv1d_scratch_floats(int N, int H, int W, int C) {
     const LfTapGeom g = conv1d_geom(N, H, W, C, 0, 1);

@@ -81,5 +81,35 @@ def main():
                      flops / td / 1e12, e2, tw * 1e6, flops / tw / 1e12, e3, e4), flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--phases" not in sys.argv:
     main()
+
+
+def phases(batch=32):
+    """Per-wave phase breakdown of the forward tap-GEMM (s_memtime stamps): prologue / main loop / epilogue."""
+    import numpy as np
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for C, H, W, axis, d in [(128, 32, 64, 1, 16), (64, 64, 128, 1, 1)]:
+        N = batch
+        x = torch.randn(N, H, W, C, device="cuda")
+        w = torch.randn(C, C, 3, device="cuda") * 0.05
+        b = torch.randn(C, device="cuda")
+        y = torch.empty_like(x)
+        scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C), device="cuda")
+        nw = ((N * H * W + 255) // 256) * 4 * (C // 64)
+        dbg = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            _lib.check(lib.lf_debug_conv1d_fwd_phases(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, P(scratch), P(dbg), st), "phases")
+        torch.cuda.synchronize()
+        t = dbg.view(nw, 8).cpu().numpy().astype(np.float64)
+        t0 = t[:, 0].min()
+        pro, main, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+        print("C=%d N=%d waves=%d (s_memtime ticks): start spread %.0f | prologue %.0f | main loop %.0f (min %.0f max %.0f) | "
+              "epilogue %.0f | last end - first start %.0f" % (C, N, nw, (t[:, 0] - t0).max(), pro.mean(), main.mean(), main.min(),
+                                                               main.max(), epi.mean(), t[:, 3].max() - t0), flush=True)
+
+
+if __name__ == "__main__" and "--phases" in sys.argv:
+    for nb in (16, 32, 64):
+        phases(nb)
