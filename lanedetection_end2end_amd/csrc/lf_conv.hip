@@ -48,10 +48,15 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);       // < 2^31, checked by the launcher
     // Workgroup b runs on XCD b % 8 (observed dispatch order).  Give every XCD a CONTIGUOUS range of pixel
     // tiles so that the halo rows neighbouring tiles share (and both halves of blockIdx.y) meet in one L2.
-    unsigned bx = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
-    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
+    // Persistent over pixel tiles: when there are more tiles than resident workgroups a wave walks several
+    // tiles back to back, so its epilogue stores / next prologue overlap the other resident waves' MFMAs
+    // instead of every wave of the chip doing them in lockstep at kernel start and end.
+    const unsigned ntiles = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
     const int cob = blockIdx.y * NT * 16;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    unsigned bx = tile;
+    if ((ntiles & 7u) == 0) bx = (bx & 7u) * (ntiles >> 3) + (bx >> 3);
+    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
 
     int pn[MT], pi[MT], pj[MT];
     bool pv[MT];
@@ -350,6 +355,8 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
             a.stats[((long)bx * 2 + (j >> 2)) * g.Cd + co] = v;
         }
     }
+    if (stats) __syncthreads();      // sred is reused by the next tile
+    }   // persistent tile loop
     if (a.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memtime();
@@ -361,6 +368,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
 }
 
 int g_tapgemm_variant = 3;
+int g_tapgemm_persist = 1;
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -372,7 +380,7 @@ int pick_nt(int Cd) {
 
 }  // namespace
 
-void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
+void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v % 10; g_tapgemm_persist = v < 10; }   // v >= 10: one tile per workgroup
 
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;
@@ -386,7 +394,15 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     const long npix = (long)g.N * g.Hl * g.Wl;
     LF_REQUIRE(npix < (1L << 30), "tapgemm: too many pixels (%ld)", npix);
     const int nt = pick_nt(g.Cd);
-    dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
+    const int gy = g.Cd / (16 * nt);
+    int gxp = lf_cdiv(npix, PIX_PER_WG);
+    const int resident = (2 * 256) / gy;           // 2 workgroups (8 waves, 2 per SIMD) per CU, 256 CUs
+    if (g_tapgemm_persist && gxp > resident) {
+        // keep the per-XCD contiguity (tile id remap needs gridDim-independent math) and an even split
+        const int rounds = lf_cdiv(gxp, resident);
+        gxp = lf_cdiv(gxp, rounds);
+    }
+    dim3 grid(gxp, gy);
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31), "tapgemm: source tensor too large for 32-bit offsets");
     const int nsteps = g.ntaps * (g.Cs / 16);      // short loops: the LDS tap table of VAR 2 does not pay off
 #define LF_TG(NTV)                                                                                                       \
