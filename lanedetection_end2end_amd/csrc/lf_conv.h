@@ -46,6 +46,7 @@ struct LfTapArgs {
     const float* msh;
     const float* asc;       // [Cd] rstd, -mean*rstd (STATS_XHAT)
     const float* ash;
+    const float* dm;        // optional Dropout2d keep-mask [N][Cd] applied to the STATS_XHAT sums only (gm = v * dm)
     float* stats;           // [rows][2][Cd] per-workgroup partial sums, rows = lf_tapgemm_stat_rows()
     unsigned long long* dbg;  // optional: per-wave phase timestamps (s_memtime), 8 words per wave (tools/kbench.py --phases)
 };

@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
             if (epi & LF_EPI_RELU) v = max0(v);
             *reinterpret_cast<f32x4*>(a.dst + doff) = v;
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; }
-            if (epi & LF_EPI_STATS_XHAT) { s1[n] += v; s2[n] += v * (ax * asc + ash); }
+            if (epi & LF_EPI_STATS_XHAT) {
+                const f32x4 gm = a.dm ? v * ldg4(a.dm + (long)pn[m] * g.Cd + co) : v;
+                s1[n] += gm; s2[n] += gm * (ax * asc + ash);
+            }
         }
     }
     if (stats) {   // one partial row per WORKGROUP: 16-lane shuffles, then the 4 waves through LDS
@@ -367,8 +370,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
     }
 }
 
-int g_tapgemm_variant = 3;
-int g_tapgemm_persist = 1;
+int g_tapgemm_variant = 2;     // measured best on MI355X (tools/kbench.py): 2-set ring; the 3-set ring spills into the 256-VGPR cap
+int g_tapgemm_persist = 0;     // persistent tiles: neutral at batch 32 (one or two rounds), kept as a switch
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -380,7 +383,7 @@ int pick_nt(int Cd) {
 
 }  // namespace
 
-void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v % 10; g_tapgemm_persist = v < 10; }   // v >= 10: one tile per workgroup
+void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v % 10; g_tapgemm_persist = v >= 10; }   // v >= 10: persistent tiles
 
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;

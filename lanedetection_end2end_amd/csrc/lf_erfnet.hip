@@ -514,97 +514,155 @@ int bn_bwd_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int n
     return lf_bn_bwd_finalize(parts, nparts, b.C, count, c.at(b.c1), c.at(b.c2), c.grads[b.p_g], c.grads[b.p_b], c.st);
 }
 
-enum { GA_ = 1u, GB_ = 2u, GC_ = 4u };
+// What the LAST data-gradient launch of layer L can do on behalf of layer L-1 (whose output it differentiates):
+// apply L-1's final ReLU mask, and accumulate the sums of L-1's last BatchNorm backward -- so L-1 starts with
+// g_z = g * [y > 0] already in memory and needs no separate reduction pass.
+struct Prep {
+    const float* y = nullptr;      // L-1 output (post ReLU)
+    const float* pre = nullptr;    // L-1 pre-BN tensor
+    const BNRef* bn = nullptr;
+    const float* dm = nullptr;
+};
 
-int backward_layers(const Ctx& c, const float* img, float* gA, float* gB, float* gC) {
-    // on entry gA holds d loss / d (output of the last block), NHWC
+Prep prep_for(const Ctx& c, const Layer& Lp) {
+    Prep p;
+    if (Lp.kind == K_NB) {
+        p.y = c.at(Lp.b[4]); p.pre = c.at(Lp.b[3]); p.bn = &Lp.bn[1];
+        p.dm = (Lp.drop_idx >= 0 && c.dropmask) ? c.dropmask + c.P->drop_off[Lp.drop_idx] : nullptr;
+    } else {
+        p.y = c.at(Lp.b[1]); p.pre = c.at(Lp.b[0]); p.bn = &Lp.bn[0];
+    }
+    return p;
+}
+
+int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float* g2) {
+    // on entry g0 holds d loss / d (output of the last block), NHWC.  The three buffers rotate roles:
+    // `in` = incoming gradient, X / Y = scratch; every layer leaves its result in one of them.
     const lf_erfnet_plan* P = c.P;
     const int N = P->N;
     float* stat0 = c.at(P->off_stat0);
+    float* bufs[3] = {g0, g1, g2};
+    auto bit = [&](const float* p) -> unsigned { return p == bufs[0] ? 1u : (p == bufs[1] ? 2u : 4u); };
+    float* in = g0;
+    bool prepped = false;        // `in` already masked by the layer's output ReLU, BN sums in stat0
+    int prep_rows = 0;
+    const bool fuse = !getenv("LF_NO_BWD_FUSE");
     for (int li = (int)P->layers.size() - 1; li >= 0; --li) {
         const Layer& L = P->layers[li];
         P->prof_layer = 100 + li;
         const long npo = (long)N * L.Hout * L.Wout;
         const long ppi = (long)L.Hout * L.Wout;
+        const int iin = in == bufs[0] ? 0 : (in == bufs[1] ? 1 : 2);
+        float* X = bufs[(iin + 1) % 3];
+        float* Y = bufs[(iin + 2) % 3];
+        // gradient preparation the final dgrad of THIS layer performs for the previous one
+        Prep nx;
+        const bool can_prep = fuse && li > 0 && (L.kind == K_NB || L.kind == K_UP);
+        if (can_prep) nx = prep_for(c, P->layers[li - 1]);
+        auto add_prep = [&](LfTapArgs& a, int& epi) {
+            if (!can_prep) return;
+            a.mask_src = nx.y; a.aux = nx.pre; a.asc = c.at(nx.bn->asc); a.ash = c.at(nx.bn->ash); a.dm = nx.dm;
+            a.stats = stat0;
+            epi |= LF_EPI_MASK | LF_EPI_STATS_XHAT;
+        };
+        const BNRef& blast = L.kind == K_NB ? L.bn[1] : L.bn[0];
+        const float* ylast = c.at(L.kind == K_NB ? L.b[4] : L.b[1]);
+        const float* prelast = c.at(L.kind == K_NB ? L.b[3] : L.b[0]);
+        const float* dm = (L.kind == K_NB && L.drop_idx >= 0 && c.dropmask) ? c.dropmask + P->drop_off[L.drop_idx] : nullptr;
+        // ---- last BatchNorm (+dropout +residual) + ReLU backward: g_pre -> X ; g_z (masked incoming gradient)
+        const float* gz;
+        if (!prepped) {
+            LF_TRY(lf_bn_bwd_reduce(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), dm, stat0, npo, L.Cout, ppi, c.st));
+            LfStatPart rp = {stat0, lf_bn_bwd_reduce_rows(npo), L.Cout, 0};
+            LF_TRY(bn_bwd_finalize(c, blast, &rp, 1, (double)npo));
+            c.before_write(bit(X) | bit(Y));
+            LF_TRY(lf_bn_bwd_apply(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), c.params[blast.p_g], c.at(blast.c1),
+                                   c.at(blast.c2), dm, X, L.kind == K_NB ? Y : nullptr, npo, L.Cout, ppi, c.st));
+            gz = Y;
+            // `in` is free from here on
+        } else {
+            LfStatPart rp = {stat0, prep_rows, L.Cout, 0};
+            LF_TRY(bn_bwd_finalize(c, blast, &rp, 1, (double)npo));
+            c.before_write(bit(X));
+            LF_TRY(lf_bn_bwd_apply(in, nullptr, prelast, c.at(blast.asc), c.at(blast.ash), c.params[blast.p_g], c.at(blast.c1),
+                                   c.at(blast.c2), dm, X, nullptr, npo, L.Cout, ppi, c.st));
+            gz = in;
+            // Y is free; `in` must survive until the residual add
+        }
+        float* F = prepped ? Y : in;       // the free scratch buffer (the other of {in, Y} holds g_z)
+        float* out = nullptr;              // where this layer leaves d loss / d (its input)
+        prepped = false;
         if (L.kind == K_NB) {
             const float* x = c.at(L.x);
-            const float *t1 = c.at(L.b[0]), *t2 = c.at(L.b[1]), *t3 = c.at(L.b[2]), *t4 = c.at(L.b[3]), *out = c.at(L.b[4]);
-            const BNRef &b1 = L.bn[0], &b2 = L.bn[1];
-            const float* dm = (L.drop_idx >= 0 && c.dropmask) ? c.dropmask + P->drop_off[L.drop_idx] : nullptr;
-            const int rrows = lf_bn_bwd_reduce_rows(npo);
-            // bn2 + dropout + residual + relu backward
-            LF_TRY(lf_bn_bwd_reduce(gA, out, t4, c.at(b2.asc), c.at(b2.ash), dm, stat0, npo, L.Cout, ppi, c.st));
-            LfStatPart rp = {stat0, rrows, L.Cout, 0};
-            LF_TRY(bn_bwd_finalize(c, b2, &rp, 1, (double)npo));
-            c.before_write(GB_ | GC_);
-            LF_TRY(lf_bn_bwd_apply(gA, out, t4, c.at(b2.asc), c.at(b2.ash), c.params[b2.p_g], c.at(b2.c1), c.at(b2.c2), dm,
-                                   gB /*g_t4*/, gC /*g_z*/, npo, L.Cout, ppi, c.st));
-            // conv1x3_2: wgrad(t3, g_t4) on the side stream, dgrad -> g_t3 = (.) * [t3 > 0]
-            LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, gB, nullptr, nullptr, 0, GB_));
+            const float *t1 = c.at(L.b[0]), *t2 = c.at(L.b[1]), *t3 = c.at(L.b[2]);
+            const BNRef& b1 = L.bn[0];
+            // conv1x3_2: wgrad(t3, g_t4 = X); dgrad -> g_t3 = (.) * [t3 > 0] -> F
+            LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, X, nullptr, nullptr, 0, bit(X)));
             LfTapArgs a = no_args();
             a.mask_src = t3;
-            c.before_write(GA_);
-            LF_TRY(run_gemm(c, L.cv[3].dg[0], gB, gA, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
-            // conv3x1_2: input a = relu(bn1(t2)) recomputed on the fly
-            LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, gA, c.at(b1.sc), c.at(b1.sh), 0, GA_));
+            c.before_write(bit(F));
+            LF_TRY(run_gemm(c, L.cv[3].dg[0], X, F, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
+            // conv3x1_2: input relu(bn1(t2)) recomputed on the fly; g_y1 -> X with the bn1-backward sums
+            LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, F, c.at(b1.sc), c.at(b1.sh), 0, bit(F)));
             a = no_args();
             a.aux = t2; a.msc = c.at(b1.sc); a.msh = c.at(b1.sh); a.asc = c.at(b1.asc); a.ash = c.at(b1.ash);
             a.stats = stat0;
-            c.before_write(GB_);
-            LF_TRY(run_gemm(c, L.cv[2].dg[0], gA, gB /*g_y1*/, nullptr, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, a));
+            c.before_write(bit(X));
+            LF_TRY(run_gemm(c, L.cv[2].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, a));
             LfStatPart sp = {stat0, lf_tapgemm_stat_rows(L.cv[2].dg[0].geom), L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, b1, &sp, 1, (double)npo));
-            c.before_write(GA_);
-            LF_TRY(lf_bn_bwd_apply(gB, nullptr, t2, c.at(b1.asc), c.at(b1.ash), c.params[b1.p_g], c.at(b1.c1), c.at(b1.c2),
-                                   nullptr, gA /*g_t2*/, nullptr, npo, L.Cout, ppi, c.st));
-            // conv1x3_1
-            LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, gA, nullptr, nullptr, 0, GA_));
+            c.before_write(bit(F));
+            LF_TRY(lf_bn_bwd_apply(X, nullptr, t2, c.at(b1.asc), c.at(b1.ash), c.params[b1.p_g], c.at(b1.c1), c.at(b1.c2),
+                                   nullptr, F /*g_t2*/, nullptr, npo, L.Cout, ppi, c.st));
+            // conv1x3_1: g_t1 -> X
+            LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, F, nullptr, nullptr, 0, bit(F)));
             a = no_args();
             a.mask_src = t1;
-            c.before_write(GB_);
-            LF_TRY(run_gemm(c, L.cv[1].dg[0], gA, gB /*g_t1*/, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
-            // conv3x1_1 (+ residual branch gradient g_z)
-            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, gB, nullptr, nullptr, 0, GB_));
+            c.before_write(bit(X));
+            LF_TRY(run_gemm(c, L.cv[1].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
+            // conv3x1_1 (+ residual branch gradient g_z) -> F, optionally prepared for the previous layer
+            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, X, nullptr, nullptr, 0, bit(X)));
             a = no_args();
-            a.add_src = gC;
-            c.before_write(GA_);
-            LF_TRY(run_gemm(c, L.cv[0].dg[0], gB, gA, nullptr, LF_PRO_NONE, LF_EPI_ADD, a));
-        } else {
-            // y = relu(bn(cpre)); gA = g_y
-            const BNRef& b = L.bn[0];
-            const float *cpre = c.at(L.b[0]), *y = c.at(L.b[1]);
-            LF_TRY(lf_bn_bwd_reduce(gA, y, cpre, c.at(b.asc), c.at(b.ash), nullptr, stat0, npo, L.Cout, ppi, c.st));
-            LfStatPart rp = {stat0, lf_bn_bwd_reduce_rows(npo), L.Cout, 0};
-            LF_TRY(bn_bwd_finalize(c, b, &rp, 1, (double)npo));
-            c.before_write(GB_);
-            LF_TRY(lf_bn_bwd_apply(gA, y, cpre, c.at(b.asc), c.at(b.ash), c.params[b.p_g], c.at(b.c1), c.at(b.c2), nullptr,
-                                   gB /*g_cpre*/, nullptr, npo, L.Cout, ppi, c.st));
-            if (L.kind == K_UP) {
-                for (int ph = 0; ph < 4; ++ph)
-                    LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), gB, nullptr, nullptr, ph > 0, GB_));
-                c.before_write(GA_);
-                LF_TRY(run_gemm(c, L.cv[0].dg[0], gB, gA, nullptr, LF_PRO_NONE, 0, no_args()));
-            } else if (L.x < 0) {
-                // stem: weight gradient only (the image needs no gradient); shares the split-K scratch -> join first
-                c.join();
-                const int Cc = 16 - L.Cin, rows = lf_stem_wgrad_rows(N, L.Hin, L.Win);
-                if (c.grads[L.cv[0].p_w]) {
-                    LF_TRY(lf_stem_wgrad(img, gB, N, L.Cin, L.Hin, L.Win, c.at(P->off_wpart), c.at(P->off_bpart), c.st));
-                    LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, Cc * L.Cin * 9, c.grads[L.cv[0].p_w], 0, c.st));
-                    if (c.grads[L.cv[0].p_b])
-                        LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, Cc, c.grads[L.cv[0].p_b], 0, c.st));
-                }
-            } else {
-                LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], c.at(L.x), gB, nullptr, nullptr, 0, GB_));
-                c.before_write(GA_);
-                LF_TRY(lf_pool_bwd(c.at(L.x), gB, N, L.Hin, L.Win, L.Cin, L.Cout, L.Cout - L.Cin, gA, c.st));
-                for (int ph = 0; ph < 4; ++ph) {
-                    LfTapArgs a = no_args();
-                    a.add_src = gA;
-                    LF_TRY(run_gemm(c, L.cv[0].dg[ph], gB, gA, nullptr, LF_PRO_NONE, LF_EPI_ADD, a));
-                }
+            a.add_src = gz;
+            int epi = LF_EPI_ADD;
+            add_prep(a, epi);
+            c.before_write(bit(F));
+            LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a));
+            out = F;
+            if (can_prep) { prepped = true; prep_rows = lf_tapgemm_stat_rows(L.cv[0].dg[0].geom); }
+        } else if (L.kind == K_UP) {
+            for (int ph = 0; ph < 4; ++ph)
+                LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, ph > 0, bit(X)));
+            LfTapArgs a = no_args();
+            int epi = 0;
+            add_prep(a, epi);
+            c.before_write(bit(F));
+            LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a));
+            out = F;
+            if (can_prep) { prepped = true; prep_rows = lf_tapgemm_stat_rows(L.cv[0].dg[0].geom); }
+        } else if (L.x < 0) {
+            // stem: weight gradient only (the image needs no gradient); shares the split-K scratch -> join first
+            c.join();
+            const int Cc = 16 - L.Cin, rows = lf_stem_wgrad_rows(N, L.Hin, L.Win);
+            if (c.grads[L.cv[0].p_w]) {
+                LF_TRY(lf_stem_wgrad(img, X, N, L.Cin, L.Hin, L.Win, c.at(P->off_wpart), c.at(P->off_bpart), c.st));
+                LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, Cc * L.Cin * 9, c.grads[L.cv[0].p_w], 0, c.st));
+                if (c.grads[L.cv[0].p_b])
+                    LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, Cc, c.grads[L.cv[0].p_b], 0, c.st));
             }
+            out = F;
+        } else {
+            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], c.at(L.x), X, nullptr, nullptr, 0, bit(X)));
+            c.before_write(bit(F));
+            LF_TRY(lf_pool_bwd(c.at(L.x), X, N, L.Hin, L.Win, L.Cin, L.Cout, L.Cout - L.Cin, F, c.st));
+            for (int ph = 0; ph < 4; ++ph) {
+                LfTapArgs a = no_args();
+                a.add_src = F;
+                LF_TRY(run_gemm(c, L.cv[0].dg[ph], X, F, nullptr, LF_PRO_NONE, LF_EPI_ADD, a));
+            }
+            out = F;
         }
+        in = out;
     }
     return 0;
 }
