@@ -40,7 +40,7 @@ __device__ __forceinline__ float sum16(float v) {
 }
 
 template <int NT, int VAR, int PROC>
-__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+__global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
@@ -48,14 +48,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);       // < 2^31, checked by the launcher
     // Workgroup b runs on XCD b % 8 (observed dispatch order).  Give every XCD a CONTIGUOUS range of pixel
     // tiles so that the halo rows neighbouring tiles share (and both halves of blockIdx.y) meet in one L2.
-    // Persistent over pixel tiles: when there are more tiles than resident workgroups a wave walks several
-    // tiles back to back, so its epilogue stores / next prologue overlap the other resident waves' MFMAs
-    // instead of every wave of the chip doing them in lockstep at kernel start and end.
-    const unsigned ntiles = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
+    // (A persistent loop over tiles and a 3-set operand ring were measured and dropped: at batch 32 every
+    // layer is one or two rounds of resident workgroups, and the extra live state cost more than it hid.)
     const int cob = blockIdx.y * NT * 16;
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    unsigned bx = tile;
-    if ((ntiles & 7u) == 0) bx = (bx & 7u) * (ntiles >> 3) + (bx >> 3);
+    unsigned bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
     const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
 
     int pn[MT], pi[MT], pj[MT];
@@ -264,41 +261,18 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         };
         static_assert(MT == 4, "tab_off packs 4 pixel tiles");
         if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memtime();
-        if constexpr (VAR == 2) {
-            Step A, B;
-            issue(A);
-            const int npairs = (nsteps + 1) >> 1;
-            for (int pr = 0; pr < npairs; ++pr) {
-                finish(A);
-                mma(A, 0);
-                issue(B);
-                mma(A, 1); mma(A, 2); mma(A, 3);
-                finish(B);
-                mma(B, 0);
-                issue(A);
-                mma(B, 1); mma(B, 2); mma(B, 3);
-            }
-        } else {
-            // VAR 3: three register sets, loads issued TWO steps (~1.7 us of MFMA time) ahead of their use:
-            // an activation line that misses L2 takes ~1.4 us under load, more than one 64-MFMA step covers.
-            Step A, B, C;
-            issue(A);
+        Step A, B;
+        issue(A);
+        const int npairs = (nsteps + 1) >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            finish(A);
+            mma(A, 0);
             issue(B);
-            const int ntrip = (nsteps + 2) / 3;
-            for (int tr = 0; tr < ntrip; ++tr) {
-                finish(A);
-                mma(A, 0);
-                issue(C);
-                mma(A, 1); mma(A, 2); mma(A, 3);
-                finish(B);
-                mma(B, 0);
-                issue(A);
-                mma(B, 1); mma(B, 2); mma(B, 3);
-                finish(C);
-                mma(C, 0);
-                issue(B);
-                mma(C, 1); mma(C, 2); mma(C, 3);
-            }
+            mma(A, 1); mma(A, 2); mma(A, 3);
+            finish(B);
+            mma(B, 0);
+            issue(A);
+            mma(B, 1); mma(B, 2); mma(B, 3);
         }
     }
 
@@ -358,8 +332,6 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
             a.stats[((long)bx * 2 + (j >> 2)) * g.Cd + co] = v;
         }
     }
-    if (stats) __syncthreads();      // sred is reused by the next tile
-    }   // persistent tile loop
     if (a.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memtime();
@@ -370,8 +342,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
     }
 }
 
-int g_tapgemm_variant = 2;     // measured best on MI355X (tools/kbench.py): 2-set ring; the 3-set ring spills into the 256-VGPR cap
-int g_tapgemm_persist = 0;     // persistent tiles: neutral at batch 32 (one or two rounds), kept as a switch
+int g_tapgemm_variant = 2;     // 0 simple loop, 1 ping-pong with per-tap setup, 2 (default) branch-free loop with LDS tap table
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -383,7 +354,7 @@ int pick_nt(int Cd) {
 
 }  // namespace
 
-void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v % 10; g_tapgemm_persist = v >= 10; }   // v >= 10: persistent tiles
+void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
 
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;
@@ -397,15 +368,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     const long npix = (long)g.N * g.Hl * g.Wl;
     LF_REQUIRE(npix < (1L << 30), "tapgemm: too many pixels (%ld)", npix);
     const int nt = pick_nt(g.Cd);
-    const int gy = g.Cd / (16 * nt);
-    int gxp = lf_cdiv(npix, PIX_PER_WG);
-    const int resident = (2 * 256) / gy;           // 2 workgroups (8 waves, 2 per SIMD) per CU, 256 CUs
-    if (g_tapgemm_persist && gxp > resident) {
-        // keep the per-XCD contiguity (tile id remap needs gridDim-independent math) and an even split
-        const int rounds = lf_cdiv(gxp, resident);
-        gxp = lf_cdiv(gxp, rounds);
-    }
-    dim3 grid(gxp, gy);
+    dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31), "tapgemm: source tensor too large for 32-bit offsets");
     const int nsteps = g.ntaps * (g.Cs / 16);      // short loops: the LDS tap table of VAR 2 does not pay off
 #define LF_TG(NTV)                                                                                                       \
@@ -413,10 +376,8 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (g_tapgemm_variant == 1) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (nsteps < 8) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi);    \
-        else if (g_tapgemm_variant == 2 && pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else if (g_tapgemm_variant == 2) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 3, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 3, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
+        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
     switch (nt) {
         case 4: LF_TG(4); break;
