@@ -257,14 +257,18 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 }
 
 // ---- stem --------------------------------------------------------------------------------
+// Compile-time channel count: the 3x3xCIN patch lives in registers, the (16-CIN) x 9*CIN weights are read
+// as LDS broadcasts in a fully unrolled FMA nest (runtime loop bounds made this kernel 5x slower).
 constexpr int STEM_MAXCIN = 4;
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, int N, int Cin, int H, int W,
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, int N, int H, int W,
                                                       const float* __restrict__ w, const float* __restrict__ b,
                                                       float* __restrict__ cat, float* __restrict__ rows) {
-    const int Cc = 16 - Cin, Ho = H / 2, Wo = W / 2, KK = Cin * 9;
-    __shared__ float sw[16 * STEM_MAXCIN * 9 + 16];
+    constexpr int Cc = 16 - CIN, KK = CIN * 9;
+    const int Ho = H / 2, Wo = W / 2;
+    __shared__ float sw[Cc * KK + 16];
     for (int i = threadIdx.x; i < Cc * KK; i += 256) sw[i] = w[i];
-    for (int i = threadIdx.x; i < Cc; i += 256) sw[16 * STEM_MAXCIN * 9 + i] = b[i];
+    for (int i = threadIdx.x; i < Cc; i += 256) sw[Cc * KK + i] = b[i];
     __syncthreads();
     const long npix = (long)N * Ho * Wo;
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
@@ -276,23 +280,29 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         const int ow = (int)(p % Wo);
         const long r = p / Wo;
         const int oh = (int)(r % Ho), n = (int)(r / Ho);
-        float patch[STEM_MAXCIN * 9];
-        for (int ci = 0; ci < Cin; ++ci) {
-            const float* pl = img + ((long)n * Cin + ci) * H * W;
+        float patch[KK];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float* pl = img + ((long)n * CIN + ci) * H * W;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
                     const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
-                    patch[ci * 9 + kh * 3 + kw] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? pl[(long)ih * W + iw] : 0.f;
+                    const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                    const float v = pl[(long)min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)];
+                    patch[ci * 9 + kh * 3 + kw] = in ? v : 0.f;
                 }
         }
+#pragma unroll
         for (int co = 0; co < Cc; ++co) {
-            float s = sw[16 * STEM_MAXCIN * 9 + co];
+            float s = sw[Cc * KK + co];
+#pragma unroll
             for (int j = 0; j < KK; ++j) s = fmaf(patch[j], sw[co * KK + j], s);
             out[co] = s;
         }
-        for (int ci = 0; ci < Cin; ++ci)   // pool window = patch taps (1,1),(1,2),(2,1),(2,2)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)   // pool window = patch taps (1,1),(1,2),(2,1),(2,2)
             out[Cc + ci] = fmaxf(fmaxf(patch[ci * 9 + 4], patch[ci * 9 + 5]), fmaxf(patch[ci * 9 + 7], patch[ci * 9 + 8]));
         float* o = cat + p * 16;
 #pragma unroll
@@ -318,49 +328,64 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
 }
 
-// dW[co][ci][kh][kw] partial rows: blockIdx.y = co
+// dW[co][ci][kh][kw] partial rows.  blockIdx.y = group of up to 4 output channels: the patch is loaded once per
+// pixel and group (4x instead of 13x), 4*9*CIN + 4 accumulators per thread.
+template <int CIN>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ gcat, int N,
-                                                        int Cin, int H, int W, float* __restrict__ wrows,
-                                                        float* __restrict__ brows) {
-    const int Cc = 16 - Cin, Ho = H / 2, Wo = W / 2, KK = Cin * 9, co = blockIdx.y;
+                                                        int H, int W, float* __restrict__ wrows, float* __restrict__ brows) {
+    constexpr int Cc = 16 - CIN, KK = CIN * 9, G = 4;
+    const int Ho = H / 2, Wo = W / 2, co0 = blockIdx.y * G;
     const long npix = (long)N * Ho * Wo;
-    float acc[STEM_MAXCIN * 9 + 1];
+    float acc[G][KK], bacc[G];
 #pragma unroll
-    for (int j = 0; j < STEM_MAXCIN * 9 + 1; ++j) acc[j] = 0.f;
+    for (int c = 0; c < G; ++c) {
+        bacc[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KK; ++j) acc[c][j] = 0.f;
+    }
     for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-        const float gv = gcat[p * 16 + co];
+        const f32x4 gq = ld4(gcat + p * 16 + co0);          // channels co0..co0+3 (pool channels are never used)
+        const float gv[G] = {gq.x, gq.y, gq.z, gq.w};
         const int ow = (int)(p % Wo);
         const long r = p / Wo;
         const int oh = (int)(r % Ho), n = (int)(r / Ho);
 #pragma unroll
-        for (int ci = 0; ci < STEM_MAXCIN; ++ci) {
-            if (ci >= Cin) break;
-            const float* pl = img + ((long)n * Cin + ci) * H * W;
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float* pl = img + ((long)n * CIN + ci) * H * W;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
                     const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
-                    const float xv = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? pl[(long)ih * W + iw] : 0.f;
-                    acc[ci * 9 + kh * 3 + kw] = fmaf(gv, xv, acc[ci * 9 + kh * 3 + kw]);
+                    const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                    const float xv = in ? pl[(long)min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < G; ++c) acc[c][ci * 9 + kh * 3 + kw] = fmaf(gv[c], xv, acc[c][ci * 9 + kh * 3 + kw]);
                 }
         }
-        acc[STEM_MAXCIN * 9] += gv;
+#pragma unroll
+        for (int c = 0; c < G; ++c) bacc[c] += gv[c];
     }
-    __shared__ float red[4][STEM_MAXCIN * 9 + 1];
+    __shared__ float red[4][G * (KK + 1)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < STEM_MAXCIN * 9 + 1; ++j) {
-        const float s = lf_wave_sum(acc[j]);
-        if (lane == 0) red[wave][j] = s;
+    for (int c = 0; c < G; ++c) {
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+            const float s = lf_wave_sum(acc[c][j]);
+            if (lane == 0) red[wave][c * (KK + 1) + j] = s;
+        }
+        const float sb = lf_wave_sum(bacc[c]);
+        if (lane == 0) red[wave][c * (KK + 1) + KK] = sb;
     }
     __syncthreads();
-    if (threadIdx.x < KK)
-        wrows[((long)blockIdx.x * Cc + co) * KK + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (threadIdx.x == 0) {
-        const int j = STEM_MAXCIN * 9;
-        brows[(long)blockIdx.x * Cc + co] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    if (threadIdx.x < G * (KK + 1)) {
+        const int c = threadIdx.x / (KK + 1), j = threadIdx.x % (KK + 1), co = co0 + c;
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (co < Cc) {
+            if (j < KK) wrows[((long)blockIdx.x * Cc + co) * KK + j] = v;
+            else brows[(long)blockIdx.x * Cc + co] = v;
+        }
     }
 }
 
@@ -583,7 +608,13 @@ int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, 
                 hipStream_t st) {
     LF_REQUIRE(Cin >= 1 && Cin <= STEM_MAXCIN, "stem: in_channels %d not in 1..%d", Cin, STEM_MAXCIN);
     LF_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: odd image size");
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(lf_stem_rows(N, H, W)), dim3(256), 0, st, img, N, Cin, H, W, w, b, cat, rows);
+    const dim3 grid(lf_stem_rows(N, H, W));
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(stem_fwd_kernel<1>, grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows); break;
+        case 2: hipLaunchKernelGGL(stem_fwd_kernel<2>, grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows); break;
+        case 3: hipLaunchKernelGGL(stem_fwd_kernel<3>, grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows); break;
+        default: hipLaunchKernelGGL(stem_fwd_kernel<4>, grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows); break;
+    }
     LF_CHECK_LAUNCH("stem_fwd");
     return 0;
 }
@@ -592,8 +623,13 @@ int lf_stem_wgrad_rows(int N, int H, int W) { return grid_for((long)N * (H / 2) 
 
 int lf_stem_wgrad(const float* img, const float* gcat, int N, int Cin, int H, int W, float* wrows, float* brows,
                   hipStream_t st) {
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(lf_stem_wgrad_rows(N, H, W), 16 - Cin), dim3(256), 0, st, img, gcat, N, Cin, H,
-                       W, wrows, brows);
+    const dim3 grid(lf_stem_wgrad_rows(N, H, W), (16 - Cin + 3) / 4);
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(stem_wgrad_kernel<1>, grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows); break;
+        case 2: hipLaunchKernelGGL(stem_wgrad_kernel<2>, grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows); break;
+        case 3: hipLaunchKernelGGL(stem_wgrad_kernel<3>, grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows); break;
+        default: hipLaunchKernelGGL(stem_wgrad_kernel<4>, grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows); break;
+    }
     LF_CHECK_LAUNCH("stem_wgrad");
     return 0;
 }
