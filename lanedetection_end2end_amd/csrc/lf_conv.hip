@@ -39,6 +39,59 @@ __device__ __forceinline__ float sum16(float v) {
     return v;
 }
 
+#define LF_TAPGEMM_EPILOGUE \
+    const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0; \
+    f32x4 s1[NT], s2[NT]; \
+_Pragma("unroll") \
+    for (int n = 0; n < NT; ++n) { s1[n] = zero4(); s2[n] = zero4(); } \
+_Pragma("unroll") \
+    for (int n = 0; n < NT; ++n) { \
+        const int co = cob + n * 16 + kq * 4; \
+        const f32x4 b = a.bias ? ldg4(a.bias + co) : zero4(); \
+        f32x4 msc, msh, asc, ash; \
+        if (epi & LF_EPI_MASKBN) { msc = ldg4(a.msc + co); msh = ldg4(a.msh + co); } \
+        if (epi & LF_EPI_STATS_XHAT) { asc = ldg4(a.asc + co); ash = ldg4(a.ash + co); } \
+_Pragma("unroll") \
+        for (int m = 0; m < MT; ++m) { \
+            if (!pv[m]) continue; \
+            const long doff = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + \
+                              g.d_choff + co; \
+            f32x4 v = acc[n][m] + b; \
+            if (epi & LF_EPI_ADD) v += ldg4(a.add_src + doff); \
+            if (epi & LF_EPI_MASK) v = keep_pos(v, ldg4(a.mask_src + doff)); \
+            f32x4 ax; \
+            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) ax = ldg4(a.aux + doff); \
+            if (epi & LF_EPI_MASKBN) v = keep_pos(v, ax * msc + msh); \
+            if (epi & LF_EPI_RELU) v = max0(v); \
+            *reinterpret_cast<f32x4*>(a.dst + doff) = v; \
+            if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
+            if (epi & LF_EPI_STATS_XHAT) { \
+                const f32x4 gm = a.dm ? v * ldg4(a.dm + (long)pn[m] * g.Cd + co) : v; \
+                s1[n] += gm; s2[n] += gm * (ax * asc + ash); \
+            } \
+        } \
+    } \
+    if (stats) { \
+        __shared__ float sred[WG_WAVES][NT][4][8]; \
+_Pragma("unroll") \
+        for (int n = 0; n < NT; ++n) { \
+            f32x4 r1, r2; \
+            r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w); \
+            r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w); \
+            if (pl == 0) { \
+                float* d = sred[wave][n][kq]; \
+                d[0] = r1.x; d[1] = r1.y; d[2] = r1.z; d[3] = r1.w; d[4] = r2.x; d[5] = r2.y; d[6] = r2.z; d[7] = r2.w; \
+            } \
+        } \
+        __syncthreads(); \
+        if (threadIdx.x < NT * 4 * 8) { \
+            const int j = threadIdx.x & 7, q = (threadIdx.x >> 3) & 3, n = threadIdx.x >> 5; \
+            const float v = sred[0][n][q][j] + sred[1][n][q][j] + sred[2][n][q][j] + sred[3][n][q][j]; \
+            const int co = cob + n * 16 + q * 4 + (j & 3); \
+            a.stats[((long)bx * 2 + (j >> 2)) * g.Cd + co] = v; \
+        } \
+    } \
+
 template <int NT, int VAR, int PROC>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -280,58 +333,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
         asm volatile("" ::"v"(acc[0][0][0]));
         tstamp[2] = __builtin_amdgcn_s_memtime();
     }
-    // ---- epilogue: lane holds channels co = cob + n*16 + 4*kq + (0..3) of pixel (tile m, pl)
-    const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0;
-    f32x4 s1[NT], s2[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) { s1[n] = zero4(); s2[n] = zero4(); }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = cob + n * 16 + kq * 4;
-        const f32x4 b = a.bias ? ldg4(a.bias + co) : zero4();
-        f32x4 msc, msh, asc, ash;
-        if (epi & LF_EPI_MASKBN) { msc = ldg4(a.msc + co); msh = ldg4(a.msh + co); }
-        if (epi & LF_EPI_STATS_XHAT) { asc = ldg4(a.asc + co); ash = ldg4(a.ash + co); }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if (!pv[m]) continue;
-            const long doff = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix +
-                              g.d_choff + co;
-            f32x4 v = acc[n][m] + b;
-            if (epi & LF_EPI_ADD) v += ldg4(a.add_src + doff);
-            if (epi & LF_EPI_MASK) v = keep_pos(v, ldg4(a.mask_src + doff));
-            f32x4 ax;
-            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) ax = ldg4(a.aux + doff);
-            if (epi & LF_EPI_MASKBN) v = keep_pos(v, ax * msc + msh);
-            if (epi & LF_EPI_RELU) v = max0(v);
-            *reinterpret_cast<f32x4*>(a.dst + doff) = v;
-            if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; }
-            if (epi & LF_EPI_STATS_XHAT) {
-                const f32x4 gm = a.dm ? v * ldg4(a.dm + (long)pn[m] * g.Cd + co) : v;
-                s1[n] += gm; s2[n] += gm * (ax * asc + ash);
-            }
-        }
-    }
-    if (stats) {   // one partial row per WORKGROUP: 16-lane shuffles, then the 4 waves through LDS
-        __shared__ float sred[WG_WAVES][NT][4][8];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            f32x4 r1, r2;
-            r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w);
-            r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w);
-            if (pl == 0) {
-                float* d = sred[wave][n][kq];
-                d[0] = r1.x; d[1] = r1.y; d[2] = r1.z; d[3] = r1.w; d[4] = r2.x; d[5] = r2.y; d[6] = r2.z; d[7] = r2.w;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < NT * 4 * 8) {
-            const int j = threadIdx.x & 7, q = (threadIdx.x >> 3) & 3, n = threadIdx.x >> 5;
-            const float v = sred[0][n][q][j] + sred[1][n][q][j] + sred[2][n][q][j] + sred[3][n][q][j];
-            const int co = cob + n * 16 + q * 4 + (j & 3);
-            a.stats[((long)bx * 2 + (j >> 2)) * g.Cd + co] = v;
-        }
-    }
+    LF_TAPGEMM_EPILOGUE
     if (a.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memtime();
@@ -340,6 +342,77 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
         }
     }
+}
+
+// Lean variant for 16-output-channel launches (the 128x256 stage, ~3 % of the FLOPs): these are HBM-bound
+// (0.75*C = 12 FLOP/B), so the goal is bytes in flight, not MFMA issue: no operand ring, few registers,
+// many waves per SIMD; the compiler is free to hoist the next step's loads.
+template <int NT>
+__global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
+    const int cob = blockIdx.y * NT * 16;
+    unsigned bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
+    int pn[MT], pi[MT], pj[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const unsigned p = tile0 + m * 16 + pl;
+        pv[m] = p < npix;
+        const unsigned q = pv[m] ? p : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj[m] = (int)(q - r * (unsigned)g.Wl);
+        pn[m] = (int)(r / (unsigned)g.Hl);
+        pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+    const int ncg = g.Cs >> 4;
+    const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;
+    for (int t = 0; t < g.ntaps; ++t) {
+        const int dh = g.tdh[t], dw = g.tdw[t];
+        unsigned xo[MT];
+        bool in[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+            in[m] = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+            xo[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4);
+        }
+        for (int cg = 0; cg < ncg; ++cg) {
+            f32x4 w[NT], x[MT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) w[n] = ldg4(wp + n * 64);
+            wp += (long)g.Cd * 16;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) x[m] = ldg4(a.src + xo[m] + cg * 16);
+            if (pro == LF_PRO_BNRELU) {
+                const f32x4 sc = ldg4(a.pro_sc + cg * 16 + kq * 4), sh = ldg4(a.pro_sh + cg * 16 + kq * 4);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) x[m] = max0(x[m] * sc + sh);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                x[m].x = in[m] ? x[m].x : 0.f; x[m].y = in[m] ? x[m].y : 0.f;
+                x[m].z = in[m] ? x[m].z : 0.f; x[m].w = in[m] ? x[m].w : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][s], x[m][s], acc[n][m], 0, 0, 0);
+        }
+    }
+    LF_TAPGEMM_EPILOGUE
 }
 
 int g_tapgemm_variant = 2;     // 0 simple loop, 1 ping-pong with per-tap setup, 2 (default) branch-free loop with LDS tap table
@@ -383,7 +456,10 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         case 4: LF_TG(4); break;
         case 3: LF_TG(3); break;
         case 2: LF_TG(2); break;
-        default: LF_TG(1); break;
+        default:
+            if (g_tapgemm_variant >= 2 && !a.dbg) hipLaunchKernelGGL(tapgemm_lean_kernel<1>, grid, dim3(256), 0, st, g, a, pro, epi);
+            else LF_TG(1);
+            break;
     }
 #undef LF_TG
     LF_CHECK_LAUNCH("tapgemm");
