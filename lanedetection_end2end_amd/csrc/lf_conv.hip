@@ -665,6 +665,102 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     }
 }
 
+// 16 x 16 channel weight gradient with ALL taps in one wave (the 128x256 stage): one pass over G and X
+// instead of one per tap -- these launches are HBM-bound, the per-tap split tripled their traffic.
+template <int NTAPS>
+__global__ __launch_bounds__(256) void tapwgrad16_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
+                                                        const long pps, const int write_bias) {
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    const long sub = (long)blockIdx.x * WG_WAVES + wave;
+    const long p_begin = sub * pps;
+    long p_end = p_begin + pps;
+    if (p_end > npix) p_end = npix;
+    f32x4 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) acc[t] = zero4();
+    float bsum = 0.f;
+    float psc = 1.f, psh = 0.f;
+    if (pro == LF_PRO_BNRELU) { psc = a.pro_sc[pl]; psh = a.pro_sh[pl]; }
+    int tdh[NTAPS], tdw[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) { tdh[t] = g.tdh[t]; tdw[t] = g.tdw[t]; }
+    long p = p_begin + kq;
+    int pj, pi, pn;
+    {
+        const unsigned q = p < npix ? (unsigned)p : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj = (int)(q - r * (unsigned)g.Wl);
+        pn = (int)(r / (unsigned)g.Hl);
+        pi = (int)(r - (unsigned)pn * (unsigned)g.Hl);
+    }
+    const unsigned gstep = (unsigned)(4 * g.dsw * g.d_pix);
+    while (p - kq < p_end) {                        // wave-uniform; 16 pixels of one row per iteration
+        const unsigned gofs = (unsigned)(((pn * g.Hd + pi * g.dsh + g.dah) * g.Wd + pj * g.dsw + g.daw) * g.d_pix + g.d_choff + pl);
+        float gv[U], xv[NTAPS][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool v = (p + 4 * u) < p_end;
+            const float t0 = a.g[v ? gofs + u * gstep : gofs];
+            gv[u] = v ? t0 : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int sy = pi * g.ssh + tdh[t];
+            const bool yin = sy >= 0 && sy < g.Hs;
+            const unsigned xrow = (unsigned)((pn * g.Hs + min(max(sy, 0), g.Hs - 1)) * g.Ws * g.s_pix + g.s_choff + pl);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sx = (pj + 4 * u) * g.ssw + tdw[t];
+                const bool in = yin && sx >= 0 && sx < g.Ws && (p + 4 * u) < p_end;
+                float x0 = a.x[xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix)];
+                if (pro == LF_PRO_BNRELU) x0 = fmaxf(x0 * psc + psh, 0.f);
+                xv[t][u] = in ? x0 : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t][u], gv[u], acc[t], 0, 0, 0);
+            bsum += gv[u];
+        }
+        p += 4 * U;
+        pj += 4 * U;
+        if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
+    }
+    __shared__ float red[WG_WAVES - 1][NTAPS * 4][64];
+    __shared__ float bred[WG_WAVES][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave - 1][t * 4 + e][lane] = acc[t][e];
+    }
+    bred[wave][lane] = bsum;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            float* out = a.partial + ((long)blockIdx.x * NTAPS + t) * g.Cs * g.Cd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[t][e];
+#pragma unroll
+                for (int w = 0; w < WG_WAVES - 1; ++w) v += red[w][t * 4 + e][lane];
+                out[(long)(4 * kq + e) * g.Cd + pl] = v;          // row = x-channel 4*kq+e, col = g-channel pl
+            }
+        }
+        if (write_bias && a.bias_partial) {
+            float v = bred[0][lane] + bred[1][lane] + bred[2][lane] + bred[3][lane];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0) a.bias_partial[(long)blockIdx.x * g.Cd + pl] = v;
+        }
+    }
+}
+
 struct WgradCfg { int xv, gv, xt, gt, gx, u; long pps; };
 
 WgradCfg wgrad_cfg(const LfTapGeom& g) {
@@ -674,9 +770,10 @@ WgradCfg wgrad_cfg(const LfTapGeom& g) {
     c.xt = c.xv ? 4 : g.Cs / 16;
     c.gt = c.gv ? 4 : g.Cd / 16;
     const int xb = c.xt * 16, gb = c.gt * 16;
-    const int jobs = g.ntaps * (g.Cs / xb) * (g.Cd / gb);
+    const bool small16 = (g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0);   // all taps in one wave
+    const int jobs = small16 ? 1 : g.ntaps * (g.Cs / xb) * (g.Cd / gb);
     const long npix = (long)g.N * g.Hl * g.Wl;
-    int gx = 2048 / (jobs * WG_WAVES);          // 2 waves per SIMD (254 VGPRs) over 256 CUs: one full round
+    int gx = (small16 ? 4096 : 2048) / (jobs * WG_WAVES);   // 2 waves/SIMD (254 VGPRs) over 256 CUs; 8 for the lean 16x16 kernel
     if (gx < 1) gx = 1;
     const long maxgx = (npix + 64 * WG_WAVES - 1) / (64 * WG_WAVES);   // at least 64 pixels per wave
     if (gx > maxgx) gx = (int)maxgx;
@@ -702,8 +799,13 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
                "tapwgrad: tensor too large for 32-bit offsets");
     const WgradCfg c = wgrad_cfg(g);
     const int xb = c.xt * 16, gb = c.gt * 16;
-    dim3 grid(c.gx, g.ntaps, (g.Cs / xb) * (g.Cd / gb));
     const int wb = a.bias_partial != nullptr;
+    if (g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0) {
+        hipLaunchKernelGGL(tapwgrad16_kernel<3>, dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);
+        LF_CHECK_LAUNCH("tapwgrad16");
+        return 0;
+    }
+    dim3 grid(c.gx, g.ntaps, (g.Cs / xb) * (g.Cd / gb));
 #define LF_WG(XV, GV, XT, GT)                                                                                     \
     do {                                                                                                          \
         if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb); \
