@@ -832,43 +832,47 @@ namespace {
 
 struct TapIdx { int v[LF_MAX_TAPS]; };
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int ntaps,
-                                                          int Cs, int Cd, float* __restrict__ grad, long sk, long sn,
-                                                          TapIdx ti, int wblocks, const float* __restrict__ brows,
-                                                          int nbrows, float* __restrict__ bgrad, int baccum) {
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int ntaps,
+                                                           int Cs, int Cd, float* __restrict__ grad, long sk, long sn,
+                                                           TapIdx ti, int wblocks, const float* __restrict__ brows,
+                                                           int nbrows, float* __restrict__ bgrad, int baccum) {
+    constexpr int SG = 16;                                       // 64 outputs x 16 split groups per block
+    __shared__ float sw[SG][64];
+    const int og = threadIdx.x & 63, sg = threadIdx.x >> 6;
     if ((int)blockIdx.x >= wblocks) {   // trailing blocks: bias gradient = column sums of the bias partial rows
-        const int c = (blockIdx.x - wblocks) * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-        __shared__ float sb[4][64];
+        const int c = (blockIdx.x - wblocks) * 64 + og;
         float s = 0.f;
         if (c < Cd)
-            for (int r = rg; r < nbrows; r += 4) s += brows[(long)r * Cd + c];
-        sb[rg][threadIdx.x & 63] = s;
+            for (int r = sg; r < nbrows; r += SG) s += brows[(long)r * Cd + c];
+        sw[sg][og] = s;
         __syncthreads();
-        if (rg == 0 && c < Cd) {
-            const float v = (sb[0][threadIdx.x] + sb[1][threadIdx.x]) + (sb[2][threadIdx.x] + sb[3][threadIdx.x]);
+        if (sg == 0 && c < Cd) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < SG; ++k) v += sw[k][og];
             bgrad[c] = baccum ? bgrad[c] + v : v;
         }
         return;
     }
     const long per = (long)ntaps * Cs * Cd;
-    __shared__ float sw[4][64];
-    const int og = threadIdx.x & 63, sg = threadIdx.x >> 6;      // 64 outputs x 4 split groups
     for (long base = (long)blockIdx.x * 64; base < per; base += (long)wblocks * 64) {
         const long i = base + og;
         float s0 = 0.f, s1 = 0.f;
         if (i < per) {
             int r = sg;
-            for (; r + 4 < splits; r += 8) { s0 += partial[(long)r * per + i]; s1 += partial[(long)(r + 4) * per + i]; }
-            for (; r < splits; r += 4) s0 += partial[(long)r * per + i];
+            for (; r + SG < splits; r += 2 * SG) { s0 += partial[(long)r * per + i]; s1 += partial[(long)(r + SG) * per + i]; }
+            for (; r < splits; r += SG) s0 += partial[(long)r * per + i];
         }
         sw[sg][og] = s0 + s1;
         __syncthreads();
         if (sg == 0 && i < per) {
-            const float v = (sw[0][og] + sw[1][og]) + (sw[2][og] + sw[3][og]);
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < SG; ++k) v += sw[k][og];          // fixed order: deterministic
             const int n = (int)(i % Cd);
             const long r2 = i / Cd;
-            const int k = (int)(r2 % Cs), t = (int)(r2 / Cs);
-            grad[k * sk + n * sn + ti.v[t]] = v;
+            const int k2 = (int)(r2 % Cs), t = (int)(r2 / Cs);
+            grad[k2 * sk + n * sn + ti.v[t]] = v;
         }
         __syncthreads();
     }
@@ -922,7 +926,7 @@ int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, 
     int wblocks = lf_cdiv(per, 64);
     if (wblocks > 4096) wblocks = 4096;
     const int bblocks = (bias_rows && bias_grad) ? lf_cdiv(Cd, 64) : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, partial, splits, ntaps, Cs, Cd, grad,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(1024), 0, st, partial, splits, ntaps, Cs, Cd, grad,
                        sk, sn, ti, wblocks, bias_rows, n_bias_rows, bias_grad, bias_accumulate);
     LF_CHECK_LAUNCH("wgrad_reduce");
     return 0;
