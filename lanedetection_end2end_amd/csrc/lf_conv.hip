@@ -778,7 +778,7 @@ WgradCfg wgrad_cfg(const LfTapGeom& g) {
     const long maxgx = (npix + 64 * WG_WAVES - 1) / (64 * WG_WAVES);   // at least 64 pixels per wave
     if (gx > maxgx) gx = (int)maxgx;
     if (gx < 1) gx = 1;
-    c.u = (g.Wl % 16 == 0) ? 4 : 1;           // k-steps per loop iteration (16 pixels of one row)
+    c.u = (g.Wl % 16 == 0) ? 4 : 1;           // k-steps per loop iteration (16 pixels of one row; 8-pixel iterations at 3 waves/SIMD spill: 1.7x slower)
     const int gran = 4 * c.u;
     long pps = (npix + (long)gx * WG_WAVES - 1) / ((long)gx * WG_WAVES);
     pps = (pps + gran - 1) / gran * gran;

@@ -135,9 +135,12 @@ class _BackboneFn(torch.autograd.Function):
         _lib.check(lib.lf_erfnet_forward(plan.handle, _lib.ptr(x), host, _lib.ptr(devarr), running,
                                          _lib.ptr(dropmask), int(training), head, _lib.ptr(logits), _lib.ptr(ws),
                                          plan.ws_bytes, _lib.stream()), "lf_erfnet_forward")
-        enc = torch.empty(N, 128, H // 8, W // 8, dtype=torch.float32, device=dev)
-        _lib.check(lib.lf_nhwc_to_nchw(ctypes.c_void_p(ws.data_ptr() + 4 * plan.enc_off), _lib.ptr(enc), N, H // 8,
-                                       W // 8, 128, _lib.stream()), "lf_nhwc_to_nchw")
+        if net.export_encoder_output:
+            enc = torch.empty(N, 128, H // 8, W // 8, dtype=torch.float32, device=dev)
+            _lib.check(lib.lf_nhwc_to_nchw(ctypes.c_void_p(ws.data_ptr() + 4 * plan.enc_off), _lib.ptr(enc), N, H // 8,
+                                           W // 8, 128, _lib.stream()), "lf_nhwc_to_nchw")
+        else:
+            enc = torch.empty(0, dtype=torch.float32, device=dev)
         ctx.net, ctx.plan, ctx.head, ctx.ws, ctx.x, ctx.dropmask = net, plan, head, ws, x, dropmask
         ctx.params = params
         ctx.mark_non_differentiable(enc)
@@ -177,6 +180,9 @@ class Net(nn.Module):
         self.in_channels, self.out_channels, self.pretrained = in_channels, out_channels, bool(pretrained)
         self._plans = {}
         self._ptr_cache = (None, None)
+        # encoder_output (N,128,H/8,W/8) is part of the return tuple; the LSQ wrappers never read it (it only feeds
+        # the out-of-scope --clas heads) and switch the NHWC->NCHW export off
+        self.export_encoder_output = True
 
     # ---- bookkeeping -------------------------------------------------------------------
     def _ordered_params(self):
@@ -213,21 +219,24 @@ class Net(nn.Module):
         return self._plans[key]
 
     def _make_dropmask(self, plan, device):
-        """Dropout2d keep-masks (N,C) per block with p > 0, drawn with torch's generator on the device."""
+        """Dropout2d keep-masks, one (N,C) block per non_bottleneck_1d built with p > 0, drawn with torch's
+        generator on the device: ONE uniform draw for all 13 blocks, thresholded by each block's current p
+        (a block whose p was set to 0 keeps everything)."""
         if plan.n_drop == 0:
             return None
-        # the engine enumerates blocks built with p > 0; a block whose p was later set to 0 gets a mask of ones
         built = [m for m in self.modules() if isinstance(m, non_bottleneck_1d) and m._built_with_dropout]
-        keep = torch.empty(plan.drop_floats, dtype=torch.float32, device=device)
-        N = plan.shape[0]
-        for m, off, ch in zip(built, plan.drop_off, plan.drop_ch):
-            p = float(m.dropout.p)
-            seg = keep[off: off + N * ch]
-            if p <= 0:
-                seg.fill_(1.0)
-            else:
-                seg.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
-        return keep
+        ps = tuple(float(m.dropout.p) for m in built)
+        cache = getattr(plan, "_drop_cache", None)
+        if cache is None or cache[0] != ps or cache[1].device != device:
+            N = plan.shape[0]
+            pvec = torch.empty(plan.drop_floats, dtype=torch.float32)
+            for p, off, ch in zip(ps, plan.drop_off, plan.drop_ch):
+                pvec[off: off + N * ch] = p
+            pvec = pvec.to(device)
+            plan._drop_cache = cache = (ps, pvec, 1.0 / (1.0 - pvec))
+        _, pvec, scale = cache
+        u = torch.rand(plan.drop_floats, dtype=torch.float32, device=device)
+        return (u >= pvec).to(torch.float32).mul_(scale)
 
     # ---- forward -----------------------------------------------------------------------
     def forward(self, input, flag, only_encode=False):

@@ -51,6 +51,7 @@ class _LaneFitNet(nn.Module):
         out_channels = args.nclasses + int(not args.end_to_end)
         self.net = backbone_cls(layers=args.layers, in_channels=args.channels_in, out_channels=out_channels,
                                 pretrained=args.pretrained, pool=args.pool)
+        self.net.export_encoder_output = False      # shared_encoder only feeds the (unsupported) --clas heads
         self.activation_name = args.activation_layer
         self.activation = activation_layer(args.activation_layer)
         resize = args.resize
