@@ -246,6 +246,105 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const L
                 mma(B, 1); mma(B, 2); mma(B, 3);
             }
         }
+    } else if constexpr (VAR == 4) {
+        // VAR 4: as VAR 2, but the weight tile of each K-step (16 channels x NT*16 outputs = NT KB) is staged
+        // ONCE per workgroup in LDS (double-buffered, one barrier per step) instead of once per wave from L1/L2:
+        // one dwordx4 per thread fills it, 4x fewer weight bytes leave the L2, and the weight operands no longer
+        // need a register ring.
+        struct XStep { f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
+        __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
+        __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
+        __shared__ f32x4 wl[2][4][NT * 16];
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int dh = g.tdh[t], dw = g.tdw[t];
+            unsigned o[MT], okb = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+                const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+                const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+                o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4);
+                okb |= (in ? 1u : 0u) << m;
+            }
+            tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+            tab_ok[wave][t][lane] = okb;
+        }
+        const int tid = threadIdx.x;
+        const bool filler = tid < NT * 64;
+        const int f_kb = filler ? tid / (NT * 16) : 0, f_co = filler ? tid % (NT * 16) : 0;
+        const float* wsrc = a.wp + ((long)f_kb * g.Cd + cob + f_co) * 4;
+        const int wstep = g.Cd * 16;
+        const int ntaps = g.ntaps;
+        int t_ld = 0, cg_ld = 0, wstepi = 0;
+        auto wfetch = [&]() -> f32x4 {              // weights of the next K-step (clamped past the end)
+            const f32x4 v = ldg4(wsrc + (long)min(wstepi, nsteps - 1) * wstep);
+            ++wstepi;
+            return v;
+        };
+        auto issue = [&](XStep& S) {
+            const bool live = t_ld < ntaps;
+            const int tc = live ? t_ld : ntaps - 1;
+            const uint4 o = tab_off[wave][tc][lane];
+            const unsigned okb = tab_ok[wave][tc][lane];
+            const int c16 = cg_ld * 16;
+            S.x[0] = ldg4(a.src + o.x + c16);
+            S.x[1] = ldg4(a.src + o.y + c16);
+            S.x[2] = ldg4(a.src + o.z + c16);
+            S.x[3] = ldg4(a.src + o.w + c16);
+            if constexpr (PROC == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + c16 + kq * 4); S.sh = ldg4(a.pro_sh + c16 + kq * 4); }
+            S.ok = live ? okb : 0u;
+            const int cgn = cg_ld + 1;
+            const bool wrap = cgn == ncg;
+            cg_ld = live ? (wrap ? 0 : cgn) : cg_ld;
+            t_ld = (live && wrap) ? t_ld + 1 : t_ld;
+        };
+        auto finish = [&](XStep& S) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = S.x[m];
+                if constexpr (PROC == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
+                const bool in = (S.ok >> m) & 1u;
+                v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+                S.x[m] = v;
+            }
+        };
+        auto mma = [&](const f32x4 (&w)[NT], const XStep& S, int s) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
+        };
+        static_assert(MT == 4, "tab_off packs 4 pixel tiles");
+        XStep A, B;
+        f32x4 wreg = wfetch();
+        issue(A);
+        if (filler) wl[0][f_kb][f_co] = wreg;
+        __syncthreads();
+        const int npairs = (nsteps + 1) >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            f32x4 w[NT];
+            // ---- step A: weights in buffer 0
+            wreg = wfetch();
+#pragma unroll
+            for (int n = 0; n < NT; ++n) w[n] = wl[0][kq][n * 16 + pl];
+            finish(A);
+            mma(w, A, 0);
+            issue(B);
+            mma(w, A, 1); mma(w, A, 2); mma(w, A, 3);
+            if (filler) wl[1][f_kb][f_co] = wreg;
+            __syncthreads();
+            // ---- step B: weights in buffer 1
+            wreg = wfetch();
+#pragma unroll
+            for (int n = 0; n < NT; ++n) w[n] = wl[1][kq][n * 16 + pl];
+            finish(B);
+            mma(w, B, 0);
+            issue(A);
+            mma(w, B, 1); mma(w, B, 2); mma(w, B, 3);
+            if (filler) wl[0][f_kb][f_co] = wreg;
+            __syncthreads();
+        }
     } else {
         // VAR 2 (default): branch-free main loop.  Per-tap source offsets and validity bits are computed ONCE
         // into an LDS table (one 16-byte row per lane and tap); the loop body is one basic block of two
@@ -449,6 +548,8 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (g_tapgemm_variant == 1) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (nsteps < 8) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi);    \
+        else if (g_tapgemm_variant == 4 && pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 4, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else if (g_tapgemm_variant == 4) hipLaunchKernelGGL((tapgemm_kernel<NTV, 4, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
