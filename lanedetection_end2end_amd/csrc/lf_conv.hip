@@ -13,6 +13,8 @@
 // straight into VGPRs, one (tap, 16-channel) step prefetched ahead of the MFMAs that use it.
 // fp32 MFMA runs at the vector rate (157 TF), 1/16 of bf16, so one dwordx4 per operand tile per
 // 16 MFMAs (512 cycles) is far below what the load path sustains.
+#include <stdlib.h>
+
 #include "lf_conv.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -543,6 +545,8 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31), "tapgemm: source tensor too large for 32-bit offsets");
     const int nsteps = g.ntaps * (g.Cs / 16);      // short loops: the LDS tap table of VAR 2 does not pay off
+    static const bool env_once = [] { if (const char* e = getenv("LF_TAPGEMM_VARIANT")) g_tapgemm_variant = atoi(e); return true; }();
+    (void)env_once;
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
         if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \

@@ -400,3 +400,38 @@ def test_segmentation_branch_cross_entropy():
     with torch.no_grad():
         out = model(x.cuda(), torch.zeros(N, K), False)
     assert len(out) == 9 and out[0].shape == (N, 3, 1)
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 48, 96), (1, 32, 64)])
+def test_ragged_shapes(N, H, W):
+    """Tile tails: pixel counts that are not multiples of the 256-pixel workgroup tile, widths that are not
+    multiples of 16 (the weight-gradient kernel's 4-pixel path), batch 1 and 3."""
+    net, P = build(out_channels=2, seed=11)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0
+    net.train()
+    x = torch.from_numpy(inputs.images(N, H, W, seed=91))
+    gy = torch.from_numpy(np.random.default_rng(92).standard_normal((N, 2, H, W))).float()
+    enc, dec = net(x.cuda(), True)
+    state = fetch_all(net, net._plan(N, H, W), dec.grad_fn.ws, N, H, W)
+    (dec * gy.cuda()).sum().backward()
+    _, dec64, _, _, _ = run_oracle(x, P, torch.float64)
+    _, dec32, _, _, _ = run_oracle(x, P, torch.float32)
+    floor = relerr(dec32.detach(), dec64.detach())
+    assert relerr(dec.detach().cpu(), dec64.detach()) < max(6 * floor, 5e-5)
+    Pd = erfnet_oracle.cast_params(P, torch.float64)
+    for k, v in Pd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    _, dec_st = erfnet_oracle.erfnet_forward(x.double(), Pd, training=True, override=state)
+    (dec_st * gy.double()).sum().backward()
+    gmax = max(float(v.grad.abs().max()) for v in Pd.values() if v.grad is not None)
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        g64 = Pd[k].grad
+        scale = float(g64.abs().max())
+        if scale < 1e-6 * gmax:
+            continue
+        assert float((p.grad.cpu().double() - g64).abs().max()) / scale < 5e-4, k
