@@ -41,11 +41,14 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 1])
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--one", type=int, nargs=5, metavar=("C", "H", "W", "AXIS", "DIL"), help="run a single shape (for PMC passes)")
     a = ap.parse_args()
     lib = _lib.load()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     shapes = [(128, 32, 64, 0, 4), (128, 32, 64, 1, 16), (64, 64, 128, 0, 1), (64, 64, 128, 1, 1), (16, 128, 256, 1, 1)]
     N = a.batch
+    if a.one:
+        shapes = [tuple(a.one)]
     for C, H, W, axis, d in shapes:
         torch.manual_seed(0)
         x = torch.randn(N, H, W, C, device="cuda")
