@@ -581,16 +581,24 @@ namespace {
 
 template <bool XV, bool GV, int XT, int GT, int U>
 __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
-                                                      const long pps, const int write_bias) {
+                                                      const long pps, const int write_bias, const int gxs) {
     constexpr int XTiles = XV ? 4 : XT, GTiles = GV ? 4 : GT;
     constexpr int XB = XTiles * 16, GB = GTiles * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
-    const int t = blockIdx.y;
+    // 1-D grid of gx * ntaps * (channel-block pairs) workgroups.  Workgroup L runs on XCD L % 8 (observed): each
+    // XCD gets a contiguous run of the (channel-block, pixel-split, tap) order with the tap fastest, so the taps of
+    // one pixel range -- which read the same G rows and overlapping X rows -- follow each other through ONE L2
+    // instead of streaming both tensors from HBM once per tap (FETCH_SIZE 177 MB -> see profiles/).
     const int ncob = g.Cd / GB;
-    const int cib = blockIdx.z / ncob, cob = blockIdx.z % ncob;
+    unsigned ord = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) ord = (ord & 7u) * (gridDim.x >> 3) + (ord >> 3);
+    const int t = (int)(ord % (unsigned)g.ntaps);
+    const unsigned bxs = (ord / (unsigned)g.ntaps) % (unsigned)gxs;       // pixel-split index
+    const int bz = (int)(ord / ((unsigned)g.ntaps * (unsigned)gxs));
+    const int cib = bz / ncob, cob = bz % ncob;
     const long npix = (long)g.N * g.Hl * g.Wl;
-    const long sub = (long)blockIdx.x * WG_WAVES + wave;
+    const long sub = (long)bxs * WG_WAVES + wave;
     const long p_begin = sub * pps;
     long p_end = p_begin + pps;
     if (p_end > npix) p_end = npix;
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     for (int q = 0; q < GTiles; ++q) bred[wave][q][lane] = bsum[q];
     __syncthreads();
     if (wave == 0) {
-        float* out = a.partial + ((long)blockIdx.x * g.ntaps + t) * g.Cs * g.Cd;
+        float* out = a.partial + ((long)bxs * g.ntaps + t) * g.Cs * g.Cd;
 #pragma unroll
         for (int r = 0; r < XTiles; ++r)
 #pragma unroll
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
                 v += __shfl_xor(v, 32, 64);
                 if (kq == 0) {
                     const int co = cob * GB + (GV ? 4 * pl + q : q * 16 + pl);
-                    a.bias_partial[(long)blockIdx.x * g.Cd + co] = v;
+                    a.bias_partial[(long)bxs * g.Cd + co] = v;
                 }
             }
         }
@@ -883,6 +891,11 @@ WgradCfg wgrad_cfg(const LfTapGeom& g) {
     const long maxgx = (npix + 64 * WG_WAVES - 1) / (64 * WG_WAVES);   // at least 64 pixels per wave
     if (gx > maxgx) gx = (int)maxgx;
     if (gx < 1) gx = 1;
+    if (!small16) {   // make gx * jobs a multiple of 8 so the kernel's per-XCD ordering applies
+        int mlt = 8;
+        for (int d = 2; d <= 8; d *= 2) if (jobs % d == 0) mlt = 8 / d;
+        if (gx >= mlt) gx = gx / mlt * mlt;
+    }
     c.u = (g.Wl % 16 == 0) ? 4 : 1;           // k-steps per loop iteration (16 pixels of one row; 8-pixel iterations at 3 waves/SIMD spill: 1.7x slower)
     const int gran = 4 * c.u;
     long pps = (npix + (long)gx * WG_WAVES - 1) / ((long)gx * WG_WAVES);
@@ -910,11 +923,11 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
         LF_CHECK_LAUNCH("tapwgrad16");
         return 0;
     }
-    dim3 grid(c.gx, g.ntaps, (g.Cs / xb) * (g.Cd / gb));
+    dim3 grid(c.gx * g.ntaps * (g.Cs / xb) * (g.Cd / gb));
 #define LF_WG(XV, GV, XT, GT)                                                                                     \
     do {                                                                                                          \
-        if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb); \
-        else hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb);        \
+        if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
+        else hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);        \
     } while (0)
     if (c.xv && c.gv) LF_WG(true, true, 4, 4);
     else if (c.xv && c.gt == 1) LF_WG(true, false, 4, 1);
