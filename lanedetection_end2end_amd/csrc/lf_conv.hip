@@ -53,23 +53,29 @@ _Pragma("unroll") \
         f32x4 msc, msh, asc, ash; \
         if (epi & LF_EPI_MASKBN) { msc = ldg4(a.msc + co); msh = ldg4(a.msh + co); } \
         if (epi & LF_EPI_STATS_XHAT) { asc = ldg4(a.asc + co); ash = ldg4(a.ash + co); } \
+        long doff[MT]; \
+        f32x4 la[MT], lm[MT], lx[MT], ld[MT]; \
 _Pragma("unroll") \
         for (int m = 0; m < MT; ++m) { \
-            if (!pv[m]) continue; \
-            const long doff = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + \
-                              g.d_choff + co; \
+            doff[m] = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + g.d_choff + co; \
+            if (epi & LF_EPI_ADD) la[m] = ldg4(a.add_src + doff[m]); \
+            if (epi & LF_EPI_MASK) lm[m] = ldg4(a.mask_src + doff[m]); \
+            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[m] = ldg4(a.aux + doff[m]); \
+            if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[m] = ldg4(a.dm + (long)pn[m] * g.Cd + co); \
+        } \
+_Pragma("unroll") \
+        for (int m = 0; m < MT; ++m) { \
             f32x4 v = acc[n][m] + b; \
-            if (epi & LF_EPI_ADD) v += ldg4(a.add_src + doff); \
-            if (epi & LF_EPI_MASK) v = keep_pos(v, ldg4(a.mask_src + doff)); \
-            f32x4 ax; \
-            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) ax = ldg4(a.aux + doff); \
-            if (epi & LF_EPI_MASKBN) v = keep_pos(v, ax * msc + msh); \
+            if (epi & LF_EPI_ADD) v += la[m]; \
+            if (epi & LF_EPI_MASK) v = keep_pos(v, lm[m]); \
+            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[m] * msc + msh); \
             if (epi & LF_EPI_RELU) v = max0(v); \
-            *reinterpret_cast<f32x4*>(a.dst + doff) = v; \
+            if (pv[m]) *reinterpret_cast<f32x4*>(a.dst + doff[m]) = v; \
+            if (!pv[m]) v = zero4(); \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
-                const f32x4 gm = a.dm ? v * ldg4(a.dm + (long)pn[m] * g.Cd + co) : v; \
-                s1[n] += gm; s2[n] += gm * (ax * asc + ash); \
+                const f32x4 gm = a.dm ? v * ld[m] : v; \
+                s1[n] += gm; s2[n] += gm * (lx[m] * asc + ash); \
             } \
         } \
     } \
@@ -587,15 +593,17 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     // 1-D grid of gx * ntaps * (channel-block pairs) workgroups.  Workgroup L runs on XCD L % 8 (observed): each
-    // XCD gets a contiguous run of the (channel-block, pixel-split, tap) order with the tap fastest, so the taps of
+    // XCD gets a contiguous run of the (pixel-split, channel-block, tap) order with the tap fastest, so all jobs of
     // one pixel range -- which read the same G rows and overlapping X rows -- follow each other through ONE L2
     // instead of streaming both tensors from HBM once per tap (FETCH_SIZE 177 MB -> see profiles/).
     const int ncob = g.Cd / GB;
     unsigned ord = blockIdx.x;
     if ((gridDim.x & 7u) == 0) ord = (ord & 7u) * (gridDim.x >> 3) + (ord >> 3);
+    const unsigned nz = (unsigned)((g.Cs / XB) * ncob);
     const int t = (int)(ord % (unsigned)g.ntaps);
-    const unsigned bxs = (ord / (unsigned)g.ntaps) % (unsigned)gxs;       // pixel-split index
-    const int bz = (int)(ord / ((unsigned)g.ntaps * (unsigned)gxs));
+    const int bz = (int)((ord / (unsigned)g.ntaps) % nz);                 // channel-block pair: next fastest
+    const unsigned bxs = ord / ((unsigned)g.ntaps * nz);                  // pixel-split index: slowest
+    (void)gxs;
     const int cib = bz / ncob, cob = bz % ncob;
     const long npix = (long)g.N * g.Hl * g.Wl;
     const long sub = (long)bxs * WG_WAVES + wave;
