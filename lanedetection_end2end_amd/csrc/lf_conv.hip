@@ -101,7 +101,7 @@ _Pragma("unroll") \
     } \
 
 template <int NT, int VAR, int PROC>
-__global__ __launch_bounds__(256) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
