@@ -435,3 +435,39 @@ def test_ragged_shapes(N, H, W):
         if scale < 1e-6 * gmax:
             continue
         assert float((p.grad.cpu().double() - g64).abs().max()) / scale < 5e-4, k
+
+
+def test_full_size_properties():
+    """Config C2 size (32x3x256x512, the bench workload): properties that need no CPU reference --
+    bit-identical repeat runs (no atomics anywhere), exact linearity of the backward pass in the output
+    gradient (scaling by 2 is exact in fp32), and, in eval mode, independence of an image's logits from
+    the rest of the batch (same per-pixel summation order whatever the tiling)."""
+    N, H, W = 32, 256, 512
+    net, P = build(out_channels=2, seed=21)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0
+    x = torch.from_numpy(inputs.images(N, H, W, seed=95)).cuda()
+    gy = torch.randn(N, 2, H, W, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    rs = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+
+    def run(scale):
+        net.load_state_dict(rs, strict=False)            # same running stats going in
+        net.train()
+        net.zero_grad(set_to_none=True)
+        _, dec = net(x, True)
+        (dec * (gy * scale)).sum().backward()
+        return dec.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    d1, g1 = run(1.0)
+    d2, g2 = run(1.0)
+    d3, g3 = run(2.0)
+    assert torch.equal(d1, d2)
+    assert all(torch.equal(g1[k], g2[k]) for k in g1), "backward is not deterministic"
+    assert torch.isfinite(d1).all() and all(torch.isfinite(v).all() for v in g1.values())
+    worst = max(float((g3[k] - 2 * g1[k]).abs().max() / (g1[k].abs().max() + 1e-30)) for k in g1)
+    assert worst < 1e-6, worst                           # only split-K partial sums could differ; they do not
+    net.eval()
+    with torch.no_grad():
+        _, e32 = net(x, True)
+        _, e1 = net(x[5:6].contiguous(), True)
+    assert torch.equal(e32[5:6], e1)
