@@ -75,6 +75,17 @@ int lf_wls_bwd(const float* logits, const float* grid_xy, long grid_batch_stride
                int act_kind, const double* beta, const double* zinv, const double* grad_beta,
                float* grad_logits, void* stream);
 
+/* GELS.forward / GELS.backward -- BP/Networks/gels.py:9-25: x = (A^T A)^-1 A^T b by Cholesky of the normal
+ * equations (no regulariser) and the hand-written backward of the reference.
+ *   A (N,P,D) fp32, b (N,P) fp32, D <= 4; x out (N,D) fp32; zinv out (N,D,D) fp64 (saved for backward);
+ *   partials >= lf_gels_workspace_bytes(N,D); status out (N) int32 (2 = not positive definite).
+ *   backward: grad_out (N,D) fp32 -> grad_A (N,P,D), grad_b (N,P) fp32. */
+size_t lf_gels_workspace_bytes(int N, int D);
+int lf_gels_fwd(const float* A, const float* b, int N, long P, int D, float* x, double* zinv, void* partials,
+                int32_t* status, void* stream);
+int lf_gels_bwd(const float* A, const float* b, const float* x, const double* zinv, const float* grad_out,
+                int N, long P, int D, float* grad_A, float* grad_b, void* stream);
+
 /* Area_Loss.forward -- BEV/Loss_crit.py:98-134.  beta (N,order+1) with element stride
  * beta_stride between images, gt (N,order+1) contiguous; dtype LF_F32/LF_F64 for both.
  * loss out: 1 element of dtype; grad out: (N,order+1) of dtype = d loss / d beta. */

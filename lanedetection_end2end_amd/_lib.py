@@ -26,6 +26,9 @@ def _declare(lib):
         "lf_wls_workspace_bytes": (c_size_t, [I, I, I]),
         "lf_wls_fwd": (I, [P, P, L, I, I, I, I, I, I, D, D, I, I, P, P, P, P, P, P]),
         "lf_wls_bwd": (I, [P, P, L, I, I, I, I, I, I, D, I, P, P, P, P, P]),
+        "lf_gels_workspace_bytes": (c_size_t, [I, I]),
+        "lf_gels_fwd": (I, [P, P, I, L, I, P, P, P, P, P]),
+        "lf_gels_bwd": (I, [P, P, P, P, P, I, L, I, P, P, P]),
         "lf_area_loss": (I, [P, L, P, I, I, I, I, P, P, P]),
         "lf_backproj_loss": (I, [P, L, P, P, P, P, P, I, I, I, P, P, P, P]),
         "lf_ce2d_fwd": (I, [P, P, P, I, I, I, I, P, P, P]),

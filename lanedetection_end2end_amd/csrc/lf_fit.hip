@@ -353,6 +353,150 @@ int wls_bwd_launch(const float* logits, const float* grid, long gbs, int N, int 
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------
+// GELS: least squares of an explicit design matrix through the normal equations + Cholesky
+// (BP/Networks/gels.py:9-25).  A (N,P,D) fp32, b (N,P) fp32, D <= 4.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+template <int D>
+__global__ __launch_bounds__(WLS_THREADS) void gels_moments_kernel(const float* __restrict__ A, const float* __restrict__ b,
+                                                                  long P, double* __restrict__ partials) {
+    constexpr int NS = D * (D + 1) / 2 + D;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const long p0 = P * chunk / WLS_CHUNKS, p1 = P * (chunk + 1) / WLS_CHUNKS;
+    double acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+    for (long p = p0 + threadIdx.x; p < p1; p += WLS_THREADS) {
+        double a[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) a[j] = (double)A[((long)n * P + p) * D + j];
+        const double bv = (double)b[(long)n * P + p];
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) { acc[k] = fma(a[i], a[j], acc[k]); ++k; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) acc[D * (D + 1) / 2 + i] = fma(a[i], bv, acc[D * (D + 1) / 2 + i]);
+    }
+    __shared__ double red[WLS_THREADS / LF_WAVE][NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const double v = lf_wave_sum(acc[j]);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < WLS_THREADS / LF_WAVE; ++w) v += red[w][threadIdx.x];
+        partials[((long)n * WLS_CHUNKS + chunk) * NS + threadIdx.x] = v;
+    }
+}
+
+template <int D>
+__global__ void gels_solve_kernel(const double* __restrict__ partials, int N, float* __restrict__ x,
+                                  double* __restrict__ zinv, int32_t* __restrict__ status) {
+    constexpr int NS = D * (D + 1) / 2 + D;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double m[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) m[j] = 0.0;
+    for (int c = 0; c < WLS_CHUNKS; ++c)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) m[j] += partials[((long)n * WLS_CHUNKS + c) * NS + j];
+    double Z[D][D], Zi[D][D], X[D];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) { Z[i][j] = m[k]; Z[j][i] = m[k]; ++k; }
+#pragma unroll
+    for (int i = 0; i < D; ++i) X[i] = m[D * (D + 1) / 2 + i];
+    const int st = invert_chol<D>(Z, Zi);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) { v = fma(Zi[i][j], X[j], v); zinv[((long)n * D + i) * D + j] = Zi[i][j]; }
+        x[(long)n * D + i] = (float)v;
+    }
+    status[n] = st;
+}
+
+template <int D>
+__global__ __launch_bounds__(WLS_THREADS) void gels_bwd_kernel(const float* __restrict__ A, const float* __restrict__ b,
+                                                              const float* __restrict__ x, const double* __restrict__ zinv,
+                                                              const float* __restrict__ gout, long P,
+                                                              float* __restrict__ gA, float* __restrict__ gb) {
+    const int n = blockIdx.y;
+    double xs[D], z[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        xs[i] = (double)x[(long)n * D + i];
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) v = fma(zinv[((long)n * D + i) * D + j], (double)gout[(long)n * D + j], v);
+        z[i] = v;
+    }
+    for (long p = (long)blockIdx.x * WLS_THREADS + threadIdx.x; p < P; p += (long)gridDim.x * WLS_THREADS) {
+        double a[D], ax = 0.0, az = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) { a[j] = (double)A[((long)n * P + p) * D + j]; ax = fma(a[j], xs[j], ax); az = fma(a[j], z[j], az); }
+        const double bv = (double)b[(long)n * P + p];
+#pragma unroll
+        for (int j = 0; j < D; ++j) gA[((long)n * P + p) * D + j] = (float)(-(ax * z[j] + az * xs[j]) + bv * z[j]);
+        gb[(long)n * P + p] = (float)az;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t lf_gels_workspace_bytes(int N, int D) { return (size_t)N * WLS_CHUNKS * (D * (D + 1) / 2 + D) * sizeof(double); }
+
+extern "C" int lf_gels_fwd(const float* A, const float* b, int N, long P, int D, float* x, double* zinv, void* partials,
+                           int32_t* status, void* stream) {
+    LF_REQUIRE(A && b && x && zinv && partials && status, "lf_gels_fwd: null pointer");
+    LF_REQUIRE(D >= 1 && D <= 4 && N > 0 && P > 0, "lf_gels_fwd: bad shape N=%d P=%ld D=%d", N, P, D);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g1(WLS_CHUNKS, N);
+    double* pp = (double*)partials;
+#define LF_GELS(DD)                                                                                              \
+    hipLaunchKernelGGL(gels_moments_kernel<DD>, g1, dim3(WLS_THREADS), 0, st, A, b, P, pp);                      \
+    hipLaunchKernelGGL(gels_solve_kernel<DD>, dim3(lf_cdiv(N, 64)), dim3(64), 0, st, pp, N, x, zinv, status)
+    switch (D) {
+        case 1: LF_GELS(1); break;
+        case 2: LF_GELS(2); break;
+        case 3: LF_GELS(3); break;
+        default: LF_GELS(4); break;
+    }
+#undef LF_GELS
+    LF_CHECK_LAUNCH("gels_fwd");
+    return 0;
+}
+
+extern "C" int lf_gels_bwd(const float* A, const float* b, const float* x, const double* zinv, const float* grad_out, int N,
+                           long P, int D, float* grad_A, float* grad_b, void* stream) {
+    LF_REQUIRE(A && b && x && zinv && grad_out && grad_A && grad_b, "lf_gels_bwd: null pointer");
+    LF_REQUIRE(D >= 1 && D <= 4 && N > 0 && P > 0, "lf_gels_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    int gx = lf_cdiv(P, WLS_THREADS);
+    if (gx > 256) gx = 256;
+    dim3 g1(gx, N);
+    switch (D) {
+        case 1: hipLaunchKernelGGL(gels_bwd_kernel<1>, g1, dim3(WLS_THREADS), 0, st, A, b, x, zinv, grad_out, P, grad_A, grad_b); break;
+        case 2: hipLaunchKernelGGL(gels_bwd_kernel<2>, g1, dim3(WLS_THREADS), 0, st, A, b, x, zinv, grad_out, P, grad_A, grad_b); break;
+        case 3: hipLaunchKernelGGL(gels_bwd_kernel<3>, g1, dim3(WLS_THREADS), 0, st, A, b, x, zinv, grad_out, P, grad_A, grad_b); break;
+        default: hipLaunchKernelGGL(gels_bwd_kernel<4>, g1, dim3(WLS_THREADS), 0, st, A, b, x, zinv, grad_out, P, grad_A, grad_b); break;
+    }
+    LF_CHECK_LAUNCH("gels_bwd");
+    return 0;
+}
+
 extern "C" size_t lf_wls_workspace_bytes(int N, int K, int order) {
     return (size_t)N * K * WLS_CHUNKS * (3 * order + 2) * sizeof(double);
 }
