@@ -157,6 +157,17 @@ int lf_erfnet_profile(const lf_erfnet_plan* plan, int enable);
 int lf_erfnet_profile_read(const lf_erfnet_plan* plan, double* out6_host);
 
 /* ------------------------------------------------------------------------------------
+ * Fused Adam step over all parameter tensors in ONE launch ("next" row 8f-1).  Replaces optimizer.step() of the
+ * torch.optim.Adam the reference builds (BEV/Networks/utils.py:411-420, BEV/main.py:266); same arithmetic.
+ *   tensors_dev: n records {float* p; const float* g; float* m; float* v; long numel} on the device;
+ *   work_dev: nblocks int2 {tensor index, chunk index}, chunk = lf_adam_chunk() elements;
+ *   step: 1-based count including this update; grad_scale: multiplies every gradient first (1/world size).
+ * ---------------------------------------------------------------------------------- */
+int lf_adam_chunk(void);
+int lf_adam_step(const void* tensors_dev, const void* work_dev, int nblocks, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Kernel-level entry points: one factorised convolution of non_bottleneck_1d
  * (nn.Conv2d(C, C, (3,1)|(1,3), padding = dilation = d), BEV/Networks/ERFNet.py:29-37) on NHWC fp32
  * tensors, outside the plan: forward, data gradient (optionally times the ReLU mask of mask_src),

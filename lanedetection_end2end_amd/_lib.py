@@ -47,6 +47,9 @@ def _declare(lib):
         "lf_erfnet_forward": (I, [P, P, P, P, P, P, I, I, P, P, c_size_t, P]),
         "lf_erfnet_backward": (I, [P, P, P, P, P, P, I, P, c_size_t, P]),
         "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
+        "lf_adam_chunk": (I, []),
+        "lf_adam_step": (I, [P, P, I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                             I, ctypes.c_float, P]),
         "lf_conv1d_scratch_floats": (L, [I, I, I, I]),
         "lf_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
