@@ -131,7 +131,7 @@ def main():
     if world > 1:
         from lanedetection_end2end_amd import dp
         dp.broadcast_parameters(model, src=0)
-        reducer = dp.FlatGradAllReduce(params)
+        reducer = dp.FlatGradAllReduce(params, flat_provider=model.net.flat_grad)
 
     def step():
         b0, b1, _, _, _, _, _, _, _ = model(x, True)

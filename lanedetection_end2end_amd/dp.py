@@ -33,10 +33,25 @@ class FlatGradAllReduce:
     checked afterwards.
     """
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, flat_provider=None):
+        """``flat_provider``: optional callable returning one contiguous tensor of which every ``p.grad`` is a
+        view, in parameter order (``erfnet.Net.flat_grad``): then the all-reduce runs in place on it, without
+        the flatten / unflatten copies."""
         self.params = list(params)
         self.group = group
         self.active = None
+        self.flat_provider = flat_provider
+
+    def _in_place_flat(self, grads):
+        flat = self.flat_provider() if self.flat_provider is not None else None
+        if flat is None or flat.numel() != sum(g.numel() for g in grads):
+            return None
+        ptr, esz = flat.data_ptr(), flat.element_size()
+        for g in grads:                       # every gradient must sit exactly at its running offset
+            if g.data_ptr() != ptr or not g.is_contiguous():
+                return None
+            ptr += g.numel() * esz
+        return flat
 
     def __call__(self):
         world = dist.get_world_size(self.group)
@@ -49,6 +64,11 @@ class FlatGradAllReduce:
         if world == 1 or not active:
             return 0
         grads = [self.params[i].grad for i in active]
+        flat = self._in_place_flat(grads)
+        if flat is not None:
+            dist.all_reduce(flat, group=self.group)
+            flat.div_(world)
+            return flat.numel()
         flat = _flatten_dense_tensors(grads)
         dist.all_reduce(flat, group=self.group)
         flat.div_(world)

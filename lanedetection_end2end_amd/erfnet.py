@@ -152,7 +152,18 @@ class _BackboneFn(torch.autograd.Function):
         plan, params = ctx.plan, ctx.params
         needs = ctx.needs_input_grad[6:]
         used = ctx.net._used_param_mask(ctx.head)
-        grads = [torch.empty_like(p) if (n and u) else None for p, n, u in zip(params, needs, used)]
+        # all parameter gradients are views of ONE flat buffer (module order): a data-parallel run all-reduces
+        # it in place, with no flatten / copy-back kernels (dp.FlatGradAllReduce picks it up via flat_grad())
+        want = [bool(n and u) for n, u in zip(needs, used)]
+        flat = torch.empty(sum(p.numel() for p, w in zip(params, want) if w), dtype=torch.float32, device=params[0].device)
+        grads, off = [], 0
+        for p, w in zip(params, want):
+            if w:
+                grads.append(flat[off: off + p.numel()].view(p.shape))
+                off += p.numel()
+            else:
+                grads.append(None)
+        ctx.net._flat_grad = flat
         glogits = glogits.contiguous()
         _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _ptr_array(params),
                                           _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.head, _lib.ptr(ctx.ws),
@@ -180,6 +191,7 @@ class Net(nn.Module):
         self.in_channels, self.out_channels, self.pretrained = in_channels, out_channels, bool(pretrained)
         self._plans = {}
         self._ptr_cache = (None, None)
+        self._flat_grad = None
         # encoder_output (N,128,H/8,W/8) is part of the return tuple; the LSQ wrappers never read it (it only feeds
         # the out-of-scope --clas heads) and switch the NHWC->NCHW export off
         self.export_encoder_output = True
@@ -200,6 +212,10 @@ class Net(nn.Module):
 
     def _dropouts(self):
         return [m.dropout for m in self.modules() if isinstance(m, non_bottleneck_1d) and m.dropout.p != 0]
+
+    def flat_grad(self):
+        """The flat fp32 buffer whose views the last backward handed out as parameter gradients (or None)."""
+        return self._flat_grad
 
     def _used_param_mask(self, head):
         names = [n for n, _ in self.named_parameters()]

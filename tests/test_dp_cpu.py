@@ -41,6 +41,17 @@ def _worker(rank, world, port, out):
         else:
             ok &= bool(torch.allclose(p.grad, torch.full_like(p, 1.5 * (1 + i % 3))))     # mean of 1 and 2
     n2 = reducer()                                      # second step: same active set
+    # in-place path: gradients that are views of one flat buffer are reduced without copies
+    act = [p for nme, p in net.named_parameters() if not nme.startswith("encoder.output_conv")]
+    flat = torch.full((sum(p.numel() for p in act),), float(rank + 1))
+    off = 0
+    for p in act:
+        p.grad = flat[off: off + p.numel()].view(p.shape)
+        off += p.numel()
+    red2 = dp.FlatGradAllReduce(net.parameters(), flat_provider=lambda: flat)
+    assert red2._in_place_flat([p.grad for p in act]) is flat
+    red2()
+    ok &= bool(torch.allclose(flat, torch.full_like(flat, 1.5))) and act[3].grad.data_ptr() >= flat.data_ptr()
     # a rank-dependent active set must be detected
     failed = False
     if rank == 0:
