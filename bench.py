@@ -23,6 +23,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_IMG_FWD_BWD = 39.67e9      # conv FLOPs, BASELINE.md section 2 (256x512, Cout = 2)
+# the other BASELINE.json configs, runnable with --workload (not the headline line): conv GFLOP/image fwd+bwd
+WORKLOADS = {"bev": dict(flop=39.67e9, R=256, K=2, batch=32, desc="BEV ERFNet + fused WLS fit + Area loss, 2 lanes, 256x512"),
+             "bp": dict(flop=62.04e9, R=320, K=4, batch=64, desc="BP ERFNet + fused WLS fit (pixel coords, fp64 betas) + "
+                                                                 "back-projection loss, 4 lanes, 320x640 (config 3 in fp32)"),
+             "seg": dict(flop=158.8e9, R=512, K=2, batch=16, desc="segmentation branch (end_to_end=False, early_return): ERFNet "
+                                                                  "Cout=3 + class-weighted cross entropy, 512x1024 (config 5, per GPU)")}
 PEAK_FP32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
@@ -33,11 +39,21 @@ def make_args(batch):
                      weight_seg=30)
 
 
-def build_model(batch, seed):
+def build_model(batch, seed, workload="bev"):
     from lanedetection_end2end_amd.bev.Loss_crit import Area_Loss
-    from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Net
     torch.manual_seed(seed)
-    model = Net(make_args(batch))
+    wl = WORKLOADS[workload]
+    if workload == "bev":
+        from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Net
+        model = Net(make_args(batch))
+    else:
+        from lanedetection_end2end_amd.bp.Networks.LSQ_layer import Net
+        args = make_args(batch)
+        args.resize, args.nclasses, args.mask_percentage, args.no_mapping = wl["R"], wl["K"], 0.2, False
+        args.end_to_end = workload != "seg"
+        args.loss_policy = "backproject"
+        model = Net(args)
+        model._bench_args = args
 
     def kaiming(m):            # the reference's weights_init_kaiming (BEV/Networks/utils.py:490-503)
         n = m.__class__.__name__
@@ -98,7 +114,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the workload's)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bev",
+                    help="bev = the BASELINE.json headline (default); bp / seg = configs 3 (in fp32) and 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable Dropout2d (parity-style run)")
     a = ap.parse_args()
@@ -116,15 +134,28 @@ def main():
 
     from lanedetection_end2end_amd import _lib
     from oracle import inputs
-    B = a.batch
-    model, crit = build_model(B, seed=0)     # identical weights on every rank (same seed)
+    wl = WORKLOADS[a.workload]
+    B = a.batch or wl["batch"]
+    R = wl["R"]
+    model, crit = build_model(B, seed=0, workload=a.workload)     # identical weights on every rank (same seed)
     if a.no_dropout:
         for m in model.modules():
             if isinstance(m, torch.nn.Dropout2d):
                 m.p = 0
     model.check_singular = False             # no per-step D2H read; status is checked after the timed region
-    x = torch.from_numpy(inputs.images(B, 256, 512, seed=100 + rank)).cuda()
+    x = torch.from_numpy(inputs.images(B, R, 2 * R, seed=100 + rank)).cuda()
     gt = torch.from_numpy(inputs.bev_gt_params(B, seed=200 + rank)).cuda()
+    if a.workload == "bp":
+        from lanedetection_end2end_amd.bp.Loss_crit import backprojection_loss
+        crit = backprojection_loss(model._bench_args)
+        lanes_np, valid_np = inputs.bp_targets(B, wl["K"], 256, seed=300 + rank)
+        lanes, valid = torch.from_numpy(lanes_np).cuda(), torch.from_numpy(valid_np).cuda()
+        gt_line = torch.zeros(B, wl["K"])
+    elif a.workload == "seg":
+        from lanedetection_end2end_amd.bp.Loss_crit import define_loss_crit
+        _, crit = define_loss_crit(model._bench_args)
+        target = torch.from_numpy(inputs.seg_targets(B, R, 2 * R, wl["K"] + 1, seed=300 + rank)).cuda()
+        gt_line = torch.zeros(B, wl["K"])
     params = [p for p in model.parameters()]
     statuses = []
     reducer = None
@@ -134,12 +165,19 @@ def main():
         reducer = dp.FlatGradAllReduce(params, flat_provider=model.net.flat_grad)
 
     def step():
-        b0, b1, _, _, _, _, _, _, _ = model(x, True)
-        loss = crit(b0, gt[:, 0]) + crit(b1, gt[:, 1])
+        if a.workload == "bev":
+            b0, b1, _, _, _, _, _, _, _ = model(x, True)
+            loss = crit(b0, gt[:, 0]) + crit(b1, gt[:, 1])
+        elif a.workload == "bp":
+            out = model(x, gt_line, True)
+            loss = sum(crit(out[k], lanes[:, k], valid[:, k])[0] for k in range(wl["K"])) / wl["K"]
+        else:
+            loss = crit(model(x, gt_line, False, early_return=True), target)
         for p in params:
             p.grad = None
         loss.backward()
-        statuses.append(model.last_status)
+        if model.last_status is not None:
+            statuses.append(model.last_status)
         if reducer is not None:
             reducer()          # one flat 8.25 MB RCCL all-reduce (sum / world)
         return loss
@@ -161,7 +199,7 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    bad = int(torch.stack(statuses).abs().sum())
+    bad = int(torch.stack(statuses).abs().sum()) if statuses else 0
     if bad or not torch.isfinite(loss):
         raise SystemExit("bench: singular normal matrix / non-finite loss inside the timed region")
 
@@ -170,7 +208,7 @@ def main():
         ips = world * B * a.steps / dt
         # ---- roofline of the dominant kernel family: extra steps with HIP events around every MFMA launch
         lib = _lib.load()
-        plan = model.net._plan(B, 256, 512)
+        plan = model.net._plan(B, R, 2 * R)
         lib.lf_erfnet_profile(plan.handle, 1)
         psteps = 3
         for _ in range(psteps):
@@ -191,17 +229,19 @@ def main():
                     "families": {names[i]: {"ms_per_step": round(fam[i]["ms"] / psteps, 3),
                                             "tflops": round(fam[i]["flops"] / max(fam[i]["ms"], 1e-9) / 1e9, 2)}
                                  for i in range(2)},
-                    "whole_step_frac_of_conv_roofline": round(ips * FLOP_PER_IMG_FWD_BWD / world / PEAK_FP32_MFMA, 4)}
-        out = {"metric": "images/sec fwd+bwd, 256x512 2-lane bs32", "value": round(ips, 2), "unit": "images/sec",
+                    "whole_step_frac_of_conv_roofline": round(ips * wl["flop"] / world / PEAK_FP32_MFMA, 4)}
+        metric = "images/sec fwd+bwd, 256x512 2-lane bs32" if a.workload == "bev" else \
+            "images/sec fwd+bwd, %s" % a.workload
+        out = {"metric": metric, "value": round(ips, 2), "unit": "images/sec",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BEV ERFNet + fused WLS fit + Area loss, 2 lanes, 256x512, batch %d per GPU, "
+               "config": {"workload": "%s, batch %d per GPU, "
                                       "fp32, train mode (BN batch stats, Dropout2d %s), fwd+bwd, optimizer excluded"
-                                      % (B, "off" if a.no_dropout else "on"),
+                                      % (wl["desc"], B, "off" if a.no_dropout else "on"),
                           "global_batch": world * B, "parallelism": "dp%d" % world,
                           "grad_allreduce": "flat fp32 bucket, RCCL" if world > 1 else "none"},
                "roofline": roofline}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "bev":
             out["cpu_baseline"] = cpu_baseline()
     if world > 1:
         dist.barrier()
