@@ -181,7 +181,7 @@ int lf_conv1d_bwd_data(const float* gy, const float* w, const float* mask_src, f
                        int C, int axis, int dilation, float* scratch, void* stream);
 int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, int N, int H, int W, int C,
                          int axis, int dilation, float* scratch, void* stream);
-/* kernel A/B switch used by tools/kbench.py only (0 = simple loop, 1 = default schedule) */
+/* kernel A/B switch used by tools/kbench.py only (1, 2 = default, 4: see lf_conv.hip) */
 void lf_debug_set_tapgemm_variant(int v);
 /* lf_conv1d_fwd + per-wave s_memtime stamps (start, tap table built, main loop done, stores retired; 8 words/wave) */
 int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C,

@@ -51,7 +51,7 @@ struct LfTapArgs {
     unsigned long long* dbg;  // optional: per-wave phase timestamps (s_memtime), 8 words per wave (tools/kbench.py --phases)
 };
 
-void lf_tapgemm_set_variant(int v);   // kernel A/B switch for tools/kbench.py (0 = simple loop, 1 = default)
+void lf_tapgemm_set_variant(int v);   // kernel A/B switch for tools/kbench.py (1, 2 = default, 4)
 int lf_tapgemm_stat_rows(const LfTapGeom& g);
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);
 

@@ -138,59 +138,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
     const int ncg = g.Cs >> 4;
     const int nsteps = g.ntaps * ncg;
 
-    if constexpr (VAR == 0) {
-    // Operand loads are UNCONDITIONAL (address clamped into the tensor, result masked at use): a branch
-        // around a load makes hipcc wait vmcnt(0) inside it, which serialises every load behind the last.
-        struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
-        auto load = [&](int t, int cg, Step& S) {
-            const float* wpt = a.wp + ((long)(t * (g.Cs >> 2) + cg * 4 + kq) * g.Cd + cob + pl) * 4;
-    #pragma unroll
-            for (int n = 0; n < NT; ++n) S.w[n] = ldg4(wpt + n * 64);
-            const int dh = g.tdh[t], dw = g.tdw[t];
-            const int ch = g.s_choff + cg * 16 + kq * 4;
-            if (pro == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + cg * 16 + kq * 4); S.sh = ldg4(a.pro_sh + cg * 16 + kq * 4); }
-            unsigned ok = 0;
-    #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
-                const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-                const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-                S.x[m] = ldg4(a.src + ((long)(pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + ch);
-                ok |= (in ? 1u : 0u) << m;
-            }
-            S.ok = ok;
-        };
-        auto finish = [&](Step& S) {   // prologue + zero padding, applied when the operand is consumed
-    #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x4 v = S.x[m];
-                if (pro == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
-                const bool in = (S.ok >> m) & 1u;
-                v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
-                S.x[m] = v;
-            }
-        };
-    
-        Step cur, nxt;
-        int t = 0, cg = 0;
-        load(0, 0, cur);
-        for (int step = 0; step < nsteps; ++step) {
-            int tn = t, cgn = cg + 1;
-            if (cgn == ncg) { cgn = 0; tn = t + 1; }
-            const bool more = step + 1 < nsteps;
-            if (more) load(tn, cgn, nxt);
-            finish(cur);
-    #pragma unroll
-            for (int s = 0; s < 4; ++s)
-    #pragma unroll
-                for (int n = 0; n < NT; ++n)
-    #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.w[n][s], cur.x[m][s], acc[n][m], 0, 0, 0);
-            if (more) cur = nxt;
-            t = tn; cg = cgn;
-        }
-    } else if constexpr (VAR == 1) {
+    if constexpr (VAR == 1) {
         // VAR 1: per-tap address setup (once per tap instead of once per 16 channels), pointer-increment
         // operand streams, two named register sets (no copy), next step's loads issued behind the first
         // quarter of the current step's MFMAs so that a single wave keeps the matrix pipe fed.
@@ -522,7 +470,8 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
     LF_TAPGEMM_EPILOGUE
 }
 
-int g_tapgemm_variant = 2;     // 0 simple loop, 1 ping-pong with per-tap setup, 2 (default) branch-free loop with LDS tap table
+int g_tapgemm_variant = 2;     // 1 ping-pong with per-tap setup (also used for < 8 K-steps), 2 (default) branch-free loop with LDS
+                               // tap table, 4 = 2 + weights staged through LDS (LF_TAPGEMM_VARIANT / tools/kbench.py --variants)
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -555,8 +504,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     (void)env_once;
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
-        if (g_tapgemm_variant == 0) hipLaunchKernelGGL((tapgemm_kernel<NTV, 0, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else if (g_tapgemm_variant == 1) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        if (g_tapgemm_variant == 1) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (nsteps < 8) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi);    \
         else if (g_tapgemm_variant == 4 && pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 4, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else if (g_tapgemm_variant == 4) hipLaunchKernelGGL((tapgemm_kernel<NTV, 4, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \

@@ -38,7 +38,7 @@ def timeit(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", type=int, nargs="+", default=[0, 1])
+    ap.add_argument("--variants", type=int, nargs="+", default=[2])
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--one", type=int, nargs=5, metavar=("C", "H", "W", "AXIS", "DIL"), help="run a single shape (for PMC passes)")
