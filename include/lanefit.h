@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 1
+#define LF_ABI_VERSION 2
 
 /* activation applied to the backbone logits: BEV/Networks/LSQ_layer.py:43-63 */
 enum { LF_ACT_SQUARE = 0, LF_ACT_ABS = 1, LF_ACT_RELU = 2, LF_ACT_SIGMOID = 3,
@@ -145,10 +145,12 @@ long lf_erfnet_activation_offset(const lf_erfnet_plan* plan, int layer, int slot
 int lf_erfnet_forward(const lf_erfnet_plan* plan, const float* img, const float* const* params_host,
                       const float* const* params_dev, float* const* running_host, const float* dropmask,
                       int training, int head, float* logits, void* workspace, size_t workspace_bytes, void* stream);
-/* Gradients are written (not accumulated) into grads_host[i]; NULL entries are skipped. */
+/* Gradients are written (not accumulated) into grads_host[i]; NULL entries are skipped.
+ * grad_encoder: optional (N,H/8,W/8,128) NHWC gradient w.r.t. the encoder output (`shared_encoder`,
+ * BP/Networks/LSQ_layer.py:275), added where the decoder's gradient reaches the encoder; NULL = none. */
 int lf_erfnet_backward(const lf_erfnet_plan* plan, const float* img, const float* grad_logits,
-                       const float* const* params_host, float* const* grads_host, const float* dropmask, int head,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       const float* grad_encoder, const float* const* params_host, float* const* grads_host,
+                       const float* dropmask, int head, void* workspace, size_t workspace_bytes, void* stream);
 int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream);
 /* Roofline instrumentation (bench.py): HIP event pairs around every matrix-core launch of the engine.
  * out6 = {ms, algorithmic FLOPs, launches} for family 0 (tap-GEMM forward + data gradient) and
@@ -166,6 +168,51 @@ int lf_erfnet_profile_read(const lf_erfnet_plan* plan, double* out6_host);
 int lf_adam_chunk(void);
 int lf_adam_step(const void* tensors_dev, const void* work_dev, int nblocks, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * "Next" row 8f-3: the `--clas` heads and the inference-side post-processing of BP/test.py.
+ *
+ * lf_convchain_*: a chain of [Conv2d(k, stride 1, pad k/2, bias) -> BatchNorm2d -> ReLU] blocks on an NHWC fp32
+ * tensor = the trunk of `Classification` (BP/Networks/LSQ_layer.py:150-181,192-196: conv1..conv4 + BNs) that the
+ * line-type and horizon heads run on the encoder output.  Plan per shape; channels[0..L] multiples of 16,
+ * ksize[i] in {1,3}.  params: 4 per block (conv.weight (Co,Ci,k,k), conv.bias, bn.weight, bn.bias) as a HOST
+ * and a DEVICE array of device pointers; running_host: 2 per block.  x is read in place from the backbone
+ * workspace (lf_erfnet_encoder_offset); y = last block's post-ReLU output, NHWC.  The workspace holds the
+ * saved pre-BN tensors until lf_convchain_backward, which writes every parameter gradient and (if gx != NULL)
+ * the NHWC input gradient to hand to lf_erfnet_backward(grad_encoder).
+ * ---------------------------------------------------------------------------------- */
+typedef struct lf_convchain_plan lf_convchain_plan;
+lf_convchain_plan* lf_convchain_plan_create(int N, int H, int W, int nlayers, const int* channels_host,
+                                            const int* ksize_host);
+void lf_convchain_plan_destroy(lf_convchain_plan* plan);
+size_t lf_convchain_workspace_bytes(const lf_convchain_plan* plan);
+int lf_convchain_forward(const lf_convchain_plan* plan, const float* x, const float* const* params_host,
+                         const float* const* params_dev, float* const* running_host, int training, float momentum,
+                         float eps, float* y, void* workspace, size_t workspace_bytes, void* stream);
+int lf_convchain_backward(const lf_convchain_plan* plan, const float* x, const float* y, const float* gy,
+                          const float* const* params_host, float* const* grads_host, float* gx, void* workspace,
+                          size_t workspace_bytes, void* stream);
+/* Pool + flatten in front of the heads' fully connected layers (LSQ_layer.py:183-187,197-201):
+ * mode 0 = MaxPool2d(2,2) -> (N, C*(H/2)*(W/2)); mode 1 = AvgPool2d((1,W)) -> (N, C*H); input NHWC,
+ * output in the NCHW flatten order nn.Linear's weights expect.  The Linear layers themselves are plain
+ * library GEMMs (rocBLAS through torch.nn.functional.linear). */
+int lf_poolflat_fwd(const float* y, int N, int H, int W, int C, int mode, float* out, void* stream);
+int lf_poolflat_bwd(const float* y, const float* gout, int N, int H, int W, int C, int mode, float* gy, void* stream);
+
+/* Projections.compute_coordinates (BP/test.py:172-186) + the gating of test_model (:77-88) in one launch:
+ * x = resize(M_inv . [poly(beta, y_eval), y_prime, 1]) per (image, lane, sample height); then
+ * line_flag[n][l] == 0 -> fill; sample index < bound[n] (python slice semantics) -> fill; x > hi or x < lo -> fill.
+ * beta (N,L,order+1) fp64, highest power first; y_eval / y_prime (S) fp64; minv_host 9 doubles;
+ * line_flag (N,L) fp32 or NULL; bound (N) int32 or NULL; lo > hi disables the range gate.
+ * Outputs (either may be NULL): x_out (N,L,S) fp64, x_int (N,L,S) int32 = round-half-even(x). */
+int lf_lane_decode(const double* beta, const double* y_eval, const double* y_prime, const double* minv_host,
+                   double scale, const float* line_flag, const int* bound, double lo, double hi, double fill,
+                   int N, int L, int S, int order, double* x_out, int* x_int, void* stream);
+
+/* "Next" row 8f-2: polynomial.trapezoidal (BEV/Loss_crit.py:26-35): area between two parabolas by the
+ * trapezium rule on [a, b] with n intervals; p, q (B,3) rows [a2, a1, a0]; fp32 or fp64; out (B). */
+int lf_trapezoid(const void* p, const void* q, int B, double a, double b, int n, int is_double, void* out,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Kernel-level entry points: one factorised convolution of non_bottleneck_1d

@@ -45,7 +45,16 @@ def _declare(lib):
         "lf_erfnet_encoder_offset": (L, [P]),
         "lf_erfnet_activation_offset": (L, [P, I, I]),
         "lf_erfnet_forward": (I, [P, P, P, P, P, P, I, I, P, P, c_size_t, P]),
-        "lf_erfnet_backward": (I, [P, P, P, P, P, P, I, P, c_size_t, P]),
+        "lf_erfnet_backward": (I, [P, P, P, P, P, P, P, I, P, c_size_t, P]),
+        "lf_convchain_plan_create": (P, [I, I, I, I, P, P]),
+        "lf_convchain_plan_destroy": (None, [P]),
+        "lf_convchain_workspace_bytes": (c_size_t, [P]),
+        "lf_convchain_forward": (I, [P, P, P, P, P, I, ctypes.c_float, ctypes.c_float, P, P, c_size_t, P]),
+        "lf_convchain_backward": (I, [P, P, P, P, P, P, P, P, c_size_t, P]),
+        "lf_poolflat_fwd": (I, [P, I, I, I, I, I, P, P]),
+        "lf_poolflat_bwd": (I, [P, P, I, I, I, I, I, P, P]),
+        "lf_lane_decode": (I, [P, P, P, P, D, P, P, D, D, D, I, I, I, I, P, P, P]),
+        "lf_trapezoid": (I, [P, P, I, D, D, I, I, P, P]),
         "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
         "lf_adam_chunk": (I, []),
         "lf_adam_step": (I, [P, P, I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,

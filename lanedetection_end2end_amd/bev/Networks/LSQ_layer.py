@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from lanedetection_end2end_amd import geometry
+from lanedetection_end2end_amd.clas import Classification  # noqa: F401
 from lanedetection_end2end_amd.fit import WeightedLeastSquares
 from lanedetection_end2end_amd.lsq import BEVNet as Net, activation_layer  # noqa: F401
 

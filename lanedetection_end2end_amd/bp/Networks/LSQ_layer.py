@@ -2,6 +2,7 @@
 import torch
 
 from lanedetection_end2end_amd import geometry
+from lanedetection_end2end_amd.clas import Classification  # noqa: F401
 from lanedetection_end2end_amd.fit import WeightedLeastSquares
 from lanedetection_end2end_amd.geometry import get_homography  # noqa: F401
 from lanedetection_end2end_amd.lsq import BPNet as Net, activation_layer  # noqa: F401

@@ -16,6 +16,7 @@
 
 #include "lf_conv.h"
 #include "lf_eltwise.h"
+#include "lf_plan.h"
 
 namespace {
 
@@ -74,21 +75,6 @@ struct lf_erfnet_plan {
 
 namespace {
 
-struct Bump {
-    long cur = 0;
-    long take(long nfloats) { long o = cur; cur += (nfloats + 63) / 64 * 64; return o; }
-};
-
-LfTapGeom base_geom(int N, int Hl, int Wl, int Hs, int Ws, int Cs_pix, int Hd, int Wd, int Cd_pix, int Cs, int Cd) {
-    LfTapGeom g;
-    memset(&g, 0, sizeof(g));
-    g.N = N; g.Hl = Hl; g.Wl = Wl;
-    g.Hs = Hs; g.Ws = Ws; g.s_pix = Cs_pix; g.s_choff = 0; g.ssh = 1; g.ssw = 1;
-    g.Hd = Hd; g.Wd = Wd; g.d_pix = Cd_pix; g.d_choff = 0; g.dsh = 1; g.dsw = 1; g.dah = 0; g.daw = 0;
-    g.Cs = Cs; g.Cd = Cd; g.ntaps = 0;
-    return g;
-}
-
 int add_pack(lf_erfnet_plan* P, int param, int Kc, int Nc, long sk, long sn, const LfTapGeom& g, const int* tapidx) {
     LfPackEntry e;
     memset(&e, 0, sizeof(e));
@@ -102,7 +88,7 @@ int add_pack(lf_erfnet_plan* P, int param, int Kc, int Nc, long sk, long sn, con
 
 // 1-D factorised conv (3 taps along H (axis 0) or W (axis 1), dilation d): forward + data gradient
 void build_conv1d(lf_erfnet_plan* P, ConvRef& c, int N, int H, int W, int C, int axis, int d) {
-    LfTapGeom g = base_geom(N, H, W, H, W, C, H, W, C, C, C);
+    LfTapGeom g = lf_base_geom(N, H, W, H, W, C, H, W, C, C, C);
     g.ntaps = 3;
     int idx_f[3], idx_d[3];
     for (int t = 0; t < 3; ++t) {
@@ -129,7 +115,7 @@ int phase_taps(int a, int* k, int* off) {
 // DownsamplerBlock conv: Conv2d(Cin, Cc, 3, stride 2, pad 1) writing channels [0,Cc) of the concat buffer
 void build_down_conv(lf_erfnet_plan* P, ConvRef& c, int N, int H, int W, int Cin, int Cc, int Ccat) {
     const int Ho = H / 2, Wo = W / 2;
-    LfTapGeom g = base_geom(N, Ho, Wo, H, W, Cin, Ho, Wo, Ccat, Cin, Cc);
+    LfTapGeom g = lf_base_geom(N, Ho, Wo, H, W, Cin, Ho, Wo, Ccat, Cin, Cc);
     g.ssh = 2; g.ssw = 2; g.ntaps = 9;
     int idx[9];
     for (int kh = 0; kh < 3; ++kh)
@@ -140,7 +126,7 @@ void build_down_conv(lf_erfnet_plan* P, ConvRef& c, int N, int H, int W, int Cin
     c.ndg = 4;
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) {
-            LfTapGeom d = base_geom(N, Ho, Wo, Ho, Wo, Ccat, H, W, Cin, Cc, Cin);
+            LfTapGeom d = lf_base_geom(N, Ho, Wo, Ho, Wo, Ccat, H, W, Cin, Cc, Cin);
             d.dsh = 2; d.dsw = 2; d.dah = a; d.daw = b;
             int kh[2], oh[2], kw[2], ow[2], ti[4];
             const int na = phase_taps(a, kh, oh), nb = phase_taps(b, kw, ow);
@@ -156,7 +142,7 @@ void build_up_conv(lf_erfnet_plan* P, ConvRef& c, int N, int Hi, int Wi, int Cin
     c.nfph = 4;
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) {
-            LfTapGeom g = base_geom(N, Hi, Wi, Hi, Wi, Cin, 2 * Hi, 2 * Wi, Co, Cin, Co);
+            LfTapGeom g = lf_base_geom(N, Hi, Wi, Hi, Wi, Cin, 2 * Hi, 2 * Wi, Co, Cin, Co);
             g.dsh = 2; g.dsw = 2; g.dah = a; g.daw = b;
             int kh[2], oh[2], kw[2], ow[2], ti[4];
             const int na = phase_taps(a, kh, oh), nb = phase_taps(b, kw, ow);
@@ -165,7 +151,7 @@ void build_up_conv(lf_erfnet_plan* P, ConvRef& c, int N, int Hi, int Wi, int Cin
             c.fph[a * 2 + b].geom = g;
             c.fph[a * 2 + b].pack = add_pack(P, c.p_w, Cin, Co, /*sk (ci)*/ (long)Co * 9, /*sn (co)*/ 9, g, ti);
         }
-    LfTapGeom d = base_geom(N, Hi, Wi, 2 * Hi, 2 * Wi, Co, Hi, Wi, Cin, Co, Cin);
+    LfTapGeom d = lf_base_geom(N, Hi, Wi, 2 * Hi, 2 * Wi, Co, Hi, Wi, Cin, Co, Cin);
     d.ssh = 2; d.ssw = 2; d.ntaps = 9;
     int idx[9];
     for (int kh = 0; kh < 3; ++kh)
@@ -176,19 +162,17 @@ void build_up_conv(lf_erfnet_plan* P, ConvRef& c, int N, int Hi, int Wi, int Cin
     c.fwd = c.fph[0];
 }
 
-void bn_alloc(Bump& ws, BNRef& b) {
+void bn_alloc(LfBump& ws, BNRef& b) {
     b.sc = ws.take(b.C); b.sh = ws.take(b.C); b.asc = ws.take(b.C); b.ash = ws.take(b.C);
     b.c1 = ws.take(b.C); b.c2 = ws.take(b.C);
 }
 
-long maxl(long a, long b) { return a > b ? a : b; }
-
 void account_fwd_stats(lf_erfnet_plan* P, const LfTapGeom& g) {
-    P->stat_floats = maxl(P->stat_floats, (long)lf_tapgemm_stat_rows(g) * 2 * g.Cd);
+    P->stat_floats = lf_maxl(P->stat_floats, (long)lf_tapgemm_stat_rows(g) * 2 * g.Cd);
 }
 void account_wgrad(lf_erfnet_plan* P, const LfTapGeom& g) {
-    P->wpart_floats = maxl(P->wpart_floats, (long)lf_tapwgrad_splits(g) * g.ntaps * g.Cs * g.Cd);
-    P->bpart_floats = maxl(P->bpart_floats, (long)lf_tapwgrad_bias_rows(g) * g.Cd);
+    P->wpart_floats = lf_maxl(P->wpart_floats, (long)lf_tapwgrad_splits(g) * g.ntaps * g.Cs * g.Cd);
+    P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_tapwgrad_bias_rows(g) * g.Cd);
 }
 
 }  // namespace
@@ -208,7 +192,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     lf_erfnet_plan* P = new lf_erfnet_plan();
     P->N = N; P->H = H; P->W = W; P->Cin = in_channels; P->Cout = out_channels; P->n_heads = n_heads;
     P->packed_floats = 0; P->stat_floats = 0; P->wpart_floats = 0; P->bpart_floats = 0; P->drop_floats = 0;
-    Bump ws;
+    LfBump ws;
     int param = 0, bn = 0, drop = 0;
     long cur = -1;
     int h = H, w = W;
@@ -265,7 +249,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
         build_up_conv(P, L.cv[0], N, h, w, cin, cout);
         long rows4 = 0;
         for (int ph = 0; ph < 4; ++ph) { rows4 += lf_tapgemm_stat_rows(L.cv[0].fph[ph].geom); account_wgrad(P, L.cv[0].fph[ph].geom); }
-        P->stat_floats = maxl(P->stat_floats, rows4 * 2 * cout);   // the 4 phases' rows are laid end to end
+        P->stat_floats = lf_maxl(P->stat_floats, rows4 * 2 * cout);   // the 4 phases' rows are laid end to end
         P->layers.push_back(L);
         cur = L.b[1]; h *= 2; w *= 2;
     };
@@ -288,13 +272,13 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
 
     // stem / pool / bn-backward partial rows also use the stat scratch regions
     const long npix1 = (long)N * (H / 2) * (W / 2);
-    P->stat_floats = maxl(P->stat_floats, (long)lf_stem_rows(N, H, W) * 2 * 16);
-    P->stat_floats = maxl(P->stat_floats, (long)lf_pool_rows(npix1) * 2 * 128);
-    P->stat_floats = maxl(P->stat_floats, (long)lf_bn_bwd_reduce_rows(npix1) * 2 * 128);
-    P->wpart_floats = maxl(P->wpart_floats, (long)lf_stem_wgrad_rows(N, H, W) * 16 * 36);
-    P->wpart_floats = maxl(P->wpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 16 * 5 * 4);
-    P->bpart_floats = maxl(P->bpart_floats, (long)lf_stem_wgrad_rows(N, H, W) * 16);
-    P->bpart_floats = maxl(P->bpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 8);
+    P->stat_floats = lf_maxl(P->stat_floats, (long)lf_stem_rows(N, H, W) * 2 * 16);
+    P->stat_floats = lf_maxl(P->stat_floats, (long)lf_pool_rows(npix1) * 2 * 128);
+    P->stat_floats = lf_maxl(P->stat_floats, (long)lf_bn_bwd_reduce_rows(npix1) * 2 * 128);
+    P->wpart_floats = lf_maxl(P->wpart_floats, (long)lf_stem_wgrad_rows(N, H, W) * 16 * 36);
+    P->wpart_floats = lf_maxl(P->wpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 16 * 5 * 4);
+    P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_stem_wgrad_rows(N, H, W) * 16);
+    P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 8);
 
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
     P->off_packed = ws.take(P->packed_floats);
@@ -356,6 +340,7 @@ struct Ctx {
     const float* dropmask;           // device buffer or null
     int training;
     hipStream_t st;
+    const float* g_enc = nullptr;    // backward: extra gradient w.r.t. the encoder output (NHWC) or null
     hipStream_t side = nullptr;          // null: everything on st
     mutable unsigned side_reads = 0;     // gradient buffers (bit 0 gA, 1 gB, 2 gC) an in-flight side-stream kernel reads
     // side stream may start once everything enqueued on the main stream so far has finished
@@ -375,12 +360,6 @@ struct Ctx {
     float* at(long off) const { return ws + off; }
     const float* packed(int pack) const { return ws + P->off_packed + P->packs[pack].dst_off; }
 };
-
-#define LF_TRY(expr)              \
-    do {                          \
-        int rc_ = (expr);         \
-        if (rc_ != 0) return rc_; \
-    } while (0)
 
 double gemm_flops(const LfTapGeom& g) { return 2.0 * (double)g.N * g.Hl * g.Wl * g.Cs * g.Cd * g.ntaps; }
 
@@ -407,8 +386,6 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
 }
 
-LfTapArgs no_args() { LfTapArgs a; memset(&a, 0, sizeof(a)); return a; }
-
 int bn_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int nparts, double count) {
     return lf_bn_finalize_fwd(parts, nparts, b.C, count, c.params[b.p_g], c.params[b.p_b], c.running[2 * b.idx],
                               c.running[2 * b.idx + 1], BN_MOM, BN_EPS, c.training, c.at(b.sc), c.at(b.sh), c.at(b.asc),
@@ -432,7 +409,7 @@ int forward_layers(const Ctx& c, const float* img) {
                                    c.training ? stat0 : nullptr, c.st));
                 parts[np++] = {stat0, lf_stem_rows(N, L.Hin, L.Win), 16, 0};
             } else {
-                LfTapArgs a = no_args();
+                LfTapArgs a = lf_no_args();
                 a.stats = stat0;
                 LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
@@ -446,17 +423,17 @@ int forward_layers(const Ctx& c, const float* img) {
                              (long)L.Hout * L.Wout, c.st));
         } else if (L.kind == K_NB) {
             const int srows = lf_tapgemm_stat_rows(L.cv[0].fwd.geom);
-            LfTapArgs a = no_args();
+            LfTapArgs a = lf_no_args();
             LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE, LF_EPI_RELU, a));
             a.stats = stat0;
             LF_TRY(run_gemm(c, L.cv[1].fwd, c.at(L.b[0]), c.at(L.b[1]), c.params[L.cv[1].p_b], LF_PRO_NONE,
                             c.training ? LF_EPI_STATS_SQ : 0, a));
             LfStatPart p0 = {stat0, srows, L.Cout, 0};
             LF_TRY(bn_finalize(c, L.bn[0], &p0, 1, (double)npo));
-            a = no_args();
+            a = lf_no_args();
             a.pro_sc = c.at(L.bn[0].sc); a.pro_sh = c.at(L.bn[0].sh);
             LF_TRY(run_gemm(c, L.cv[2].fwd, c.at(L.b[1]), c.at(L.b[2]), c.params[L.cv[2].p_b], LF_PRO_BNRELU, LF_EPI_RELU, a));
-            a = no_args();
+            a = lf_no_args();
             a.stats = stat0;
             LF_TRY(run_gemm(c, L.cv[3].fwd, c.at(L.b[2]), c.at(L.b[3]), c.params[L.cv[3].p_b], LF_PRO_NONE,
                             c.training ? LF_EPI_STATS_SQ : 0, a));
@@ -469,7 +446,7 @@ int forward_layers(const Ctx& c, const float* img) {
             // the 4 sub-pixel phases write disjoint pixels of c; their stat rows are laid end to end
             int rows = 0;
             for (int ph = 0; ph < 4; ++ph) {
-                LfTapArgs a = no_args();
+                LfTapArgs a = lf_no_args();
                 a.stats = stat0 + (long)rows * 2 * L.Cout;
                 LF_TRY(run_gemm(c, L.cv[0].fph[ph], c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
@@ -598,13 +575,13 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             const BNRef& b1 = L.bn[0];
             // conv1x3_2: wgrad(t3, g_t4 = X); dgrad -> g_t3 = (.) * [t3 > 0] -> F
             LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, X, nullptr, nullptr, 0, bit(X)));
-            LfTapArgs a = no_args();
+            LfTapArgs a = lf_no_args();
             a.mask_src = t3;
             c.before_write(bit(F));
             LF_TRY(run_gemm(c, L.cv[3].dg[0], X, F, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
             // conv3x1_2: input relu(bn1(t2)) recomputed on the fly; g_y1 -> X with the bn1-backward sums
             LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, F, c.at(b1.sc), c.at(b1.sh), 0, bit(F)));
-            a = no_args();
+            a = lf_no_args();
             a.aux = t2; a.msc = c.at(b1.sc); a.msh = c.at(b1.sh); a.asc = c.at(b1.asc); a.ash = c.at(b1.ash);
             a.stats = stat0;
             c.before_write(bit(X));
@@ -616,13 +593,13 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
                                    nullptr, F /*g_t2*/, nullptr, npo, L.Cout, ppi, c.st));
             // conv1x3_1: g_t1 -> X
             LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, F, nullptr, nullptr, 0, bit(F)));
-            a = no_args();
+            a = lf_no_args();
             a.mask_src = t1;
             c.before_write(bit(X));
             LF_TRY(run_gemm(c, L.cv[1].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
             // conv3x1_1 (+ residual branch gradient g_z) -> F, optionally prepared for the previous layer
             LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, X, nullptr, nullptr, 0, bit(X)));
-            a = no_args();
+            a = lf_no_args();
             a.add_src = gz;
             int epi = LF_EPI_ADD;
             add_prep(a, epi);
@@ -633,8 +610,12 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         } else if (L.kind == K_UP) {
             for (int ph = 0; ph < 4; ++ph)
                 LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, ph > 0, bit(X)));
-            LfTapArgs a = no_args();
+            LfTapArgs a = lf_no_args();
             int epi = 0;
+            if (c.g_enc && L.x == lf_erfnet_encoder_offset(P)) {   // gradient of the --clas heads joins here
+                a.add_src = c.g_enc;
+                epi |= LF_EPI_ADD;
+            }
             add_prep(a, epi);
             c.before_write(bit(F));
             LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a));
@@ -656,7 +637,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             c.before_write(bit(F));
             LF_TRY(lf_pool_bwd(c.at(L.x), X, N, L.Hin, L.Win, L.Cin, L.Cout, L.Cout - L.Cin, F, c.st));
             for (int ph = 0; ph < 4; ++ph) {
-                LfTapArgs a = no_args();
+                LfTapArgs a = lf_no_args();
                 a.add_src = F;
                 LF_TRY(run_gemm(c, L.cv[0].dg[ph], X, F, nullptr, LF_PRO_NONE, LF_EPI_ADD, a));
             }
@@ -698,16 +679,18 @@ int lf_erfnet_forward(const lf_erfnet_plan* P, const float* img, const float* co
                        P->W / 2, P->Cout + head, c.st);   // output_conv2 has one more channel (ERFNet.py:125-126)
 }
 
-// Backward of the forward that last used `workspace`.  grad_logits (N,Cout,H,W) NCHW;
+// Backward of the forward that last used `workspace`.  grad_logits (N,Cout,H,W) NCHW; grad_encoder: optional
+// (N,H/8,W/8,128) NHWC gradient w.r.t. the encoder output (the `shared_encoder` the --clas heads consume);
 // grads_host: n_params device pointers receiving d loss / d param (NULL entries are skipped:
 // encoder.output_conv, the unused head).  Gradients are WRITTEN, not accumulated.
 int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* grad_logits,
-                       const float* const* params_host, float* const* grads_host, const float* dropmask, int head,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+                       const float* grad_encoder, const float* const* params_host, float* const* grads_host,
+                       const float* dropmask, int head, void* workspace, size_t workspace_bytes, void* stream) {
     LF_REQUIRE(P && img && grad_logits && params_host && grads_host && workspace, "lf_erfnet_backward: null pointer");
     LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_backward: workspace too small");
     LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_backward: head %d out of range", head);
     Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, 1, (hipStream_t)stream};
+    c.g_enc = grad_encoder;
     // Measured on MI355X (batch 32): running the weight gradients concurrently with the data gradients is
     // ~5 % SLOWER than one stream (two 2-waves/SIMD kernels evict each other's L2 working set), so the side
     // stream is opt-in.

@@ -772,3 +772,85 @@ extern "C" int lf_ce2d_bwd(const float* logits, const int64_t* target, const flo
     LF_CHECK_LAUNCH("ce2d_bwd");
     return 0;
 }
+
+// ---- inference-side back-projection + lane post-processing (BP/test.py:60-88, Projections :128-186) -------
+// One thread per (image, lane, sample height): evaluate the fitted polynomial at y_eval, map (x', y') back
+// through M_inv, scale to the 1280-wide frame, then apply the three gates of test_model in its order:
+// line-type flag == 0 -> fill; sample index below the horizon bound -> fill; outside [lo, hi] -> fill.
+__global__ __launch_bounds__(256) void lane_decode_kernel(const double* __restrict__ beta, const double* __restrict__ y_eval,
+                                                         const double* __restrict__ y_prime, double m0, double m1, double m2,
+                                                         double m6, double m7, double m8, double scale,
+                                                         const float* __restrict__ line_flag, const int* __restrict__ bound,
+                                                         double lo, double hi, double fill, int N, int L, int S, int order,
+                                                         double* __restrict__ x_out, int* __restrict__ x_int) {
+    const long total = (long)N * L * S;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const int s = (int)(u % S);
+        const long nl = u / S;
+        const int n = (int)(nl / L);
+        const double* b = beta + nl * (order + 1);
+        const double ye = y_eval[s];
+        double xp = b[0];
+        for (int k = 1; k <= order; ++k) xp = xp * ye + b[k];          // highest power first, as Projections.Y
+        const double yp = y_prime[s];
+        double x = (m0 * xp + m1 * yp + m2) / (m6 * xp + m7 * yp + m8) * scale;
+        if (line_flag && line_flag[nl] == 0.f) x = fill;
+        if (bound) {
+            int bd = bound[n];                                          // python slice [:bd]
+            if (bd < 0) bd = S + bd < 0 ? 0 : S + bd;
+            if (s < bd) x = fill;
+        }
+        if (x > hi) x = fill;
+        if (x < lo) x = fill;
+        if (x_out) x_out[u] = x;
+        if (x_int) x_int[u] = (int)rint(x);                             // np.round: half to even
+    }
+}
+
+// beta (N, L, order+1) fp64 contiguous; line_flag (N, L) fp32 (already in lane order) or NULL; bound (N) int32 or NULL;
+// lo > hi disables the range gate.  x_out (N, L, S) fp64 and/or x_int (N, L, S) int32.
+extern "C" int lf_lane_decode(const double* beta, const double* y_eval, const double* y_prime, const double* minv_host,
+                              double scale, const float* line_flag, const int* bound, double lo, double hi, double fill, int N,
+                              int L, int S, int order, double* x_out, int* x_int, void* stream) {
+    LF_REQUIRE(beta && y_eval && y_prime && minv_host && (x_out || x_int), "lf_lane_decode: null pointer");
+    LF_REQUIRE(order >= 0 && order <= 3 && N > 0 && L > 0 && S > 0, "lf_lane_decode: bad shape");
+    const double* m = minv_host;
+    if (lo > hi) { lo = -1e300; hi = 1e300; }
+    hipLaunchKernelGGL(lane_decode_kernel, dim3(lf_cdiv((long)N * L * S, 256)), dim3(256), 0, (hipStream_t)stream, beta, y_eval,
+                       y_prime, m[0], m[1], m[2], m[6], m[7], m[8], scale, line_flag, bound, lo, hi, fill, N, L, S, order, x_out,
+                       x_int);
+    LF_CHECK_LAUNCH("lane_decode");
+    return 0;
+}
+
+// ---- exact-area metric (BEV/Loss_crit.py:12-35 polynomial.trapezoidal) ------------------------------------
+// One thread per curve pair; the sum runs in the reference's order and dtype so fp32 inputs round identically.
+template <typename T>
+__global__ __launch_bounds__(256) void trapezoid_kernel(const T* __restrict__ p, const T* __restrict__ q, int B, double a,
+                                                       double b, int n, T* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const T pa = p[3 * i], pb = p[3 * i + 1], pc = p[3 * i + 2];
+    const T qa = q[3 * i], qb = q[3 * i + 1], qc = q[3 * i + 2];
+    const double h = (b - a) / n;
+    auto ev = [](T c2, T c1, T c0, double x) -> T { return c2 * (T)(x * x) + c1 * (T)x + c0; };
+    T s = (T)0;
+    s += fabs(ev(pa, pb, pc, a) / (T)2 - ev(qa, qb, qc, a) / (T)2);
+    for (int k = 1; k < n; ++k) s += fabs(ev(pa, pb, pc, a + k * h) - ev(qa, qb, qc, a + k * h));
+    s += fabs(ev(pa, pb, pc, b) / (T)2 - ev(qa, qb, qc, b) / (T)2);
+    out[i] = s * (T)h;
+}
+
+// p, q: (B, 3) coefficient rows [a, b, c] of a*x^2 + b*x + c; is_double selects fp64 / fp32 storage.
+extern "C" int lf_trapezoid(const void* p, const void* q, int B, double a, double b, int n, int is_double, void* out,
+                            void* stream) {
+    LF_REQUIRE(p && q && out && B > 0 && n > 0, "lf_trapezoid: bad arguments");
+    if (is_double)
+        hipLaunchKernelGGL(trapezoid_kernel<double>, dim3(lf_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)p,
+                           (const double*)q, B, a, b, n, (double*)out);
+    else
+        hipLaunchKernelGGL(trapezoid_kernel<float>, dim3(lf_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)p,
+                           (const float*)q, B, a, b, n, (float*)out);
+    LF_CHECK_LAUNCH("trapezoid");
+    return 0;
+}

@@ -135,20 +135,27 @@ class _BackboneFn(torch.autograd.Function):
         _lib.check(lib.lf_erfnet_forward(plan.handle, _lib.ptr(x), host, _lib.ptr(devarr), running,
                                          _lib.ptr(dropmask), int(training), head, _lib.ptr(logits), _lib.ptr(ws),
                                          plan.ws_bytes, _lib.stream()), "lf_erfnet_forward")
+        ctx.set_materialize_grads(False)
         if net.export_encoder_output:
-            enc = torch.empty(N, 128, H // 8, W // 8, dtype=torch.float32, device=dev)
-            _lib.check(lib.lf_nhwc_to_nchw(ctypes.c_void_p(ws.data_ptr() + 4 * plan.enc_off), _lib.ptr(enc), N, H // 8,
-                                           W // 8, 128, _lib.stream()), "lf_nhwc_to_nchw")
+            # the encoder output is handed out IN PLACE: an NHWC view of the workspace (no copy, no transpose);
+            # Net.forward permutes it to the reference's logical (N,128,H/8,W/8)
+            nenc = N * (H // 8) * (W // 8) * 128
+            enc = ws[4 * plan.enc_off: 4 * (plan.enc_off + nenc)].view(torch.float32).view(N, H // 8, W // 8, 128)
         else:
             enc = torch.empty(0, dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(enc)
         ctx.net, ctx.plan, ctx.head, ctx.ws, ctx.x, ctx.dropmask = net, plan, head, ws, x, dropmask
         ctx.params = params
-        ctx.mark_non_differentiable(enc)
         return logits, enc
 
     @staticmethod
-    def backward(ctx, glogits, _genc):
+    def backward(ctx, glogits, genc):
         lib = _lib.load()
+        if glogits is None:      # only the encoder output was used downstream
+            N, H, W = ctx.plan.shape
+            glogits = torch.zeros(N, ctx.net.out_channels + ctx.head, H, W, dtype=torch.float32, device=ctx.x.device)
+        if genc is not None:
+            genc = genc.contiguous()
         plan, params = ctx.plan, ctx.params
         needs = ctx.needs_input_grad[6:]
         used = ctx.net._used_param_mask(ctx.head)
@@ -165,9 +172,9 @@ class _BackboneFn(torch.autograd.Function):
                 grads.append(None)
         ctx.net._flat_grad = flat
         glogits = glogits.contiguous()
-        _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _ptr_array(params),
-                                          _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.head, _lib.ptr(ctx.ws),
-                                          plan.ws_bytes, _lib.stream()), "lf_erfnet_backward")
+        _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _lib.ptr(genc),
+                                          _ptr_array(params), _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.head,
+                                          _lib.ptr(ctx.ws), plan.ws_bytes, _lib.stream()), "lf_erfnet_backward")
         ctx.ws = None
         return (None, None, None, None, None, None) + tuple(grads)
 
@@ -178,9 +185,9 @@ class Net(nn.Module):
     exactly as BEV/Networks/ERFNet.py:145-157.  ``three_outputs=True`` gives the BP variant's
     ``(encoder_output, decoder_output, output_seg=None)`` (BP/Networks/ERFNet.py:170-176).
 
-    Deviations, all outside the training hot path: ``only_encode=True`` is not implemented;
-    ``encoder_output`` is returned detached (it only feeds the out-of-scope ``--clas`` heads);
-    no gradient is produced for the input image.
+    Deviations: ``only_encode=True`` is not implemented; ``encoder_output`` is a channels-last view of the
+    engine's workspace (logical shape (N,128,H/8,W/8) as in the reference, differentiable: the ``--clas`` heads
+    train through it); no gradient is produced for the input image.
     """
     three_outputs = False
 
@@ -192,8 +199,8 @@ class Net(nn.Module):
         self._plans = {}
         self._ptr_cache = (None, None)
         self._flat_grad = None
-        # encoder_output (N,128,H/8,W/8) is part of the return tuple; the LSQ wrappers never read it (it only feeds
-        # the out-of-scope --clas heads) and switch the NHWC->NCHW export off
+        # encoder_output (N,128,H/8,W/8) is part of the return tuple (zero-copy view); wrappers that never read it
+        # may switch it off
         self.export_encoder_output = True
 
     # ---- bookkeeping -------------------------------------------------------------------
@@ -273,6 +280,8 @@ class Net(nn.Module):
         logits, enc = _BackboneFn.apply(self, plan, x, head, self.training, dropmask, *params)
         if self.training:
             torch._foreach_add_([m.num_batches_tracked for m in self._batchnorms()], 1)
+        if enc.dim() == 4:
+            enc = enc.permute(0, 3, 1, 2)             # logical NCHW, channels-last memory
         if self.three_outputs:
             return enc, logits, None
         return enc, logits

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import geometry, ops
+from . import _lib, geometry, ops
 
 
 class polynomial():
@@ -23,6 +23,17 @@ class polynomial():
         return self.a1 * x ** 2 + self.b1 * x + self.c1
 
     def trapezoidal(self, other):
+        if self.a1.is_cuda:
+            # one launch, no host sync: sums in the reference's order and dtype (lf_trapezoid)
+            lib = _lib.load()
+            dt = self.a1.dtype if self.a1.dtype in (torch.float32, torch.float64) else torch.float32
+            p = torch.stack((self.a1, self.b1, self.c1), 1).to(dt).contiguous()
+            q = torch.stack((other.a1, other.b1, other.c1), 1).to(dt).to(p.device).contiguous()
+            out = torch.empty(p.shape[0], dtype=dt, device=p.device)
+            _lib.check(lib.lf_trapezoid(_lib.ptr(p), _lib.ptr(q), p.shape[0], float(self.a), float(self.b), int(self.n),
+                                        int(dt == torch.float64), _lib.ptr(out), _lib.stream()), "lf_trapezoid")
+            return out
+        # host tensors (the reference calls this on .cpu() copies, BEV/main.py:274-279): same rule, vectorised
         h = float(self.b - self.a) / self.n
         xs = self.a + h * torch.arange(0, self.n + 1, device=self.a1.device, dtype=self.a1.dtype)
         d = (self.calc_pol(xs[:, None]) - other.calc_pol(xs[:, None])).abs()

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import erfnet, fit, geometry
+from .clas import Classification
 
 
 def activation_layer(activation='square', no_cuda=False):
@@ -44,14 +45,11 @@ class _LaneFitNet(nn.Module):
         if self.order < 0 or self.order > self.max_order:
             raise NotImplementedError(
                 'Requested order {} for polynomial fit is not implemented'.format(self.order))
-        if getattr(args, "clas", False):
-            raise NotImplementedError("the --clas line/horizon heads are outside the accelerated hot path")
         if getattr(args, "no_cuda", False):
             raise RuntimeError("lanefit: no_cuda=True requested but this implementation has no CPU path")
         out_channels = args.nclasses + int(not args.end_to_end)
         self.net = backbone_cls(layers=args.layers, in_channels=args.channels_in, out_channels=out_channels,
                                 pretrained=args.pretrained, pool=args.pool)
-        self.net.export_encoder_output = False      # shared_encoder only feeds the (unsupported) --clas heads
         self.activation_name = args.activation_layer
         self.activation = activation_layer(args.activation_layer)
         resize = args.resize
@@ -61,7 +59,12 @@ class _LaneFitNet(nn.Module):
         self.use_cholesky = bool(args.use_cholesky)
         self.end_to_end = args.end_to_end
         self.pretrained = args.pretrained
-        self.classification_branch = False
+        self.classification_branch = bool(getattr(args, "clas", False))
+        if self.classification_branch:
+            # LSQ_layer.py:247-254 (BP) / :270-277 (BEV): both heads read the (32, 64) encoder output
+            self.line_classification = Classification('line', size=(32, 64), channels_in=128, resize=resize).cuda()
+            self.horizon_estimation = Classification('horizon', size=(32, 64), channels_in=128, resize=resize).cuda()
+        self.net.export_encoder_output = self.classification_branch
         self.check_singular = True      # False: skip the per-step D2H status read; inspect self.last_status
         self.return_masked = True
         self.last_status = None
@@ -73,6 +76,11 @@ class _LaneFitNet(nn.Module):
         if self._grid is None or self._grid.device != device:
             self._grid = self._grid_cpu.to(device)
         return self._grid
+
+    def _heads(self, shared_encoder, end_to_end):
+        if end_to_end and self.classification_branch:
+            return self.line_classification(shared_encoder), self.horizon_estimation(shared_encoder)
+        return None, None
 
     def _seg_maps(self, output):
         """Non-end-to-end path: arg-max of the segmentation logits -> per-lane maps valued k at class k
@@ -113,8 +121,9 @@ class BEVNet(_LaneFitNet):
 
     def forward(self, input, end_to_end):
         shared_encoder, output = self.net(input, end_to_end * self.pretrained)
+        line, horizon = self._heads(shared_encoder, end_to_end)
         (b0, b1, b2, b3), masked = self._fit(output, end_to_end)
-        return b0, b1, b2, b3, masked, self.M, output, None, None
+        return b0, b1, b2, b3, masked, self.M, output, line, horizon
 
 
 class _BPBackbone(erfnet.Net):
@@ -139,5 +148,6 @@ class BPNet(_LaneFitNet):
         shared_encoder, output, output_seg = self.net(input, end_to_end * self.pretrained)
         if early_return:
             return output
+        line, horizon = self._heads(shared_encoder, end_to_end)
         (b0, b1, b2, b3), masked = self._fit(output, end_to_end, gt_line)
-        return b0, b1, b2, b3, masked, output, None, None, output_seg
+        return b0, b1, b2, b3, masked, output, line, horizon, output_seg

@@ -121,9 +121,9 @@ def test_backbone_vs_golden_and_grads(golden_backbone, out_channels):
         print("logits |hip - reference fp32| %.2e" % relerr(dec.detach().cpu(), golden_backbone["bb_train_dec_f32"]))
     e = relerr(dec.detach().cpu(), dec64.detach())
     floor = relerr(dec32.detach(), dec64.detach())
-    print("logits |hip-ref64| %.2e |ref32-ref64| %.2e ; enc %.2e" % (e, floor, relerr(enc.cpu(), enc64.detach())))
+    print("logits |hip-ref64| %.2e |ref32-ref64| %.2e ; enc %.2e" % (e, floor, relerr(enc.detach().cpu(), enc64.detach())))
     assert e < max(4 * floor, 2e-5)
-    assert relerr(enc.cpu(), enc64.detach()) < max(4 * floor, 2e-5)
+    assert relerr(enc.detach().cpu(), enc64.detach()) < max(4 * floor, 2e-5)
     sd = net.state_dict()
     for k, v in stats.items():
         assert relerr(sd[k].cpu(), v) < 1e-4, k
