@@ -215,6 +215,32 @@ int lf_trapezoid(const void* p, const void* q, int B, double a, double b, int n,
                  void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * "Next" row 8f-4: the input pipeline on the device.  Replaces the per-sample PIL/torchvision work of
+ * LaneDataset.__getitem__ (BEV/Dataloader/Load_Data_new.py:77-101, BP/Dataloader/Load_Data_new.py:126-173):
+ * F.crop(bottom rows) -> F.resize((R,2R), BILINEAR | NEAREST) -> class remap -> F.hflip -> ToTensor, with
+ * Pillow's fixed-point resampling arithmetic reproduced bit for bit (see csrc/lf_pipeline.hip).
+ *   plan: host object holding the resampling tables for one geometry; upload them once to a device buffer of
+ *     lf_pipeline_table_bytes() and pass that buffer to every call;
+ *   lf_pipeline_image: frames (N,Hin,Win,3) uint8 HWC -> out (N,3,out_h,out_w) fp32 in [0,1];
+ *   lf_pipeline_label: labels (N,Hin,Win) uint8 -> out (N,1,out_h,out_w) int64 through lut (256 int64 =
+ *     (ToTensor(v)*255).long()), mode bit 0: zero classes 3,4 (BEV; BP with nclasses < 3), bit 1: BP's flip
+ *     statement order (pre-flip masks of 3/4 applied to the flipped map, Load_Data_new.py:152-165);
+ *     horizon (N,out_h) fp32 = ones above the first labelled row (BEV :103-105) or NULL;
+ *   flip: (N) uint8 per-sample horizontal flip flags or NULL.
+ * ---------------------------------------------------------------------------------- */
+typedef struct lf_pipeline_plan lf_pipeline_plan;
+lf_pipeline_plan* lf_pipeline_plan_create(int Hin, int Win, int crop_top, int crop_h, int out_h, int out_w);
+void lf_pipeline_plan_destroy(lf_pipeline_plan* plan);
+size_t lf_pipeline_table_bytes(const lf_pipeline_plan* plan);
+int lf_pipeline_upload(const lf_pipeline_plan* plan, void* tables_dev, void* stream);
+int lf_pipeline_tables_host(const lf_pipeline_plan* plan, int* ksx_host, int* ksy_host, int* bx_host, int* kx_host,
+                            int* by_host, int* ky_host, int* ntx_host, int* nty_host);
+int lf_pipeline_image(const lf_pipeline_plan* plan, const uint8_t* frames, int N, const void* tables_dev,
+                      const uint8_t* flip, float* out, void* stream);
+int lf_pipeline_label(const lf_pipeline_plan* plan, const uint8_t* labels, int N, const void* tables_dev,
+                      const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Kernel-level entry points: one factorised convolution of non_bottleneck_1d
  * (nn.Conv2d(C, C, (3,1)|(1,3), padding = dilation = d), BEV/Networks/ERFNet.py:29-37) on NHWC fp32
  * tensors, outside the plan: forward, data gradient (optionally times the ReLU mask of mask_src),

@@ -55,6 +55,13 @@ def _declare(lib):
         "lf_poolflat_bwd": (I, [P, P, I, I, I, I, I, P, P]),
         "lf_lane_decode": (I, [P, P, P, P, D, P, P, D, D, D, I, I, I, I, P, P, P]),
         "lf_trapezoid": (I, [P, P, I, D, D, I, I, P, P]),
+        "lf_pipeline_plan_create": (P, [I, I, I, I, I, I]),
+        "lf_pipeline_plan_destroy": (None, [P]),
+        "lf_pipeline_table_bytes": (c_size_t, [P]),
+        "lf_pipeline_upload": (I, [P, P, P]),
+        "lf_pipeline_tables_host": (I, [P, P, P, P, P, P, P, P, P]),
+        "lf_pipeline_image": (I, [P, P, I, P, P, P, P]),
+        "lf_pipeline_label": (I, [P, P, I, P, P, I, P, P, P, P]),
         "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
         "lf_adam_chunk": (I, []),
         "lf_adam_step": (I, [P, P, I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
