@@ -31,6 +31,8 @@ struct lf_pipeline_plan {
     std::vector<int> ntx, nty;           // nearest source index tables
     int tile_h, tile_w;                  // output tile per workgroup (shrunk until its input window fits the LDS budget)
     int max_rows, max_cols;              // largest input window of an output tile
+    size_t lds_bytes;
+    int in_stride;                       // LDS bytes per staged input row (dword aligned, + shift + tap over-read pad)
     long table_ints;
 };
 
@@ -102,51 +104,95 @@ __host__ __device__ inline Tables table_ptrs(const int* t, int oh, int ow, int k
     return r;
 }
 
-__global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __restrict__ frames, int Hin, int Win, int crop_top,
-                                                             const int* __restrict__ tables, int oh, int ow, int ksx, int ksy,
-                                                             int TILE_H, int TILE_W, int max_rows, int max_cols,
+// KSX / KSY: compile-time tap counts (table rows are zero-padded to them); 0 = generic (runtime count).
+// Staging uses aligned dword loads with a per-row byte shift; the horizontal pass keeps a column's weights in
+// registers while it walks the rows; the vertical pass walks output rows with wave-uniform (scalar) weights.
+template <int KSX, int KSY>
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __restrict__ frames, size_t total_bytes, int Hin, int Win,
+                                                             int crop_top, const int* __restrict__ tables, int oh, int ow,
+                                                             int ksx, int ksy, int TILE_H, int TILE_W, int max_rows, int in_stride,
                                                              const uint8_t* __restrict__ flip, float* __restrict__ out) {
     extern __shared__ uint8_t smem[];
-    uint8_t* s_in = smem;                                         // [max_rows][max_cols*3]
-    uint8_t* s_h = smem + (size_t)max_rows * max_cols * 3;        // [max_rows][TILE_W*3]
+    const int h_stride = TILE_W * 3;
+    int* s_shift = reinterpret_cast<int*>(smem);                                  // [max_rows + 1] byte shift of each staged row
+    uint8_t* s_in = smem + ((size_t)(max_rows + 1) * sizeof(int) + 15) / 16 * 16;   // [max_rows + 1][in_stride]
+    uint8_t* s_h = s_in + (size_t)(max_rows + 1) * in_stride;                     // [max_rows + ksy][h_stride]
     const Tables T = table_ptrs(tables, oh, ow, ksx, ksy);
-    const int n = blockIdx.z;
+    const int n = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ty0 = blockIdx.y * TILE_H, tx0 = blockIdx.x * TILE_W;
     const int th = min(TILE_H, oh - ty0), tw = min(TILE_W, ow - tx0);
     const int r0 = T.by[2 * ty0], r1 = T.by[2 * (ty0 + th - 1)] + T.by[2 * (ty0 + th - 1) + 1];
     const int c0 = T.bx[2 * tx0], c1 = T.bx[2 * (tx0 + tw - 1)] + T.bx[2 * (tx0 + tw - 1) + 1];
     const int nr = r1 - r0, ncb = (c1 - c0) * 3;
-    const uint8_t* base = frames + ((size_t)n * Hin + crop_top + r0) * Win * 3 + (size_t)c0 * 3;
-    for (int i = threadIdx.x; i < nr * ncb; i += 256) {
-        const int r = i / ncb, b = i - r * ncb;
-        s_in[r * (max_cols * 3) + b] = base[(size_t)r * Win * 3 + b];
+    for (int r = wave; r < nr; r += 4) {
+        const size_t g0 = (((size_t)n * Hin + crop_top + r0 + r) * Win + c0) * 3;
+        const int sh = (int)(g0 & 3);
+        const size_t a0 = g0 - sh;
+        const int nd = (sh + ncb + 3) >> 2;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_in + (size_t)r * in_stride);
+        for (int d = lane; d < nd; d += 64) {
+            const size_t byte = a0 + 4 * (size_t)d;
+            uint32_t v;
+            if (byte + 4 <= total_bytes) {
+                v = *reinterpret_cast<const uint32_t*>(frames + byte);
+            } else {
+                v = 0;
+                for (int e = 0; e < 4; ++e)
+                    if (byte + e < total_bytes) v |= (uint32_t)frames[byte + e] << (8 * e);
+            }
+            dst[d] = v;
+        }
+        if (lane == 0) s_shift[r] = sh;
     }
     __syncthreads();
-    // horizontal pass: (row, x, channel) -> uint8
-    for (int i = threadIdx.x; i < nr * tw * 3; i += 256) {
-        const int r = i / (tw * 3), j = i - r * (tw * 3);
-        const int x = j / 3, c = j - x * 3;
-        const int first = T.bx[2 * (tx0 + x)] - c0, cnt = T.bx[2 * (tx0 + x) + 1];
+    // horizontal pass: one (x, channel) column per thread, rows in sequence
+    if ((int)threadIdx.x < tw * 3) {
+        const int j = threadIdx.x, x = j / 3, c = j - x * 3;
+        const int first = (T.bx[2 * (tx0 + x)] - c0) * 3 + c;
         const int* k = T.kx + (long)(tx0 + x) * ksx;
-        const uint8_t* p = s_in + r * (max_cols * 3) + first * 3 + c;
-        int acc = 1 << (PIL_PRECISION_BITS - 1);
-        for (int t = 0; t < cnt; ++t) acc += (int)p[t * 3] * k[t];
-        s_h[r * (TILE_W * 3) + j] = (uint8_t)clip8(acc);
+        if (KSX > 0) {
+            int w[KSX > 0 ? KSX : 1];
+#pragma unroll
+            for (int t = 0; t < KSX; ++t) w[t] = k[t];
+            for (int r = 0; r < nr; ++r) {
+                const uint8_t* p = s_in + (size_t)r * in_stride + s_shift[r] + first;
+                int acc = 1 << (PIL_PRECISION_BITS - 1);
+#pragma unroll
+                for (int t = 0; t < KSX; ++t) acc += (int)p[t * 3] * w[t];     // taps past the count have zero weight
+                s_h[r * h_stride + j] = (uint8_t)clip8(acc);
+            }
+        } else {
+            const int cnt = T.bx[2 * (tx0 + x) + 1];
+            for (int r = 0; r < nr; ++r) {
+                const uint8_t* p = s_in + (size_t)r * in_stride + s_shift[r] + first;
+                int acc = 1 << (PIL_PRECISION_BITS - 1);
+                for (int t = 0; t < cnt; ++t) acc += (int)p[t * 3] * k[t];
+                s_h[r * h_stride + j] = (uint8_t)clip8(acc);
+            }
+        }
     }
     __syncthreads();
-    // vertical pass + ToTensor: fp32 = uint8 / 255, NCHW, optional horizontal flip
+    // vertical pass + ToTensor: fp32 = uint8 / 255, NCHW, optional horizontal flip; thread = (channel, x), x fastest
     const bool fl = flip && flip[n];
-    for (int i = threadIdx.x; i < th * 3 * tw; i += 256) {
-        const int x = i % tw;
-        const int q = i / tw;
-        const int c = q % 3, y = q / 3;
-        const int first = T.by[2 * (ty0 + y)] - r0, cnt = T.by[2 * (ty0 + y) + 1];
-        const int* k = T.ky + (long)(ty0 + y) * ksy;
-        const uint8_t* p = s_h + first * (TILE_W * 3) + x * 3 + c;
-        int acc = 1 << (PIL_PRECISION_BITS - 1);
-        for (int t = 0; t < cnt; ++t) acc += (int)p[t * (TILE_W * 3)] * k[t];
+    for (int j = threadIdx.x; j < 3 * tw; j += 256) {
+        const int c = j / tw, x = j - c * tw;
         const int xo = fl ? ow - 1 - (tx0 + x) : tx0 + x;
-        out[(((size_t)n * 3 + c) * oh + ty0 + y) * ow + xo] = (float)clip8(acc) / 255.0f;
+        float* o = out + (((size_t)n * 3 + c) * oh + ty0) * ow + xo;
+        const uint8_t* col = s_h + x * 3 + c;
+        for (int y = 0; y < th; ++y) {
+            const int first = T.by[2 * (ty0 + y)] - r0;              // wave-uniform: scalar loads
+            const int* k = T.ky + (long)(ty0 + y) * ksy;
+            const uint8_t* p = col + first * h_stride;
+            int acc = 1 << (PIL_PRECISION_BITS - 1);
+            if (KSY > 0) {
+#pragma unroll
+                for (int t = 0; t < KSY; ++t) acc += (int)p[t * h_stride] * k[t];
+            } else {
+                const int cnt = T.by[2 * (ty0 + y) + 1];
+                for (int t = 0; t < cnt; ++t) acc += (int)p[t * h_stride] * k[t];
+            }
+            o[(size_t)y * ow] = (float)clip8(acc) / 255.0f;
+        }
     }
 }
 
@@ -193,8 +239,11 @@ __global__ __launch_bounds__(256) void horizon_kernel(const int64_t* __restrict_
 
 }  // namespace
 
-static size_t lf_pipeline_lds_bytes(const lf_pipeline_plan* P) {
-    return (size_t)P->max_rows * P->max_cols * 3 + (size_t)P->max_rows * P->tile_w * 3;
+static size_t lf_pipeline_lds_bytes(lf_pipeline_plan* P) {
+    // staged rows hold [shift <= 3][window][over-read of up to ksx taps], rounded to dwords; one spare row each
+    P->in_stride = (P->max_cols * 3 + 3 + P->ksx * 3 + 3) / 4 * 4;
+    return ((size_t)(P->max_rows + 1) * sizeof(int) + 15) / 16 * 16 + (size_t)(P->max_rows + 1) * P->in_stride +
+           (size_t)(P->max_rows + P->ksy) * P->tile_w * 3;
 }
 
 extern "C" {
@@ -225,7 +274,8 @@ lf_pipeline_plan* lf_pipeline_plan_create(int Hin, int Win, int crop_top, int cr
             const int n = P->bx[2 * x1] + P->bx[2 * x1 + 1] - P->bx[2 * x0];
             if (n > P->max_cols) P->max_cols = n;
         }
-        if (lf_pipeline_lds_bytes(P) <= LDS_BUDGET) return P;
+        P->lds_bytes = lf_pipeline_lds_bytes(P);
+        if (P->lds_bytes <= LDS_BUDGET) return P;
         if (P->tile_h == 1 && P->tile_w == 1) break;
         if (P->max_cols >= 2 * P->max_rows && P->tile_w > 1) P->tile_w /= 2;     // keep rows of >= 16 pixels while possible
         else if (P->tile_h > 1) P->tile_h /= 2;
@@ -271,9 +321,15 @@ int lf_pipeline_image(const lf_pipeline_plan* P, const uint8_t* frames, int N, c
                       float* out, void* stream) {
     LF_REQUIRE(P && frames && tables_dev && out && N > 0, "lf_pipeline_image: bad arguments");
     const dim3 grid(lf_cdiv(P->out_w, P->tile_w), lf_cdiv(P->out_h, P->tile_h), N);
-    hipLaunchKernelGGL(resize_bilinear_kernel, grid, dim3(256), lf_pipeline_lds_bytes(P), (hipStream_t)stream, frames, P->Hin,
-                       P->Win, P->crop_top, (const int*)tables_dev, P->out_h, P->out_w, P->ksx, P->ksy, P->tile_h, P->tile_w,
-                       P->max_rows, P->max_cols, flip, out);
+    const size_t total = (size_t)N * P->Hin * P->Win * 3;
+#define LF_RESIZE_LAUNCH(KX, KY)                                                                                              \
+    hipLaunchKernelGGL((resize_bilinear_kernel<KX, KY>), grid, dim3(256), P->lds_bytes, (hipStream_t)stream, frames, total,   \
+                       P->Hin, P->Win, P->crop_top, (const int*)tables_dev, P->out_h, P->out_w, P->ksx, P->ksy, P->tile_h,    \
+                       P->tile_w, P->max_rows, P->in_stride, flip, out)
+    if (P->ksx == 7 && P->ksy == 7) LF_RESIZE_LAUNCH(7, 7);          // 640x1280 -> 256x512 (x2.5)
+    else if (P->ksx == 5 && P->ksy == 5) LF_RESIZE_LAUNCH(5, 5);     // -> 320x640 (x2), 512x1024 (x1.25)
+    else LF_RESIZE_LAUNCH(0, 0);
+#undef LF_RESIZE_LAUNCH
     LF_CHECK_LAUNCH("lf_pipeline_image");
     return 0;
 }
