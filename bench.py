@@ -30,6 +30,12 @@ WORKLOADS = {"bev": dict(flop=39.67e9, R=256, K=2, batch=32, desc="BEV ERFNet + 
              "seg": dict(flop=158.8e9, R=512, K=2, batch=16, desc="segmentation branch (end_to_end=False, early_return): ERFNet "
                                                                   "Cout=3 + class-weighted cross entropy, 512x1024 (config 5, per GPU)")}
 PEAK_FP32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA = 2500e12            # MI355X_MICROARCH.md: bf16 dense peak (v_mfma_f32_16x16x32_bf16)
+# HBM-side bytes per launch of the 128-channel 3-tap launch at batch 32 (33.5 MB in + 33.5 MB out algorithmic), from
+# profiles/r1_pmc_hbm_conv128.txt: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads
+# on gfx950 (Infinity-Cache hits are counted too), plus WRITE_SIZE; tap-GEMM 2*30.3 + 35.6 MB, weight gradient
+# 2*176.9 + 7.9 MB
+TRAFFIC_PMC = {0: 2 * 30264.3e3 + 35571.8e3, 1: 2 * 176891.3e3 + 7892.6e3}
 
 
 def make_args(batch):
@@ -119,6 +125,9 @@ def main():
                     help="bev = the BASELINE.json headline (default); bp / seg = configs 3 (in fp32) and 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable Dropout2d (parity-style run)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="matrix-core precision of the convolutions: fp32 (default = the BASELINE headline) or bf16 operands "
+                         "with fp32 accumulation and fp32 tensors (config 3; not a parity mode, the reference is fp32 only)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,6 +151,7 @@ def main():
         for m in model.modules():
             if isinstance(m, torch.nn.Dropout2d):
                 m.p = 0
+    model.net.precision = a.precision
     model.check_singular = False             # no per-step D2H read; status is checked after the timed region
     x = torch.from_numpy(inputs.images(B, R, 2 * R, seed=100 + rank)).cuda()
     gt = torch.from_numpy(inputs.bev_gt_params(B, seed=200 + rank)).cuda()
@@ -222,8 +232,15 @@ def main():
         dom = 0 if fam[0]["ms"] >= fam[1]["ms"] else 1
         d = fam[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA / 1e12,
-                    "unit": "TFLOP/s", "frac": round(ach / (PEAK_FP32_MFMA / 1e12), 4), "traffic": None,
+        # family 0 runs on the bf16 matrix cores in --precision bf16 (the weight gradient stays fp32)
+        peak = PEAK_BF16_MFMA if (a.precision == "bf16" and dom == 0) else PEAK_FP32_MFMA
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak / 1e12,
+                    "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4),
+                    # HBM bytes per launch of the family's representative launch (128-channel 3-tap conv, batch 32:
+                    # 33.5 MB in + 33.5 MB out algorithmic), FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc
+                    # passes: profiles/r1_pmc_hbm_conv128.txt (not re-measured by this run)
+                    "traffic": (TRAFFIC_PMC[dom] if a.workload == "bev" and a.precision == "fp32" and B == 32 else None),
+                    "traffic_note": "bytes per launch of the 128-ch 3-tap launch, rocprofv3 PMC (profiles/r1_pmc_hbm_conv128.txt)",
                     "avg_launch_us": round(1e3 * d["ms"] / max(d["launches"], 1), 2),
                     "launches_per_step": d["launches"] / psteps,
                     "families": {names[i]: {"ms_per_step": round(fam[i]["ms"] / psteps, 3),
@@ -234,10 +251,12 @@ def main():
             "images/sec fwd+bwd, %s" % a.workload
         out = {"metric": metric, "value": round(ips, 2), "unit": "images/sec",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if a.precision == "fp32" else "bf16 MFMA operands (fp32 accumulate, fp32 tensors); weight gradient f32",
+               "data": "synthetic",
                "config": {"workload": "%s, batch %d per GPU, "
-                                      "fp32, train mode (BN batch stats, Dropout2d %s), fwd+bwd, optimizer excluded"
-                                      % (wl["desc"], B, "off" if a.no_dropout else "on"),
+                                      "%s, train mode (BN batch stats, Dropout2d %s), fwd+bwd, optimizer excluded"
+                                      % (wl["desc"], B, "fp32" if a.precision == "fp32" else "bf16 matrix cores", "off" if a.no_dropout else "on"),
                           "global_batch": world * B, "parallelism": "dp%d" % world,
                           "grad_allreduce": "flat fp32 bucket, RCCL" if world > 1 else "none"},
                "roofline": roofline}

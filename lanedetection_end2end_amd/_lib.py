@@ -71,6 +71,8 @@ def _declare(lib):
         "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_weight": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_debug_set_tapgemm_variant": (None, [I]),
+        "lf_debug_set_ops_precision": (None, [I]),
+        "lf_erfnet_set_precision": (I, [P, I]),
         "lf_debug_conv1d_fwd_phases": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P]),
         "lf_erfnet_profile": (I, [P, I]),
         "lf_erfnet_profile_read": (I, [P, P]),

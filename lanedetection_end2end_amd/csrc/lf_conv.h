@@ -35,6 +35,7 @@ enum {
 struct LfTapArgs {
     const float* src;
     const float* wp;        // packed weights [tap][Cs/4][Cd][4]
+    const void* wp16;       // non-null selects the bf16 matrix-core kernel: packed bf16 weights [tap][ceil(Cs/32)*4][Cd][8]
     const float* bias;      // [Cd] or null
     float* dst;
     const float* pro_sc;    // prologue BN scale / shift per source channel
@@ -84,6 +85,10 @@ struct LfPackEntry {
     long sk, sn;
     int tapidx[LF_MAX_TAPS];
     int param;      // index of the parameter tensor holding the weights
+    long dst16_off; // bf16-element offset into the bf16 packed arena (precision mode "bf16")
 };
 int lf_pack_weights_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena,
                            hipStream_t st);
+long lf_pack_bf16_elems(int Kc, int Nc, int ntaps);
+int lf_pack_weights_bf16_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, void* arena16,
+                                hipStream_t st);

@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;
         const int wstep = g.Cd * 16;                       // floats per 16-channel step
         const int ntaps = g.ntaps;
+        const int wlast = (nsteps - 1) * wstep;
         int t_ld = 0, cg_ld = 0, wofs = 0;
         auto issue = [&](Step& S) {
             const bool live = t_ld < ntaps;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
             // advance (scalar selects, no branches); a dead step re-reads the last live operands
             const int cgn = cg_ld + 1;
             const bool wrap = cgn == ncg;
-            wofs = live ? wofs + wstep : wofs;
+            wofs = min(wofs + wstep, wlast);                // a dead step re-reads the last live weights
             cg_ld = live ? (wrap ? 0 : cgn) : cg_ld;
             t_ld = (live && wrap) ? t_ld + 1 : t_ld;
         };
@@ -397,6 +398,134 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// bf16 matrix-core variant (precision mode "bf16": operands rounded to bf16 in registers, fp32 accumulate,
+// fp32 tensors in HBM).  v_mfma_f32_16x16x32_bf16: a lane supplies 8 consecutive k of its row / column
+// (k-block kq = l>>4 of the 32-channel step), C/D layout as the fp32 form -- so the tap table, the pixel
+// mapping and the whole epilogue are shared with tapgemm_kernel.  Per 32-channel step a lane loads 2 dwordx4
+// of its pixel (8 fp32 channels), applies the optional BN+ReLU prologue and the validity mask in fp32,
+// converts with v_cvt_pk_bf16_f32 (round to nearest even) and feeds 16 MFMAs (one per 16x16 tile).
+// Weights are pre-packed bf16 [tap][ceil(Cs/32)*4][Cd][8], zero-padded to whole 32-channel steps, so the
+// partial last step of a 16- or 48-channel contraction multiplies (valid, clamped) pixel data by zeros.
+// At the bf16 rate (16 cycles per MFMA) the loop is bound by the operand path, not by the matrix cores.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 cvt_bf16x8(f32x4 lo, f32x4 hi) {
+    bf16x8 r;
+    r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+    r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+    return r;
+}
+
+template <int NT, int PROC>
+__global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
+    const int cob = blockIdx.y * NT * 16;
+    unsigned bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
+
+    int pn[MT], pi[MT], pj[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const unsigned p = tile0 + m * 16 + pl;
+        pv[m] = p < npix;
+        const unsigned q = pv[m] ? p : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj[m] = (int)(q - r * (unsigned)g.Wl);
+        pn[m] = (int)(r / (unsigned)g.Hl);
+        pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+
+    struct Step { u32x4 w[NT]; f32x4 xl[MT], xh[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
+    __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
+    __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
+    for (int t = 0; t < g.ntaps; ++t) {
+        const int dh = g.tdh[t], dw = g.tdw[t];
+        unsigned o[MT], okb = 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+            const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+            o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff);
+            okb |= (in ? 1u : 0u) << m;
+        }
+        tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+        tab_ok[wave][t][lane] = okb;
+    }
+    const int ncb = (g.Cs + 31) >> 5;                       // 32-channel steps per tap
+    const int nsteps = g.ntaps * ncb;
+    const __bf16* wp = reinterpret_cast<const __bf16*>(a.wp16) + ((long)kq * g.Cd + cob + pl) * 8;
+    const int wstep = g.Cd * 32;                            // bf16 elements per 32-channel step
+    const int ntaps = g.ntaps;
+    const int wlast = (nsteps - 1) * wstep;
+    int t_ld = 0, cb_ld = 0, wofs = 0;
+    auto issue = [&](Step& S) {
+        const bool live = t_ld < ntaps;
+        const int tc = live ? t_ld : ntaps - 1;
+        const uint4 o = tab_off[wave][tc][lane];
+        const unsigned okb = tab_ok[wave][tc][lane];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) S.w[n] = *reinterpret_cast<const u32x4*>(wp + wofs + n * 128);
+        const int c8 = min(cb_ld * 32 + kq * 8, g.Cs - 8);  // a partial last step re-reads valid channels (weights are 0)
+        S.xl[0] = ldg4(a.src + o.x + c8); S.xh[0] = ldg4(a.src + o.x + c8 + 4);
+        S.xl[1] = ldg4(a.src + o.y + c8); S.xh[1] = ldg4(a.src + o.y + c8 + 4);
+        S.xl[2] = ldg4(a.src + o.z + c8); S.xh[2] = ldg4(a.src + o.z + c8 + 4);
+        S.xl[3] = ldg4(a.src + o.w + c8); S.xh[3] = ldg4(a.src + o.w + c8 + 4);
+        if constexpr (PROC == LF_PRO_BNRELU) {
+            S.sc0 = ldg4(a.pro_sc + c8); S.sc1 = ldg4(a.pro_sc + c8 + 4);
+            S.sh0 = ldg4(a.pro_sh + c8); S.sh1 = ldg4(a.pro_sh + c8 + 4);
+        }
+        S.ok = live ? okb : 0u;
+        const int cbn = cb_ld + 1;
+        const bool wrap = cbn == ncb;
+        wofs = min(wofs + wstep, wlast);                    // a dead step re-reads the last live weights
+        cb_ld = live ? (wrap ? 0 : cbn) : cb_ld;
+        t_ld = (live && wrap) ? t_ld + 1 : t_ld;
+    };
+    auto mma = [&](const Step& S) {
+        bf16x8 xb[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 lo = S.xl[m], hi = S.xh[m];
+            if constexpr (PROC == LF_PRO_BNRELU) { lo = max0(lo * S.sc0 + S.sh0); hi = max0(hi * S.sc1 + S.sh1); }
+            const bool in = (S.ok >> m) & 1u;
+            lo.x = in ? lo.x : 0.f; lo.y = in ? lo.y : 0.f; lo.z = in ? lo.z : 0.f; lo.w = in ? lo.w : 0.f;
+            hi.x = in ? hi.x : 0.f; hi.y = in ? hi.y : 0.f; hi.z = in ? hi.z : 0.f; hi.w = in ? hi.w : 0.f;
+            xb[m] = cvt_bf16x8(lo, hi);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 wb = __builtin_bit_cast(bf16x8, S.w[n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb[m], acc[n][m], 0, 0, 0);
+        }
+    };
+    static_assert(MT == 4, "tab_off packs 4 pixel tiles");
+    Step A, B;
+    issue(A);
+    const int npairs = (nsteps + 1) >> 1;
+    for (int pr = 0; pr < npairs; ++pr) {
+        issue(B);
+        mma(A);
+        issue(A);
+        mma(B);
+    }
+    LF_TAPGEMM_EPILOGUE
 }
 
 // Lean variant for 16-output-channel launches (the 128x256 stage, ~3 % of the FLOPs): these are HBM-bound
@@ -511,6 +640,23 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
+    if (a.wp16) {
+#define LF_TG16(NTV)                                                                                                     \
+    do {                                                                                                                 \
+        if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                  \
+    } while (0)
+        LF_REQUIRE(g.Cs >= 8 && g.s_pix >= g.s_choff + 8, "tapgemm bf16: needs at least 8 source channels");
+        switch (nt) {
+            case 4: LF_TG16(4); break;
+            case 3: LF_TG16(3); break;
+            case 2: LF_TG16(2); break;
+            default: LF_TG16(1); break;
+        }
+#undef LF_TG16
+        LF_CHECK_LAUNCH("tapgemm_bf16");
+        return 0;
+    }
     switch (nt) {
         case 4: LF_TG(4); break;
         case 3: LF_TG(3); break;
@@ -989,6 +1135,27 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const LfPackEntry* __
     }
 }
 
+// bf16 operand order of tapgemm_bf16_kernel: [tap][ceil(Kc/32)*4][Nc][8], zero beyond Kc
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const LfPackEntry* __restrict__ entries,
+                                                               const float* const* __restrict__ params,
+                                                               __bf16* __restrict__ arena) {
+    const LfPackEntry e = entries[blockIdx.x];
+    const float* w = params[e.param];
+    __bf16* dst = arena + e.dst16_off;
+    const int kb_per_tap = ((e.Kc + 31) >> 5) * 4;
+    const long total = (long)e.ntaps * kb_per_tap * e.Nc * 8;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const int k8 = (int)(i & 7);
+        long r = i >> 3;
+        const int n = (int)(r % e.Nc);
+        r /= e.Nc;
+        const int kb = (int)(r % kb_per_tap);
+        const int t = (int)(r / kb_per_tap);
+        const int k = kb * 8 + k8;
+        dst[i] = (__bf16)(k < e.Kc ? w[k * e.sk + n * e.sn + e.tapidx[t]] : 0.f);
+    }
+}
+
 }  // namespace
 
 int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,
@@ -1018,3 +1185,13 @@ int lf_pack_weights_launch(const LfPackEntry* entries_dev, int nentries, const f
     LF_CHECK_LAUNCH("pack_weights");
     return 0;
 }
+
+int lf_pack_weights_bf16_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, void* arena16,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(nentries, 16), dim3(256), 0, st, entries_dev, params_dev,
+                       reinterpret_cast<__bf16*>(arena16));
+    LF_CHECK_LAUNCH("pack_weights_bf16");
+    return 0;
+}
+
+long lf_pack_bf16_elems(int Kc, int Nc, int ntaps) { return (long)ntaps * (((Kc + 31) >> 5) * 32) * Nc; }

@@ -38,6 +38,7 @@ int add_pack(lf_convchain_plan* P, int param, int Kc, int Nc, long sk, long sn, 
     e.param = param; e.Kc = Kc; e.Nc = Nc; e.ntaps = g.ntaps; e.sk = sk; e.sn = sn;
     for (int t = 0; t < g.ntaps; ++t) e.tapidx[t] = tapidx[t];
     e.dst_off = P->packed_floats;
+    e.dst16_off = 0;                       // the heads stay on the fp32 matrix-core path
     P->packed_floats += (long)g.ntaps * Kc * Nc;
     P->packs.push_back(e);
     return (int)P->packs.size() - 1;

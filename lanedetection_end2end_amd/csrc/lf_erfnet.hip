@@ -56,6 +56,8 @@ struct lf_erfnet_plan {
     int n_params, n_bn, n_drop;
     int p_head_w[2], p_head_b[2], n_heads;
     long off_entries, off_packed, packed_floats;
+    long off_packed16, packed16_elems;          // bf16 operand copies of the packed weights (precision mode 1)
+    mutable int precision = 0;                  // 0 = fp32 MFMA, 1 = bf16 MFMA operands (fp32 accumulate / storage)
     long off_stat0, off_stat1, stat_floats;     // two scratch regions for BN partial rows
     long off_wpart, wpart_floats, off_bpart, bpart_floats;
     long off_gA, off_gB, off_gC, gbuf_floats;
@@ -82,6 +84,8 @@ int add_pack(lf_erfnet_plan* P, int param, int Kc, int Nc, long sk, long sn, con
     for (int t = 0; t < g.ntaps; ++t) e.tapidx[t] = tapidx[t];
     e.dst_off = P->packed_floats;
     P->packed_floats += (long)g.ntaps * Kc * Nc;
+    e.dst16_off = P->packed16_elems;
+    P->packed16_elems += lf_pack_bf16_elems(Kc, Nc, g.ntaps);
     P->packs.push_back(e);
     return (int)P->packs.size() - 1;
 }
@@ -191,7 +195,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     }
     lf_erfnet_plan* P = new lf_erfnet_plan();
     P->N = N; P->H = H; P->W = W; P->Cin = in_channels; P->Cout = out_channels; P->n_heads = n_heads;
-    P->packed_floats = 0; P->stat_floats = 0; P->wpart_floats = 0; P->bpart_floats = 0; P->drop_floats = 0;
+    P->packed_floats = 0; P->packed16_elems = 0; P->stat_floats = 0; P->wpart_floats = 0; P->bpart_floats = 0; P->drop_floats = 0;
     LfBump ws;
     int param = 0, bn = 0, drop = 0;
     long cur = -1;
@@ -282,6 +286,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
 
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
     P->off_packed = ws.take(P->packed_floats);
+    P->off_packed16 = ws.take((P->packed16_elems + 1) / 2);
     P->off_stat0 = ws.take(P->stat_floats);
     P->off_stat1 = ws.take(P->stat_floats);
     P->off_wpart = ws.take(P->wpart_floats);
@@ -302,6 +307,14 @@ void lf_erfnet_plan_destroy(lf_erfnet_plan* P) {
     delete P;
 }
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)P->total_floats * sizeof(float); }
+// Matrix-core precision of the convolutions and their data gradients: 0 = fp32 MFMA (default, the parity
+// path), 1 = operands rounded to bf16 in registers (v_mfma_f32_16x16x32_bf16), fp32 accumulation, fp32 tensors.
+// Set before a forward; the matching backward must run with the same setting.
+int lf_erfnet_set_precision(const lf_erfnet_plan* P, int mode) {
+    LF_REQUIRE(P && (mode == 0 || mode == 1), "lf_erfnet_set_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+    P->precision = mode;
+    return 0;
+}
 int lf_erfnet_num_params(const lf_erfnet_plan* P) { return P->n_params; }
 int lf_erfnet_num_bn(const lf_erfnet_plan* P) { return P->n_bn; }
 // Dropout2d keep-masks: one (N, C) fp32 block per non_bottleneck_1d with p > 0, in module order;
@@ -382,6 +395,8 @@ struct ProfScope {   // records a HIP event pair on the launch stream around one
 int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const float* bias, int pro, int epi,
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
+    if (c.P->precision == 1)
+        extra.wp16 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed16) + c.P->packs[op.pack].dst16_off;
     ProfScope ps(c, 0, op.geom, epi | (pro << 8), c.st);
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
 }
@@ -653,7 +668,10 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
     LfPackEntry* ent = reinterpret_cast<LfPackEntry*>(c.at(P->off_entries));
     if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
         return lf_fail("erfnet: upload of the pack table failed");
-    return lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st);
+    LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
+    if (P->precision == 1)
+        LF_TRY(lf_pack_weights_bf16_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed16), c.st));
+    return 0;
 }
 
 }  // namespace

@@ -20,6 +20,36 @@ __global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__
     }
 }
 
+// bf16 operand order of tapgemm_bf16_kernel: [tap][ceil(Kc/32)*4][Nc][8], zero beyond Kc
+__global__ __launch_bounds__(256) void pack_one_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Kc, int Nc,
+                                                           int ntaps, long sk, long sn, int flip) {
+    const int kb_per_tap = ((Kc + 31) >> 5) * 4;
+    const long total = (long)ntaps * kb_per_tap * Nc * 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k8 = (int)(i & 7);
+        long r = i >> 3;
+        const int n = (int)(r % Nc);
+        r /= Nc;
+        const int kb = (int)(r % kb_per_tap);
+        const int t = (int)(r / kb_per_tap);
+        const int k = kb * 8 + k8;
+        dst[i] = (__bf16)(k < Kc ? w[k * sk + n * sn + (flip ? ntaps - 1 - t : t)] : 0.f);
+    }
+}
+
+int g_ops_bf16 = 0;
+
+// pack into scratch in the order the selected kernel wants; returns the LfTapArgs weight fields
+void pack_conv1d(LfTapArgs& a, const float* w, float* scratch, int C, long sk, long sn, int flip, hipStream_t st) {
+    if (g_ops_bf16) {
+        hipLaunchKernelGGL(pack_one_bf16_kernel, dim3(64), dim3(256), 0, st, w, reinterpret_cast<__bf16*>(scratch), C, C, 3, sk, sn, flip);
+        a.wp16 = scratch;
+    } else {
+        hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, sk, sn, flip);
+    }
+    a.wp = scratch;
+}
+
 LfTapGeom conv1d_geom(int N, int H, int W, int C, int axis, int d) {
     LfTapGeom g;
     memset(&g, 0, sizeof(g));
@@ -34,6 +64,8 @@ LfTapGeom conv1d_geom(int N, int H, int W, int C, int axis, int d) {
 extern "C" {
 
 void lf_debug_set_tapgemm_variant(int v) { lf_tapgemm_set_variant(v); }
+// 1: the kernel-level conv1d forward / data-gradient calls below use the bf16 matrix-core kernel (tests, kbench)
+void lf_debug_set_ops_precision(int bf16) { g_ops_bf16 = bf16; }
 
 // same as lf_conv1d_fwd with per-wave phase timestamps: dbg receives 8 uint64 per wave
 // (start, tap table built, main loop done, stores retired); waves = ceil(N*H*W/256)*4*(C/64)
@@ -62,10 +94,10 @@ int lf_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, i
     LF_REQUIRE(x && w && y && scratch, "lf_conv1d_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
-    hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, 3L, 3L * C, 0);
     LfTapArgs a;
     memset(&a, 0, sizeof(a));
-    a.src = x; a.wp = scratch; a.bias = bias; a.dst = y;
+    pack_conv1d(a, w, scratch, C, 3L, 3L * C, 0, st);
+    a.src = x; a.bias = bias; a.dst = y;
     return lf_tapgemm_launch(g, a, LF_PRO_NONE, relu ? LF_EPI_RELU : 0, st);
 }
 
@@ -75,10 +107,10 @@ int lf_conv1d_bwd_data(const float* gy, const float* w, const float* mask_src, f
     LF_REQUIRE(gy && w && gx && scratch, "lf_conv1d_bwd_data: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
-    hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, 3L * C, 3L, 1);
     LfTapArgs a;
     memset(&a, 0, sizeof(a));
-    a.src = gy; a.wp = scratch; a.dst = gx; a.mask_src = mask_src;
+    pack_conv1d(a, w, scratch, C, 3L * C, 3L, 1, st);
+    a.src = gy; a.dst = gx; a.mask_src = mask_src;
     return lf_tapgemm_launch(g, a, LF_PRO_NONE, mask_src ? LF_EPI_MASK : 0, st);
 }
 

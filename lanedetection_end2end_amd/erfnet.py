@@ -131,6 +131,8 @@ class _BackboneFn(torch.autograd.Function):
             assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
         host = _ptr_array(params)
         devarr = net._device_ptr_table(params)
+        ctx.precision = 1 if net.precision == "bf16" else 0
+        _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         running = _ptr_array(net._running_buffers())
         _lib.check(lib.lf_erfnet_forward(plan.handle, _lib.ptr(x), host, _lib.ptr(devarr), running,
                                          _lib.ptr(dropmask), int(training), head, _lib.ptr(logits), _lib.ptr(ws),
@@ -172,6 +174,7 @@ class _BackboneFn(torch.autograd.Function):
                 grads.append(None)
         ctx.net._flat_grad = flat
         glogits = glogits.contiguous()
+        _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _lib.ptr(genc),
                                           _ptr_array(params), _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.head,
                                           _lib.ptr(ctx.ws), plan.ws_bytes, _lib.stream()), "lf_erfnet_backward")
@@ -199,6 +202,9 @@ class Net(nn.Module):
         self._plans = {}
         self._ptr_cache = (None, None)
         self._flat_grad = None
+        # matrix-core precision of the convolutions: "fp32" (default, the parity path) or "bf16" (operands rounded
+        # to bf16 in registers, fp32 accumulation and storage; BASELINE config 3 -- the reference has no such mode)
+        self.precision = "fp32"
         # encoder_output (N,128,H/8,W/8) is part of the return tuple (zero-copy view); wrappers that never read it
         # may switch it off
         self.export_encoder_output = True

@@ -471,3 +471,74 @@ def test_full_size_properties():
         _, e32 = net(x, True)
         _, e1 = net(x[5:6].contiguous(), True)
     assert torch.equal(e32[5:6], e1)
+
+
+def test_bf16_matrix_core_mode_kernel_parity():
+    """precision mode "bf16" (BASELINE config 3; the reference has no such mode): the conv kernels round their
+    operands to bf16 and accumulate in fp32.  Sharp statement of that contract, per kernel: the result equals the
+    fp32-accumulated convolution of the bf16-ROUNDED operands (products of bf16 values are exact in fp32), for the
+    forward and the data gradient, with ReLU / mask epilogues, every channel count of the network."""
+    import torch.nn.functional as F
+    from lanedetection_end2end_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream()
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    try:
+        lib.lf_debug_set_ops_precision(1)
+        for (C, H, W, axis, d) in ((128, 16, 32, 0, 4), (128, 16, 32, 1, 16), (64, 24, 40, 0, 1), (64, 24, 40, 1, 2), (16, 32, 64, 1, 1)):
+            N = 3
+            torch.manual_seed(C + axis)
+            x = torch.randn(N, H, W, C, device="cuda")
+            gy = torch.randn(N, H, W, C, device="cuda")
+            w = torch.randn(C, C, 3, device="cuda") * (2.0 / (3 * C)) ** 0.5
+            b = torch.randn(C, device="cuda")
+            y, gx = torch.empty_like(x), torch.empty_like(x)
+            scratch = torch.full((lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096,), float("nan"), device="cuda")
+            w4 = w.view(C, C, 3, 1) if axis == 0 else w.view(C, C, 1, 3)
+            pad, dil = ((d, 0), (d, 1)) if axis == 0 else ((0, d), (1, d))
+            xn = x.permute(0, 3, 1, 2).contiguous()
+            gn = gy.permute(0, 3, 1, 2).contiguous()
+            ref = torch.relu(F.conv2d(rb(xn).double(), rb(w4).double(), b.double(), padding=pad, dilation=dil))
+            _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 1, P(scratch), st), "fwd")
+            e1 = relerr(y.permute(0, 3, 1, 2).cpu(), ref.cpu())
+            gref = torch.nn.grad.conv2d_input(xn.shape, rb(w4).double(), rb(gn).double(), padding=pad, dilation=dil)
+            gref = gref * (xn > 0)
+            _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), P(x), P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
+            e2 = relerr(gx.permute(0, 3, 1, 2).cpu(), gref.cpu())
+            # and it is NOT the fp32 result: the rounding is really applied
+            full = torch.relu(F.conv2d(xn.double(), w4.double(), b.double(), padding=pad, dilation=dil))
+            e3 = relerr(y.permute(0, 3, 1, 2).cpu(), full.cpu())
+            print("bf16 operands C=%d axis %d dil %d: fwd %.1e dgrad %.1e (vs unrounded fp32 conv %.1e)" % (C, axis, d, e1, e2, e3))
+            assert e1 < 2e-6 and e2 < 2e-6 and 5e-4 < e3 < 3e-2
+    finally:
+        lib.lf_debug_set_ops_precision(0)
+
+
+def test_bf16_matrix_core_mode_network():
+    """Whole-network run in precision mode "bf16": finite, deterministic, the fp32 path is untouched by it, and the
+    eval-mode logits stay within bf16 distance of the fp32 engine's (eval mode: running statistics, no batch-stat
+    chaos; train mode on random weights decorrelates under ANY 2^-9 perturbation, the CPU oracle in bf16 included)."""
+    net, P = build(out_channels=2)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0
+    x = torch.from_numpy(inputs.images(2, 64, 128, seed=51)).cuda()
+    net.eval()
+    with torch.no_grad():
+        _, ref = net(x, True)
+        net.precision = "bf16"
+        _, lo = net(x, True)
+        _, lo2 = net(x, True)
+        net.precision = "fp32"
+        _, ref2 = net(x, True)
+    assert torch.equal(ref, ref2) and torch.equal(lo, lo2) and not torch.equal(ref, lo)
+    e = float((lo - ref).norm() / ref.norm())
+    print("eval-mode logits, bf16 matrix cores vs fp32: relative L2 %.2e" % e)
+    assert e < 0.1
+    net.train()
+    net.precision = "bf16"
+    enc, dec = net(x, True)
+    dec.square().mean().backward()
+    g = [p.grad for p in net.parameters() if p.grad is not None]
+    assert torch.isfinite(dec).all() and all(torch.isfinite(t).all() for t in g) and len(g) == 226

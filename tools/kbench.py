@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[2])
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--bf16", action="store_true", help="bf16 matrix-core kernel for fwd / dgrad; the torch check runs on "
+                    "bf16-rounded operands (products exact in fp32, so the tolerance stays at fp32 level)")
     ap.add_argument("--one", type=int, nargs=5, metavar=("C", "H", "W", "AXIS", "DIL"), help="run a single shape (for PMC passes)")
     a = ap.parse_args()
     lib = _lib.load()
@@ -66,6 +68,14 @@ def main():
         bn = b.clone().requires_grad_(True)
         yr = F.conv2d(xn, wn, bn, padding=pad, dilation=dil)
         yr.backward(gy.permute(0, 3, 1, 2))
+        gx_ref = xn.grad
+        lib.lf_debug_set_ops_precision(1 if a.bf16 else 0)
+        if a.bf16:
+            rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+            with torch.no_grad():
+                yr = F.conv2d(rb(xn), rb(w4), b, padding=pad, dilation=dil)
+                gx_ref = torch.nn.grad.conv2d_input(xn.shape, rb(w4), rb(gy.permute(0, 3, 1, 2).contiguous()), padding=pad,
+                                                    dilation=dil)
         for v in a.variants:
             lib.lf_debug_set_tapgemm_variant(v)
             f = lambda: _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 0, P(scratch), st), "fwd")
@@ -73,7 +83,7 @@ def main():
             e1 = float((y.permute(0, 3, 1, 2) - yr).abs().max() / yr.abs().max())
             g = lambda: _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), None, P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
             td = timeit(g, a.iters)
-            e2 = float((gx.permute(0, 3, 1, 2) - xn.grad).abs().max() / xn.grad.abs().max())
+            e2 = float((gx.permute(0, 3, 1, 2) - gx_ref).abs().max() / gx_ref.abs().max())
             h = lambda: _lib.check(lib.lf_conv1d_bwd_weight(P(x), P(gy), P(gw), P(gb), N, H, W, C, axis, d, P(scratch), st), "wgrad")
             tw = timeit(h, a.iters)
             e3 = float((gw.view_as(wn.grad) - wn.grad).abs().max() / wn.grad.abs().max())
