@@ -135,7 +135,9 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
 void lf_erfnet_plan_destroy(lf_erfnet_plan* plan);
 /* Matrix-core precision of the convolutions and their data gradients (BASELINE config 3 "bf16"; there is no
  * reference for it -- the reference is fp32 only): 0 = fp32 MFMA (default; the parity path), 1 = operands
- * rounded to bf16 (RNE) in registers, v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 tensors in HBM. */
+ * rounded to bf16 (RNE) in registers, v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 tensors in HBM,
+ * 2 = mode 1 with every activation / gradient tensor of the workspace stored as bf16 (weight gradient on the fp32
+ * matrix cores from widened operands; parameters, their gradients, BN statistics, logits stay fp32). */
 int lf_erfnet_set_precision(const lf_erfnet_plan* plan, int mode);
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* plan);
 int lf_erfnet_num_params(const lf_erfnet_plan* plan);
@@ -260,8 +262,9 @@ int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, 
                          int axis, int dilation, float* scratch, void* stream);
 /* kernel A/B switch used by tools/kbench.py only (1, 2 = default, 4: see lf_conv.hip) */
 void lf_debug_set_tapgemm_variant(int v);
-/* 1: lf_conv1d_fwd / lf_conv1d_bwd_data run the bf16 matrix-core kernel (kernel-level parity tests, kbench) */
-void lf_debug_set_ops_precision(int bf16);
+/* precision mode of the lf_conv1d_* calls (kernel-level parity tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32
+ * tensors, 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src hold bf16; w, bias, gw, gb stay fp32) */
+void lf_debug_set_ops_precision(int mode);
 /* lf_conv1d_fwd + per-wave s_memtime stamps (start, tap table built, main loop done, stores retired; 8 words/wave) */
 int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C,
                                int axis, int dilation, float* scratch, unsigned long long* dbg, void* stream);

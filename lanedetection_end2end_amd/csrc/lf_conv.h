@@ -35,6 +35,7 @@ enum {
 struct LfTapArgs {
     const float* src;
     const float* wp;        // packed weights [tap][Cs/4][Cd][4]
+    int s16;                // 1: src / dst / mask_src / add_src / aux hold bf16 elements (needs wp16)
     const void* wp16;       // non-null selects the bf16 matrix-core kernel: packed bf16 weights [tap][ceil(Cs/32)*4][Cd][8]
     const float* bias;      // [Cd] or null
     float* dst;
@@ -61,6 +62,7 @@ struct LfWgradArgs {
     const float* g;         // dest-side gradient tensor, geometry = dest fields
     const float* pro_sc;    // optional BN+ReLU recompute on x
     const float* pro_sh;
+    int s16;                // 1: x and g hold bf16 elements (partials and bias rows stay fp32)
     float* partial;         // [splits][ntaps][Cs][Cd]
     float* bias_partial;    // [bias_rows][Cd] or null
 };

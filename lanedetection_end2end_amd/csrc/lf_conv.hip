@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "lf_conv.h"
+#include "lf_types.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -33,6 +34,21 @@ __device__ __forceinline__ f32x4 max0(f32x4 v) {
 }
 __device__ __forceinline__ f32x4 keep_pos(f32x4 v, f32x4 m) {
     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    return v;
+}
+// storage-typed access of the epilogue operands / result (S16: the tensors hold bf16 elements, see lf_types.h)
+template <bool S16>
+__device__ __forceinline__ f32x4 epi_ld(const float* base, long off) {
+    if constexpr (S16) return lf_ldv(reinterpret_cast<const lf_bf16*>(base) + off);
+    else return ldg4(base + off);
+}
+template <bool S16>
+__device__ __forceinline__ void epi_st(float* base, long off, f32x4 v) {
+    if constexpr (S16) lf_stv(reinterpret_cast<lf_bf16*>(base) + off, v);
+    else *reinterpret_cast<f32x4*>(base + off) = v;
+}
+__device__ __forceinline__ f32x4 round_bf16(f32x4 v) {
+    v.x = (float)(lf_bf16)v.x; v.y = (float)(lf_bf16)v.y; v.z = (float)(lf_bf16)v.z; v.w = (float)(lf_bf16)v.w;
     return v;
 }
 // sum over the 16 lanes that share l>>4 (xor 1,2,4,8 stays inside the 16-lane group)
@@ -58,9 +74,9 @@ _Pragma("unroll") \
 _Pragma("unroll") \
         for (int m = 0; m < MT; ++m) { \
             doff[m] = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + g.d_choff + co; \
-            if (epi & LF_EPI_ADD) la[m] = ldg4(a.add_src + doff[m]); \
-            if (epi & LF_EPI_MASK) lm[m] = ldg4(a.mask_src + doff[m]); \
-            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[m] = ldg4(a.aux + doff[m]); \
+            if (epi & LF_EPI_ADD) la[m] = epi_ld<S16>(a.add_src, doff[m]); \
+            if (epi & LF_EPI_MASK) lm[m] = epi_ld<S16>(a.mask_src, doff[m]); \
+            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[m] = epi_ld<S16>(a.aux, doff[m]); \
             if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[m] = ldg4(a.dm + (long)pn[m] * g.Cd + co); \
         } \
 _Pragma("unroll") \
@@ -70,7 +86,8 @@ _Pragma("unroll") \
             if (epi & LF_EPI_MASK) v = keep_pos(v, lm[m]); \
             if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[m] * msc + msh); \
             if (epi & LF_EPI_RELU) v = max0(v); \
-            if (pv[m]) *reinterpret_cast<f32x4*>(a.dst + doff[m]) = v; \
+            if (S16) v = round_bf16(v);   /* statistics are taken from the values as stored */ \
+            if (pv[m]) epi_st<S16>(a.dst, doff[m], v); \
             if (!pv[m]) v = zero4(); \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
@@ -102,6 +119,7 @@ _Pragma("unroll") \
 
 template <int NT, int VAR, int PROC>
 __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    constexpr bool S16 = false;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
@@ -421,7 +439,7 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(f32x4 lo, f32x4 hi) {
     return r;
 }
 
-template <int NT, int PROC>
+template <int NT, int PROC, bool S16>
 __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
@@ -449,7 +467,9 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
 
+    // S16: the source holds bf16 -> one dwordx4 per tile is the whole 8-channel operand (xl used as raw bits)
     struct Step { u32x4 w[NT]; f32x4 xl[MT], xh[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
+    const lf_bf16* src16 = reinterpret_cast<const lf_bf16*>(a.src);
     __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
     __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
     for (int t = 0; t < g.ntaps; ++t) {
@@ -481,10 +501,17 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 #pragma unroll
         for (int n = 0; n < NT; ++n) S.w[n] = *reinterpret_cast<const u32x4*>(wp + wofs + n * 128);
         const int c8 = min(cb_ld * 32 + kq * 8, g.Cs - 8);  // a partial last step re-reads valid channels (weights are 0)
-        S.xl[0] = ldg4(a.src + o.x + c8); S.xh[0] = ldg4(a.src + o.x + c8 + 4);
-        S.xl[1] = ldg4(a.src + o.y + c8); S.xh[1] = ldg4(a.src + o.y + c8 + 4);
-        S.xl[2] = ldg4(a.src + o.z + c8); S.xh[2] = ldg4(a.src + o.z + c8 + 4);
-        S.xl[3] = ldg4(a.src + o.w + c8); S.xh[3] = ldg4(a.src + o.w + c8 + 4);
+        if constexpr (S16) {
+            S.xl[0] = *reinterpret_cast<const f32x4*>(src16 + o.x + c8);
+            S.xl[1] = *reinterpret_cast<const f32x4*>(src16 + o.y + c8);
+            S.xl[2] = *reinterpret_cast<const f32x4*>(src16 + o.z + c8);
+            S.xl[3] = *reinterpret_cast<const f32x4*>(src16 + o.w + c8);
+        } else {
+            S.xl[0] = ldg4(a.src + o.x + c8); S.xh[0] = ldg4(a.src + o.x + c8 + 4);
+            S.xl[1] = ldg4(a.src + o.y + c8); S.xh[1] = ldg4(a.src + o.y + c8 + 4);
+            S.xl[2] = ldg4(a.src + o.z + c8); S.xh[2] = ldg4(a.src + o.z + c8 + 4);
+            S.xl[3] = ldg4(a.src + o.w + c8); S.xh[3] = ldg4(a.src + o.w + c8 + 4);
+        }
         if constexpr (PROC == LF_PRO_BNRELU) {
             S.sc0 = ldg4(a.pro_sc + c8); S.sc1 = ldg4(a.pro_sc + c8 + 4);
             S.sh0 = ldg4(a.pro_sh + c8); S.sh1 = ldg4(a.pro_sh + c8 + 4);
@@ -500,9 +527,24 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
         bf16x8 xb[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            f32x4 lo = S.xl[m], hi = S.xh[m];
-            if constexpr (PROC == LF_PRO_BNRELU) { lo = max0(lo * S.sc0 + S.sh0); hi = max0(hi * S.sc1 + S.sh1); }
             const bool in = (S.ok >> m) & 1u;
+            if constexpr (S16 && PROC != LF_PRO_BNRELU) {       // raw bf16 bits: mask and use as they are
+                u32x4 r = __builtin_bit_cast(u32x4, S.xl[m]);
+                r.x = in ? r.x : 0u; r.y = in ? r.y : 0u; r.z = in ? r.z : 0u; r.w = in ? r.w : 0u;
+                xb[m] = __builtin_bit_cast(bf16x8, r);
+                continue;
+            }
+            f32x4 lo, hi;
+            if constexpr (S16) {
+                const u32x4 r = __builtin_bit_cast(u32x4, S.xl[m]);
+                lo.x = __uint_as_float(r.x << 16); lo.y = __uint_as_float(r.x & 0xffff0000u);
+                lo.z = __uint_as_float(r.y << 16); lo.w = __uint_as_float(r.y & 0xffff0000u);
+                hi.x = __uint_as_float(r.z << 16); hi.y = __uint_as_float(r.z & 0xffff0000u);
+                hi.z = __uint_as_float(r.w << 16); hi.w = __uint_as_float(r.w & 0xffff0000u);
+            } else {
+                lo = S.xl[m]; hi = S.xh[m];
+            }
+            if constexpr (PROC == LF_PRO_BNRELU) { lo = max0(lo * S.sc0 + S.sh0); hi = max0(hi * S.sc1 + S.sh1); }
             lo.x = in ? lo.x : 0.f; lo.y = in ? lo.y : 0.f; lo.z = in ? lo.z : 0.f; lo.w = in ? lo.w : 0.f;
             hi.x = in ? hi.x : 0.f; hi.y = in ? hi.y : 0.f; hi.z = in ? hi.z : 0.f; hi.w = in ? hi.w : 0.f;
             xb[m] = cvt_bf16x8(lo, hi);
@@ -533,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 // many waves per SIMD; the compiler is free to hoist the next step's loads.
 template <int NT>
 __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    constexpr bool S16 = false;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
@@ -640,11 +683,15 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
         else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
+    LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
+    LF_REQUIRE(!a.s16 || (g.s_pix % 8 == 0 && g.s_choff % 8 == 0), "tapgemm: bf16 source layout must be 16-byte aligned per pixel");
     if (a.wp16) {
 #define LF_TG16(NTV)                                                                                                     \
     do {                                                                                                                 \
-        if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                  \
+        if (a.s16 && pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 1, true>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else if (a.s16) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0, true>), grid, dim3(256), 0, st, g, a, pro, epi);  \
+        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 1, false>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0, false>), grid, dim3(256), 0, st, g, a, pro, epi);            \
     } while (0)
         LF_REQUIRE(g.Cs >= 8 && g.s_pix >= g.s_choff + 8, "tapgemm bf16: needs at least 8 source channels");
         switch (nt) {
@@ -679,7 +726,19 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
 // ---------------------------------------------------------------------------------------
 namespace {
 
-template <bool XV, bool GV, int XT, int GT, int U>
+// storage-typed loads of the weight-gradient kernels (S16: x and g hold bf16 elements, widened exactly to fp32)
+template <bool S16>
+__device__ __forceinline__ f32x4 wg_ld4(const float* base, unsigned off) {
+    if constexpr (S16) return lf_ldv(reinterpret_cast<const lf_bf16*>(base) + off);
+    else return ldg4(base + off);
+}
+template <bool S16>
+__device__ __forceinline__ float wg_ld1(const float* base, unsigned off) {
+    if constexpr (S16) return (float)reinterpret_cast<const lf_bf16*>(base)[off];
+    else return base[off];
+}
+
+template <bool XV, bool GV, int XT, int GT, int U, bool S16>
 __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
                                                       const long pps, const int write_bias, const int gxs) {
     constexpr int XTiles = XV ? 4 : XT, GTiles = GV ? 4 : GT;
@@ -762,19 +821,19 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
             const bool v = rowv && (p + 4 * u) < p_end;
             vm |= (v ? 1u : 0u) << u;
             const unsigned go = v ? gofs + u * gstep : gofs;
-            if constexpr (GV) S.g4[u] = ldg4(a.g + go);
+            if constexpr (GV) S.g4[u] = wg_ld4<S16>(a.g, go);
             else {
 #pragma unroll
-                for (int q = 0; q < GTiles; ++q) S.gs[u][q] = a.g[go + q * 16];
+                for (int q = 0; q < GTiles; ++q) S.gs[u][q] = wg_ld1<S16>(a.g, go + q * 16);
             }
             const int sx = (jj + 4 * u) * g.ssw + dw;
             const bool xin = v && yin && sx >= 0 && sx < g.Ws;
             xm |= (xin ? 1u : 0u) << u;
             const unsigned xo = xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix);
-            if constexpr (XV) S.x4[u] = ldg4(a.x + xo);
+            if constexpr (XV) S.x4[u] = wg_ld4<S16>(a.x, xo);
             else {
 #pragma unroll
-                for (int r = 0; r < XTiles; ++r) S.xs[u][r] = a.x[xo + r * 16];
+                for (int r = 0; r < XTiles; ++r) S.xs[u][r] = wg_ld1<S16>(a.x, xo + r * 16);
             }
         }
         S.vmask = vm; S.xmask = xm;
@@ -882,7 +941,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
 
 // 16 x 16 channel weight gradient with ALL taps in one wave (the 128x256 stage): one pass over G and X
 // instead of one per tap -- these launches are HBM-bound, the per-tap split tripled their traffic.
-template <int NTAPS>
+template <int NTAPS, bool S16>
 __global__ __launch_bounds__(256) void tapwgrad16_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
                                                         const long pps, const int write_bias) {
     constexpr int U = 4;
@@ -918,7 +977,7 @@ __global__ __launch_bounds__(256) void tapwgrad16_kernel(const LfTapGeom g, cons
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool v = (p + 4 * u) < p_end;
-            const float t0 = a.g[v ? gofs + u * gstep : gofs];
+            const float t0 = wg_ld1<S16>(a.g, v ? gofs + u * gstep : gofs);
             gv[u] = v ? t0 : 0.f;
         }
 #pragma unroll
@@ -930,7 +989,7 @@ __global__ __launch_bounds__(256) void tapwgrad16_kernel(const LfTapGeom g, cons
             for (int u = 0; u < U; ++u) {
                 const int sx = (pj + 4 * u) * g.ssw + tdw[t];
                 const bool in = yin && sx >= 0 && sx < g.Ws && (p + 4 * u) < p_end;
-                float x0 = a.x[xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix)];
+                float x0 = wg_ld1<S16>(a.x, xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix));
                 if (pro == LF_PRO_BNRELU) x0 = fmaxf(x0 * psc + psh, 0.f);
                 xv[t][u] = in ? x0 : 0.f;
             }
@@ -1021,15 +1080,18 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
     const int xb = c.xt * 16, gb = c.gt * 16;
     const int wb = a.bias_partial != nullptr;
     if (g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0) {
-        hipLaunchKernelGGL(tapwgrad16_kernel<3>, dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);
+        if (a.s16) hipLaunchKernelGGL((tapwgrad16_kernel<3, true>), dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);
+        else hipLaunchKernelGGL((tapwgrad16_kernel<3, false>), dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);
         LF_CHECK_LAUNCH("tapwgrad16");
         return 0;
     }
     dim3 grid(c.gx * g.ntaps * (g.Cs / xb) * (g.Cd / gb));
 #define LF_WG(XV, GV, XT, GT)                                                                                     \
     do {                                                                                                          \
-        if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
-        else hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);        \
+        if (a.s16 && c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
+        else if (a.s16) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);   \
+        else if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, false>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
+        else hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1, false>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);  \
     } while (0)
     if (c.xv && c.gv) LF_WG(true, true, 4, 4);
     else if (c.xv && c.gt == 1) LF_WG(true, false, 4, 1);

@@ -214,7 +214,7 @@ int lf_convchain_forward(const lf_convchain_plan* P, const float* x, const float
                                   ws + P->sh[i], ws + P->asc[i], ws + P->ash[i], st));
     }
     const int l = P->L - 1;
-    return lf_bn_act(ws + P->z[l], ws + P->sc[l], ws + P->sh[l], nullptr, nullptr, y, npix, P->C[P->L], (long)P->H * P->W, st);
+    return lf_bn_act(ws + P->z[l], ws + P->sc[l], ws + P->sh[l], nullptr, nullptr, y, npix, P->C[P->L], (long)P->H * P->W, 0, st);
 }
 
 // Backward of the forward that last used `workspace`.  gy (N,H,W,C_L) NHWC; grads_host: 4*L device pointers
@@ -232,18 +232,19 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
     float *A = ws + P->off_gA, *B = ws + P->off_gB;
     // last block: BatchNorm + ReLU backward from the saved output
     int l = P->L - 1;
-    LF_TRY(lf_bn_bwd_reduce(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], nullptr, stat, npix, P->C[l + 1], ppi, st));
+    LF_TRY(lf_bn_bwd_reduce(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], nullptr, stat, npix, P->C[l + 1], ppi, 0, st));
     LfStatPart rp = {stat, lf_bn_bwd_reduce_rows(npix), P->C[l + 1], 0};
     LF_TRY(lf_bn_bwd_finalize(&rp, 1, P->C[l + 1], (double)npix, ws + P->c1[l], ws + P->c2[l], grads_host[4 * l + 2],
                               grads_host[4 * l + 3], st));
     LF_TRY(lf_bn_bwd_apply(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], params_host[4 * l + 2], ws + P->c1[l],
-                           ws + P->c2[l], nullptr, A, nullptr, npix, P->C[l + 1], ppi, st));
+                           ws + P->c2[l], nullptr, A, nullptr, npix, P->C[l + 1], ppi, 0, st));
     float *gz = A, *other = B;      // gz = d loss / d z_i
     for (int i = l; i >= 0; --i) {
         // weight + bias gradient: input a_{i-1} = relu(bn_{i-1}(z_{i-1})) recomputed on the operand load
         LfWgradArgs wa;
         wa.x = i == 0 ? x : ws + P->z[i - 1];
         wa.g = gz;
+        wa.s16 = 0;
         wa.pro_sc = i == 0 ? nullptr : ws + P->sc[i - 1];
         wa.pro_sh = i == 0 ? nullptr : ws + P->sh[i - 1];
         wa.partial = ws + P->off_wpart;
@@ -270,7 +271,7 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
         LF_TRY(lf_bn_bwd_finalize(&sp, 1, P->C[i], (double)npix, ws + P->c1[j], ws + P->c2[j], grads_host[4 * j + 2],
                                   grads_host[4 * j + 3], st));
         LF_TRY(lf_bn_bwd_apply(other, nullptr, ws + P->z[j], ws + P->asc[j], ws + P->ash[j], params_host[4 * j + 2],
-                               ws + P->c1[j], ws + P->c2[j], nullptr, gz, nullptr, npix, P->C[i], ppi, st));
+                               ws + P->c1[j], ws + P->c2[j], nullptr, gz, nullptr, npix, P->C[i], ppi, 0, st));
         // gz now holds d loss / d z_{i-1} (written over the consumed gradient), `other` is scratch again
     }
     return 0;

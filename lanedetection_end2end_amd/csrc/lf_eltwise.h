@@ -1,4 +1,6 @@
-// Bandwidth-bound kernels of the ERFNet backbone (NHWC fp32): BatchNorm statistics finalise /
+// Bandwidth-bound kernels of the ERFNet backbone.  Activation / gradient tensors are NHWC fp32, or NHWC bf16 when the
+// launcher's `s16` flag is set (precision mode 2; the pointers still travel as float*): arithmetic is fp32 either
+// way, per-channel vectors, statistics rows and parameter gradients are always fp32.  Kernels: BatchNorm statistics finalise /
 // apply / backward, max-pool branches, the 3-channel stem, the 2x2 transposed-conv head.
 #pragma once
 #include "lf_common.h"
@@ -14,37 +16,38 @@ int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count,
                        float* scale, float* shift, float* asc /*rstd*/, float* ash /*-mean*rstd*/, hipStream_t st);
 // y = relu((x*sc+sh) [* dm[n][c]] [+ res])
 int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm, const float* res, float* y,
-              long npix, int C, long pix_per_image, hipStream_t st);
+              long npix, int C, long pix_per_image, int s16, hipStream_t st);
 // gm = g * [y > 0] * dm ; partial rows of (sum gm, sum gm*xhat), xhat = t*asc + ash
 int lf_bn_bwd_reduce_rows(long npix);
 int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* dm,
-                     float* rows, long npix, int C, long pix_per_image, hipStream_t st);
+                     float* rows, long npix, int C, long pix_per_image, int s16, hipStream_t st);
 // partial rows -> c1 = sum/M, c2 = sumx/M, and the parameter gradients ggamma = sumx, gbeta = sum
 int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count, float* c1, float* c2, float* ggamma,
                        float* gbeta, hipStream_t st);
 // g_t = gamma*rstd*(gm - c1 - xhat*c2); optionally g_z = g*[y>0]
 int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* gamma,
                     const float* c1, const float* c2, const float* dm, float* g_t, float* g_z, long npix, int C,
-                    long pix_per_image, hipStream_t st);
+                    long pix_per_image, int s16, hipStream_t st);
 
 // DownsamplerBlock pool branch: cat[..., choff:choff+Cin] = maxpool2x2(x), + stat partial rows
 int lf_pool_rows(long npix_out);
 int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat, int cat_pix, int choff, float* rows,
-                       hipStream_t st);
+                       int s16, hipStream_t st);
 int lf_pool_bwd(const float* x, const float* gcat, int N, int H, int W, int Cin, int cat_pix, int choff, float* gx,
-                hipStream_t st);
+                int s16, hipStream_t st);
 
 // stem: DownsamplerBlock(3,16) on the NCHW input image: conv3x3 s2 (3->13) || maxpool -> cat (N,H/2,W/2,16)
 int lf_stem_rows(int N, int H, int W);
 int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, const float* b, float* cat, float* rows,
-                hipStream_t st);
+                int s16, hipStream_t st);
 int lf_stem_wgrad_rows(int N, int H, int W);
 int lf_stem_wgrad(const float* img, const float* gcat, int N, int Cin, int H, int W, float* wrows, float* brows,
-                  hipStream_t st);
+                  int s16, hipStream_t st);
 
 // head: ConvTranspose2d(16, K, 2, stride 2): NHWC (N,h,w,16) -> NCHW (N,K,2h,2w)
-int lf_head_fwd(const float* x, const float* w, const float* b, float* out, int N, int h, int w_, int K, hipStream_t st);
-int lf_head_bwd_data(const float* gout, const float* w, float* gx, int N, int h, int w_, int K, hipStream_t st);
+int lf_head_fwd(const float* x, const float* w, const float* b, float* out, int N, int h, int w_, int K, int s16,
+                hipStream_t st);
+int lf_head_bwd_data(const float* gout, const float* w, float* gx, int N, int h, int w_, int K, int s16, hipStream_t st);
 int lf_head_wgrad_rows(int N, int h, int w_);
 int lf_head_wgrad(const float* x, const float* gout, float* wrows, float* brows, int N, int h, int w_, int K,
-                  hipStream_t st);
+                  int s16, hipStream_t st);

@@ -3,6 +3,7 @@
 // Reference behaviour: BEV/Networks/ERFNet.py (DownsamplerBlock :11-22, non_bottleneck_1d :44-60,
 // UpsamplerBlock :98-107, Decoder.output_conv :124), nn.BatchNorm2d(eps=1e-3), nn.Dropout2d.
 #include "lf_eltwise.h"
+#include "lf_types.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -92,22 +93,24 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(StatParts sp, int
     }
 }
 
-__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, const float* __restrict__ sc,
                                                     const float* __restrict__ sh, const float* __restrict__ dm,
-                                                    const float* __restrict__ res, float* __restrict__ y, long units,
+                                                    const T* __restrict__ res, T* __restrict__ y, long units,
                                                     int Q, long pix_per_image) {
     const int C = Q * 4;
     for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
         const int c = (int)(u % Q) * 4;
-        f32x4 v = ld4(x + u * 4) * ld4(sc + c) + ld4(sh + c);
+        f32x4 v = lf_ldv(x + u * 4) * ld4(sc + c) + ld4(sh + c);
         if (dm) v *= ld4(dm + ((u / Q) / pix_per_image) * C + c);
-        if (res) v += ld4(res + u * 4);
-        st4(y + u * 4, relu4(v));
+        if (res) v += lf_ldv(res + u * 4);
+        lf_stv(y + u * 4, relu4(v));
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
-                                                           const float* __restrict__ t, const float* __restrict__ asc,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                           const T* __restrict__ t, const float* __restrict__ asc,
                                                            const float* __restrict__ ash, const float* __restrict__ dm,
                                                            float* __restrict__ rows, long npix, int Q, long pix_per_image) {
     const int C = Q * 4, ppi = 256 / Q;
@@ -121,11 +124,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (p1 > npix) p1 = npix;
     for (long p = p0 + pr; p < p1; p += ppi) {
         const long off = p * C + c;
-        f32x4 gm = ld4(g + off);
-        if (y) gm = pos4(gm, ld4(y + off));
+        f32x4 gm = lf_ldv(g + off);
+        if (y) gm = pos4(gm, lf_ldv(y + off));
         if (dm) gm *= ld4(dm + (p / pix_per_image) * C + c);
         a1 += gm;
-        a2 += gm * (ld4(t + off) * a_sc + a_sh);
+        a2 += gm * (lf_ldv(t + off) * a_sc + a_sh);
     }
     __shared__ float sm[256][8];
     block_reduce_quads(a1, a2, Q, sm);
@@ -172,28 +175,30 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(StatParts sp, int
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
-                                                          const float* __restrict__ t, const float* __restrict__ asc,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                          const T* __restrict__ t, const float* __restrict__ asc,
                                                           const float* __restrict__ ash, const float* __restrict__ gamma,
                                                           const float* __restrict__ c1, const float* __restrict__ c2,
-                                                          const float* __restrict__ dm, float* __restrict__ g_t,
-                                                          float* __restrict__ g_z, long units, int Q, long pix_per_image) {
+                                                          const float* __restrict__ dm, T* __restrict__ g_t,
+                                                          T* __restrict__ g_z, long units, int Q, long pix_per_image) {
     const int C = Q * 4;
     for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
         const int c = (int)(u % Q) * 4;
-        f32x4 gm = ld4(g + u * 4);
-        if (y) gm = pos4(gm, ld4(y + u * 4));
-        if (g_z) st4(g_z + u * 4, gm);
+        f32x4 gm = lf_ldv(g + u * 4);
+        if (y) gm = pos4(gm, lf_ldv(y + u * 4));
+        if (g_z) lf_stv(g_z + u * 4, gm);
         if (dm) gm *= ld4(dm + ((u / Q) / pix_per_image) * C + c);
         const f32x4 rstd = ld4(asc + c);
-        const f32x4 xh = ld4(t + u * 4) * rstd + ld4(ash + c);
-        st4(g_t + u * 4, ld4(gamma + c) * rstd * (gm - ld4(c1 + c) - xh * ld4(c2 + c)));
+        const f32x4 xh = lf_ldv(t + u * 4) * rstd + ld4(ash + c);
+        lf_stv(g_t + u * 4, ld4(gamma + c) * rstd * (gm - ld4(c1 + c) - xh * ld4(c2 + c)));
     }
 }
 
 // ---- max-pool branch of DownsamplerBlock ------------------------------------------------
-__global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int Q,
-                                                             float* __restrict__ cat, int cat_pix, int choff,
+template <typename T>
+__global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int Q,
+                                                             T* __restrict__ cat, int cat_pix, int choff,
                                                              float* __restrict__ rows) {
     const int C = Q * 4, ppi = 256 / Q, Ho = H / 2, Wo = W / 2;
     const int cq = threadIdx.x % Q, pr = threadIdx.x / Q, c = cq * 4;
@@ -207,15 +212,15 @@ __global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const float* __res
         const int ow = (int)(p % Wo);
         const long r = p / Wo;
         const int oh = (int)(r % Ho), n = (int)(r / Ho);
-        const float* b = x + (((long)n * H + 2 * oh) * W + 2 * ow) * C + c;
-        f32x4 v = ld4(b);
-        f32x4 u = ld4(b + C);
+        const T* b = x + (((long)n * H + 2 * oh) * W + 2 * ow) * C + c;
+        f32x4 v = lf_ldv(b);
+        f32x4 u = lf_ldv(b + C);
         v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
-        u = ld4(b + (long)W * C);
+        u = lf_ldv(b + (long)W * C);
         v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
-        u = ld4(b + (long)W * C + C);
+        u = lf_ldv(b + (long)W * C + C);
         v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
-        st4(cat + p * cat_pix + choff + c, v);
+        lf_stv(cat + p * cat_pix + choff + c, v);
         a1 += v;
         a2 += v * v;
     }
@@ -227,8 +232,9 @@ __global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const float* __res
     }
 }
 
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gcat, int N,
-                                                      int H, int W, int Q, int cat_pix, int choff, float* __restrict__ gx) {
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gcat, int N,
+                                                      int H, int W, int Q, int cat_pix, int choff, T* __restrict__ gx) {
     const int C = Q * 4, Ho = H / 2, Wo = W / 2;
     const long units = (long)N * Ho * Wo * Q;
     for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
@@ -239,8 +245,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
         const int oh = (int)(r % Ho), n = (int)(r / Ho);
         const long base = (((long)n * H + 2 * oh) * W + 2 * ow) * C + c;
         const long o1 = C, o2 = (long)W * C, o3 = (long)W * C + C;
-        const f32x4 v0 = ld4(x + base), v1 = ld4(x + base + o1), v2 = ld4(x + base + o2), v3 = ld4(x + base + o3);
-        const f32x4 g = ld4(gcat + p * cat_pix + choff + c);
+        const f32x4 v0 = lf_ldv(x + base), v1 = lf_ldv(x + base + o1), v2 = lf_ldv(x + base + o2), v3 = lf_ldv(x + base + o3);
+        const f32x4 g = lf_ldv(gcat + p * cat_pix + choff + c);
         f32x4 r0 = z4(), r1 = z4(), r2 = z4(), r3 = z4();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {   // first maximum in window scan order wins (strict >), as ATen's max_pool2d
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
             r0[e] = arg == 0 ? g[e] : 0.f; r1[e] = arg == 1 ? g[e] : 0.f;
             r2[e] = arg == 2 ? g[e] : 0.f; r3[e] = arg == 3 ? g[e] : 0.f;
         }
-        st4(gx + base, r0); st4(gx + base + o1, r1); st4(gx + base + o2, r2); st4(gx + base + o3, r3);
+        lf_stv(gx + base, r0); lf_stv(gx + base + o1, r1); lf_stv(gx + base + o2, r2); lf_stv(gx + base + o3, r3);
     }
 }
 
@@ -260,10 +266,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 // Compile-time channel count: the 3x3xCIN patch lives in registers, the (16-CIN) x 9*CIN weights are read
 // as LDS broadcasts in a fully unrolled FMA nest (runtime loop bounds made this kernel 5x slower).
 constexpr int STEM_MAXCIN = 4;
-template <int CIN>
+template <int CIN, typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, int N, int H, int W,
                                                       const float* __restrict__ w, const float* __restrict__ b,
-                                                      float* __restrict__ cat, float* __restrict__ rows) {
+                                                      T* __restrict__ cat, float* __restrict__ rows) {
     constexpr int Cc = 16 - CIN, KK = CIN * 9;
     const int Ho = H / 2, Wo = W / 2;
     __shared__ float sw[Cc * KK + 16];
@@ -304,11 +310,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci)   // pool window = patch taps (1,1),(1,2),(2,1),(2,2)
             out[Cc + ci] = fmaxf(fmaxf(patch[ci * 9 + 4], patch[ci * 9 + 5]), fmaxf(patch[ci * 9 + 7], patch[ci * 9 + 8]));
-        float* o = cat + p * 16;
+        T* o = cat + p * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {out[q * 4], out[q * 4 + 1], out[q * 4 + 2], out[q * 4 + 3]};
-            st4(o + q * 4, v);
+            lf_stv(o + q * 4, v);
         }
     }
     if (rows) {
@@ -330,8 +336,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 
 // dW[co][ci][kh][kw] partial rows.  blockIdx.y = group of up to 4 output channels: the patch is loaded once per
 // pixel and group (4x instead of 13x), 4*9*CIN + 4 accumulators per thread.
-template <int CIN>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ gcat, int N,
+template <int CIN, typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ gcat, int N,
                                                         int H, int W, float* __restrict__ wrows, float* __restrict__ brows) {
     constexpr int Cc = 16 - CIN, KK = CIN * 9, G = 4;
     const int Ho = H / 2, Wo = W / 2, co0 = blockIdx.y * G;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         for (int j = 0; j < KK; ++j) acc[c][j] = 0.f;
     }
     for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-        const f32x4 gq = ld4(gcat + p * 16 + co0);          // channels co0..co0+3 (pool channels are never used)
+        const f32x4 gq = lf_ldv(gcat + p * 16 + co0);          // channels co0..co0+3 (pool channels are never used)
         const float gv[G] = {gq.x, gq.y, gq.z, gq.w};
         const int ow = (int)(p % Wo);
         const long r = p / Wo;
@@ -391,7 +397,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 
 // ---- head: ConvTranspose2d(16, K, 2, stride=2), weight (16,K,2,2) -------------------------
 constexpr int HEAD_MAXK = 8;
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ b, float* __restrict__ out, int N, int h,
                                                       int wd, int K) {
     __shared__ float sw[16 * HEAD_MAXK * 4 + HEAD_MAXK];
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         float xv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = ld4(x + p * 16 + q * 4);
+            const f32x4 v = lf_ldv(x + p * 16 + q * 4);
             xv[q * 4] = v.x; xv[q * 4 + 1] = v.y; xv[q * 4 + 2] = v.z; xv[q * 4 + 3] = v.w;
         }
         for (int k = 0; k < K; ++k) {
@@ -425,8 +432,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ gout, const float* __restrict__ w,
-                                                           float* __restrict__ gx, int N, int h, int wd, int K) {
+                                                           T* __restrict__ gx, int N, int h, int wd, int K) {
     __shared__ float sw[16 * HEAD_MAXK * 4];
     for (int i = threadIdx.x; i < 16 * K * 4; i += 256) sw[i] = w[i];
     __syncthreads();
@@ -451,14 +459,14 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
-            st4(gx + p * 16 + q * 4, v);
+            lf_stv(gx + p * 16 + q * 4, v);
         }
     }
 }
 
 // blockIdx.y = input-channel quad; rows[(b*16 + ci)*K*4 + k*4 + ab]
-template <int K>
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+template <int K, typename T>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ gout,
                                                         float* __restrict__ wrows, float* __restrict__ brows, int N, int h,
                                                         int wd) {
     const int cq = blockIdx.y;
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
         const int j = (int)(p % wd);
         const long r = p / wd;
         const int i = (int)(r % h), n = (int)(r / h);
-        const f32x4 xv = ld4(x + p * 16 + cq * 4);
+        const f32x4 xv = lf_ldv(x + p * 16 + cq * 4);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float* gp = gout + (((long)n * K + k) * (2 * h) + 2 * i) * (2 * wd) + 2 * j;
@@ -522,6 +530,10 @@ inline int grid_for(long units, int cap) {
     return (int)g;
 }
 inline bool quad_ok(int C) { return C % 4 == 0 && 256 % (C / 4) == 0; }
+// activation pointers travel as float* through the host code; s16 says they hold bf16 elements
+template <typename T> inline const T* as(const float* p) { return reinterpret_cast<const T*>(p); }
+template <typename T> inline T* as(float* p) { return reinterpret_cast<T*>(p); }
+#define LF_BY_STORAGE(s16, CALL_BF16, CALL_F32) do { if (s16) { CALL_BF16; } else { CALL_F32; } } while (0)
 
 }  // namespace
 
@@ -539,11 +551,13 @@ int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count,
 }
 
 int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm, const float* res, float* y, long npix,
-              int C, long pix_per_image, hipStream_t st) {
+              int C, long pix_per_image, int s16, hipStream_t st) {
     LF_REQUIRE(C % 4 == 0, "bn_act: C %% 4");
     const long units = npix * (C / 4);
-    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(units, 4096)), dim3(256), 0, st, x, sc, sh, dm, res, y, units, C / 4,
-                       pix_per_image);
+    const dim3 grid(grid_for(units, 4096));
+    LF_BY_STORAGE(s16,
+        hipLaunchKernelGGL(bn_act_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(x), sc, sh, dm, as<lf_bf16>(res), as<lf_bf16>(y), units, C / 4, pix_per_image),
+        hipLaunchKernelGGL(bn_act_kernel<float>, grid, dim3(256), 0, st, x, sc, sh, dm, res, y, units, C / 4, pix_per_image));
     LF_CHECK_LAUNCH("bn_act");
     return 0;
 }
@@ -551,10 +565,12 @@ int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm,
 int lf_bn_bwd_reduce_rows(long npix) { return grid_for(npix * 4, 1024); }
 
 int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* dm,
-                     float* rows, long npix, int C, long pix_per_image, hipStream_t st) {
+                     float* rows, long npix, int C, long pix_per_image, int s16, hipStream_t st) {
     LF_REQUIRE(quad_ok(C), "bn_bwd_reduce: unsupported channel count %d", C);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(lf_bn_bwd_reduce_rows(npix)), dim3(256), 0, st, g, y, t, asc, ash, dm, rows,
-                       npix, C / 4, pix_per_image);
+    const dim3 grid(lf_bn_bwd_reduce_rows(npix));
+    LF_BY_STORAGE(s16,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, dm, rows, npix, C / 4, pix_per_image),
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, g, y, t, asc, ash, dm, rows, npix, C / 4, pix_per_image));
     LF_CHECK_LAUNCH("bn_bwd_reduce");
     return 0;
 }
@@ -572,11 +588,13 @@ int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count,
 
 int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* gamma,
                     const float* c1, const float* c2, const float* dm, float* g_t, float* g_z, long npix, int C,
-                    long pix_per_image, hipStream_t st) {
+                    long pix_per_image, int s16, hipStream_t st) {
     LF_REQUIRE(C % 4 == 0, "bn_bwd_apply: C %% 4");
     const long units = npix * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(units, 4096)), dim3(256), 0, st, g, y, t, asc, ash, gamma, c1, c2,
-                       dm, g_t, g_z, units, C / 4, pix_per_image);
+    const dim3 grid(grid_for(units, 4096));
+    LF_BY_STORAGE(s16,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, gamma, c1, c2, dm, as<lf_bf16>(g_t), as<lf_bf16>(g_z), units, C / 4, pix_per_image),
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, g, y, t, asc, ash, gamma, c1, c2, dm, g_t, g_z, units, C / 4, pix_per_image));
     LF_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
 }
@@ -584,20 +602,24 @@ int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float*
 int lf_pool_rows(long npix_out) { return grid_for(npix_out * 4, 1024); }
 
 int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat, int cat_pix, int choff, float* rows,
-                       hipStream_t st) {
+                       int s16, hipStream_t st) {
     LF_REQUIRE(quad_ok(Cin) && H % 2 == 0 && W % 2 == 0, "pool_concat: unsupported shape");
     const long npo = (long)N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(pool_concat_fwd_kernel, dim3(lf_pool_rows(npo)), dim3(256), 0, st, x, N, H, W, Cin / 4, cat, cat_pix,
-                       choff, rows);
+    const dim3 grid(lf_pool_rows(npo));
+    LF_BY_STORAGE(s16,
+        hipLaunchKernelGGL(pool_concat_fwd_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(x), N, H, W, Cin / 4, as<lf_bf16>(cat), cat_pix, choff, rows),
+        hipLaunchKernelGGL(pool_concat_fwd_kernel<float>, grid, dim3(256), 0, st, x, N, H, W, Cin / 4, cat, cat_pix, choff, rows));
     LF_CHECK_LAUNCH("pool_concat_fwd");
     return 0;
 }
 
 int lf_pool_bwd(const float* x, const float* gcat, int N, int H, int W, int Cin, int cat_pix, int choff, float* gx,
-                hipStream_t st) {
+                int s16, hipStream_t st) {
     const long units = (long)N * (H / 2) * (W / 2) * (Cin / 4);
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(units, 4096)), dim3(256), 0, st, x, gcat, N, H, W, Cin / 4, cat_pix,
-                       choff, gx);
+    const dim3 grid(grid_for(units, 4096));
+    LF_BY_STORAGE(s16,
+        hipLaunchKernelGGL(pool_bwd_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(x), as<lf_bf16>(gcat), N, H, W, Cin / 4, cat_pix, choff, as<lf_bf16>(gx)),
+        hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, st, x, gcat, N, H, W, Cin / 4, cat_pix, choff, gx));
     LF_CHECK_LAUNCH("pool_bwd");
     return 0;
 }
@@ -605,15 +627,19 @@ int lf_pool_bwd(const float* x, const float* gcat, int N, int H, int W, int Cin,
 int lf_stem_rows(int N, int H, int W) { return lf_cdiv((long)N * (H / 2) * (W / 2), 256); }
 
 int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, const float* b, float* cat, float* rows,
-                hipStream_t st) {
+                int s16, hipStream_t st) {
     LF_REQUIRE(Cin >= 1 && Cin <= STEM_MAXCIN, "stem: in_channels %d not in 1..%d", Cin, STEM_MAXCIN);
     LF_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: odd image size");
     const dim3 grid(lf_stem_rows(N, H, W));
     switch (Cin) {
-        case 1: hipLaunchKernelGGL(stem_fwd_kernel<1>, grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows); break;
-        case 2: hipLaunchKernelGGL(stem_fwd_kernel<2>, grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows); break;
-        case 3: hipLaunchKernelGGL(stem_fwd_kernel<3>, grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows); break;
-        default: hipLaunchKernelGGL(stem_fwd_kernel<4>, grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows); break;
+        case 1: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_fwd_kernel<1, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows),
+                                   hipLaunchKernelGGL((stem_fwd_kernel<1, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows)); break;
+        case 2: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_fwd_kernel<2, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows),
+                                   hipLaunchKernelGGL((stem_fwd_kernel<2, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows)); break;
+        case 3: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_fwd_kernel<3, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows),
+                                   hipLaunchKernelGGL((stem_fwd_kernel<3, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows)); break;
+        default: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_fwd_kernel<4, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows),
+                                   hipLaunchKernelGGL((stem_fwd_kernel<4, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows)); break;
     }
     LF_CHECK_LAUNCH("stem_fwd");
     return 0;
@@ -622,28 +648,39 @@ int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, 
 int lf_stem_wgrad_rows(int N, int H, int W) { return grid_for((long)N * (H / 2) * (W / 2), 256); }
 
 int lf_stem_wgrad(const float* img, const float* gcat, int N, int Cin, int H, int W, float* wrows, float* brows,
-                  hipStream_t st) {
+                  int s16, hipStream_t st) {
     const dim3 grid(lf_stem_wgrad_rows(N, H, W), (16 - Cin + 3) / 4);
     switch (Cin) {
-        case 1: hipLaunchKernelGGL(stem_wgrad_kernel<1>, grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows); break;
-        case 2: hipLaunchKernelGGL(stem_wgrad_kernel<2>, grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows); break;
-        case 3: hipLaunchKernelGGL(stem_wgrad_kernel<3>, grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows); break;
-        default: hipLaunchKernelGGL(stem_wgrad_kernel<4>, grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows); break;
+        case 1: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_wgrad_kernel<1, lf_bf16>), grid, dim3(256), 0, st, img, as<lf_bf16>(gcat), N, H, W, wrows, brows),
+                                   hipLaunchKernelGGL((stem_wgrad_kernel<1, float>), grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows)); break;
+        case 2: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_wgrad_kernel<2, lf_bf16>), grid, dim3(256), 0, st, img, as<lf_bf16>(gcat), N, H, W, wrows, brows),
+                                   hipLaunchKernelGGL((stem_wgrad_kernel<2, float>), grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows)); break;
+        case 3: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_wgrad_kernel<3, lf_bf16>), grid, dim3(256), 0, st, img, as<lf_bf16>(gcat), N, H, W, wrows, brows),
+                                   hipLaunchKernelGGL((stem_wgrad_kernel<3, float>), grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows)); break;
+        default: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_wgrad_kernel<4, lf_bf16>), grid, dim3(256), 0, st, img, as<lf_bf16>(gcat), N, H, W, wrows, brows),
+                                   hipLaunchKernelGGL((stem_wgrad_kernel<4, float>), grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows)); break;
     }
     LF_CHECK_LAUNCH("stem_wgrad");
     return 0;
 }
 
-int lf_head_fwd(const float* x, const float* w, const float* b, float* out, int N, int h, int w_, int K, hipStream_t st) {
+int lf_head_fwd(const float* x, const float* w, const float* b, float* out, int N, int h, int w_, int K, int s16,
+                hipStream_t st) {
     LF_REQUIRE(K >= 1 && K <= HEAD_MAXK, "head: out_channels %d not in 1..%d", K, HEAD_MAXK);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for((long)N * h * w_, 4096)), dim3(256), 0, st, x, w, b, out, N, h, w_, K);
+    const dim3 grid(grid_for((long)N * h * w_, 4096));
+    LF_BY_STORAGE(s16,
+        hipLaunchKernelGGL(head_fwd_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(x), w, b, out, N, h, w_, K),
+        hipLaunchKernelGGL(head_fwd_kernel<float>, grid, dim3(256), 0, st, x, w, b, out, N, h, w_, K));
     LF_CHECK_LAUNCH("head_fwd");
     return 0;
 }
 
-int lf_head_bwd_data(const float* gout, const float* w, float* gx, int N, int h, int w_, int K, hipStream_t st) {
+int lf_head_bwd_data(const float* gout, const float* w, float* gx, int N, int h, int w_, int K, int s16, hipStream_t st) {
     LF_REQUIRE(K >= 1 && K <= HEAD_MAXK, "head: out_channels %d not in 1..%d", K, HEAD_MAXK);
-    hipLaunchKernelGGL(head_bwd_data_kernel, dim3(grid_for((long)N * h * w_, 4096)), dim3(256), 0, st, gout, w, gx, N, h, w_, K);
+    const dim3 grid(grid_for((long)N * h * w_, 4096));
+    LF_BY_STORAGE(s16,
+        hipLaunchKernelGGL(head_bwd_data_kernel<lf_bf16>, grid, dim3(256), 0, st, gout, w, as<lf_bf16>(gx), N, h, w_, K),
+        hipLaunchKernelGGL(head_bwd_data_kernel<float>, grid, dim3(256), 0, st, gout, w, gx, N, h, w_, K));
     LF_CHECK_LAUNCH("head_bwd_data");
     return 0;
 }
@@ -651,9 +688,10 @@ int lf_head_bwd_data(const float* gout, const float* w, float* gx, int N, int h,
 int lf_head_wgrad_rows(int N, int h, int w_) { return grid_for((long)N * h * w_, 512); }
 
 int lf_head_wgrad(const float* x, const float* gout, float* wrows, float* brows, int N, int h, int w_, int K,
-                  hipStream_t st) {
+                  int s16, hipStream_t st) {
     dim3 grid(lf_head_wgrad_rows(N, h, w_), 4);
-#define LF_HW(KK) hipLaunchKernelGGL(head_wgrad_kernel<KK>, grid, dim3(256), 0, st, x, gout, wrows, brows, N, h, w_)
+#define LF_HW(KK) LF_BY_STORAGE(s16, hipLaunchKernelGGL((head_wgrad_kernel<KK, lf_bf16>), grid, dim3(256), 0, st, as<lf_bf16>(x), gout, wrows, brows, N, h, w_), \
+                                hipLaunchKernelGGL((head_wgrad_kernel<KK, float>), grid, dim3(256), 0, st, x, gout, wrows, brows, N, h, w_))
     switch (K) {
         case 1: LF_HW(1); break;
         case 2: LF_HW(2); break;

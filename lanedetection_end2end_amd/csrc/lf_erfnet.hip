@@ -308,10 +308,13 @@ void lf_erfnet_plan_destroy(lf_erfnet_plan* P) {
 }
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)P->total_floats * sizeof(float); }
 // Matrix-core precision of the convolutions and their data gradients: 0 = fp32 MFMA (default, the parity
-// path), 1 = operands rounded to bf16 in registers (v_mfma_f32_16x16x32_bf16), fp32 accumulation, fp32 tensors.
+// path), 1 = operands rounded to bf16 in registers (v_mfma_f32_16x16x32_bf16), fp32 accumulation, fp32 tensors,
+// 2 = mode 1 + every activation / gradient tensor of the backbone stored as bf16 (half the HBM traffic; the
+// weight gradient widens its bf16 operands and stays on the fp32 matrix cores; parameters, parameter gradients,
+// BatchNorm statistics and the logits stay fp32).
 // Set before a forward; the matching backward must run with the same setting.
 int lf_erfnet_set_precision(const lf_erfnet_plan* P, int mode) {
-    LF_REQUIRE(P && (mode == 0 || mode == 1), "lf_erfnet_set_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+    LF_REQUIRE(P && mode >= 0 && mode <= 2, "lf_erfnet_set_precision: mode must be 0 (fp32), 1 (bf16 operands) or 2 (bf16 tensors)");
     P->precision = mode;
     return 0;
 }
@@ -354,6 +357,7 @@ struct Ctx {
     int training;
     hipStream_t st;
     const float* g_enc = nullptr;    // backward: extra gradient w.r.t. the encoder output (NHWC) or null
+    int s16 = 0;                     // precision mode 2: activation / gradient tensors hold bf16 elements
     hipStream_t side = nullptr;          // null: everything on st
     mutable unsigned side_reads = 0;     // gradient buffers (bit 0 gA, 1 gB, 2 gC) an in-flight side-stream kernel reads
     // side stream may start once everything enqueued on the main stream so far has finished
@@ -395,7 +399,8 @@ struct ProfScope {   // records a HIP event pair on the launch stream around one
 int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const float* bias, int pro, int epi,
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
-    if (c.P->precision == 1)
+    extra.s16 = c.s16;
+    if (c.P->precision >= 1)
         extra.wp16 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed16) + c.P->packs[op.pack].dst16_off;
     ProfScope ps(c, 0, op.geom, epi | (pro << 8), c.st);
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
@@ -421,7 +426,7 @@ int forward_layers(const Ctx& c, const float* img) {
             int np = 0;
             if (L.x < 0) {
                 LF_TRY(lf_stem_fwd(img, N, L.Cin, L.Hin, L.Win, c.params[L.cv[0].p_w], c.params[L.cv[0].p_b], c.at(L.b[0]),
-                                   c.training ? stat0 : nullptr, c.st));
+                                   c.training ? stat0 : nullptr, c.s16, c.st));
                 parts[np++] = {stat0, lf_stem_rows(N, L.Hin, L.Win), 16, 0};
             } else {
                 LfTapArgs a = lf_no_args();
@@ -430,12 +435,12 @@ int forward_layers(const Ctx& c, const float* img) {
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
                 parts[np++] = {stat0, lf_tapgemm_stat_rows(L.cv[0].fwd.geom), L.Cout - L.Cin, 0};
                 LF_TRY(lf_pool_concat_fwd(c.at(L.x), N, L.Hin, L.Win, L.Cin, c.at(L.b[0]), L.Cout, L.Cout - L.Cin,
-                                          c.training ? stat1 : nullptr, c.st));
+                                          c.training ? stat1 : nullptr, c.s16, c.st));
                 parts[np++] = {stat1, lf_pool_rows(npo), L.Cin, L.Cout - L.Cin};
             }
             LF_TRY(bn_finalize(c, L.bn[0], parts, np, (double)npo));
             LF_TRY(lf_bn_act(c.at(L.b[0]), c.at(L.bn[0].sc), c.at(L.bn[0].sh), nullptr, nullptr, c.at(L.b[1]), npo, L.Cout,
-                             (long)L.Hout * L.Wout, c.st));
+                             (long)L.Hout * L.Wout, c.s16, c.st));
         } else if (L.kind == K_NB) {
             const int srows = lf_tapgemm_stat_rows(L.cv[0].fwd.geom);
             LfTapArgs a = lf_no_args();
@@ -455,7 +460,7 @@ int forward_layers(const Ctx& c, const float* img) {
             LF_TRY(bn_finalize(c, L.bn[1], &p0, 1, (double)npo));
             const float* dm = (c.training && L.drop_idx >= 0 && c.dropmask) ? c.dropmask + P->drop_off[L.drop_idx] : nullptr;
             LF_TRY(lf_bn_act(c.at(L.b[3]), c.at(L.bn[1].sc), c.at(L.bn[1].sh), dm, c.at(L.x), c.at(L.b[4]), npo, L.Cout,
-                             (long)L.Hout * L.Wout, c.st));
+                             (long)L.Hout * L.Wout, c.s16, c.st));
         } else {
             LfStatPart parts[1];
             // the 4 sub-pixel phases write disjoint pixels of c; their stat rows are laid end to end
@@ -470,7 +475,7 @@ int forward_layers(const Ctx& c, const float* img) {
             parts[0] = {stat0, rows, L.Cout, 0};
             LF_TRY(bn_finalize(c, L.bn[0], parts, 1, (double)npo));
             LF_TRY(lf_bn_act(c.at(L.b[0]), c.at(L.bn[0].sc), c.at(L.bn[0].sh), nullptr, nullptr, c.at(L.b[1]), npo, L.Cout,
-                             (long)L.Hout * L.Wout, c.st));
+                             (long)L.Hout * L.Wout, c.s16, c.st));
         }
     }
     return 0;
@@ -486,7 +491,7 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     c.fork();
     c.side_reads |= gbuf;
     LfWgradArgs a;
-    a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh;
+    a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh; a.s16 = c.s16;
     a.partial = c.at(P->off_wpart);
     a.bias_partial = c.grads[cv.p_b] ? c.at(P->off_bpart) : nullptr;
     {
@@ -564,12 +569,12 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         // ---- last BatchNorm (+dropout +residual) + ReLU backward: g_pre -> X ; g_z (masked incoming gradient)
         const float* gz;
         if (!prepped) {
-            LF_TRY(lf_bn_bwd_reduce(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), dm, stat0, npo, L.Cout, ppi, c.st));
+            LF_TRY(lf_bn_bwd_reduce(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), dm, stat0, npo, L.Cout, ppi, c.s16, c.st));
             LfStatPart rp = {stat0, lf_bn_bwd_reduce_rows(npo), L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, blast, &rp, 1, (double)npo));
             c.before_write(bit(X) | bit(Y));
             LF_TRY(lf_bn_bwd_apply(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), c.params[blast.p_g], c.at(blast.c1),
-                                   c.at(blast.c2), dm, X, L.kind == K_NB ? Y : nullptr, npo, L.Cout, ppi, c.st));
+                                   c.at(blast.c2), dm, X, L.kind == K_NB ? Y : nullptr, npo, L.Cout, ppi, c.s16, c.st));
             gz = Y;
             // `in` is free from here on
         } else {
@@ -577,7 +582,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             LF_TRY(bn_bwd_finalize(c, blast, &rp, 1, (double)npo));
             c.before_write(bit(X));
             LF_TRY(lf_bn_bwd_apply(in, nullptr, prelast, c.at(blast.asc), c.at(blast.ash), c.params[blast.p_g], c.at(blast.c1),
-                                   c.at(blast.c2), dm, X, nullptr, npo, L.Cout, ppi, c.st));
+                                   c.at(blast.c2), dm, X, nullptr, npo, L.Cout, ppi, c.s16, c.st));
             gz = in;
             // Y is free; `in` must survive until the residual add
         }
@@ -605,7 +610,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             LF_TRY(bn_bwd_finalize(c, b1, &sp, 1, (double)npo));
             c.before_write(bit(F));
             LF_TRY(lf_bn_bwd_apply(X, nullptr, t2, c.at(b1.asc), c.at(b1.ash), c.params[b1.p_g], c.at(b1.c1), c.at(b1.c2),
-                                   nullptr, F /*g_t2*/, nullptr, npo, L.Cout, ppi, c.st));
+                                   nullptr, F /*g_t2*/, nullptr, npo, L.Cout, ppi, c.s16, c.st));
             // conv1x3_1: g_t1 -> X
             LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, F, nullptr, nullptr, 0, bit(F)));
             a = lf_no_args();
@@ -641,7 +646,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             c.join();
             const int Cc = 16 - L.Cin, rows = lf_stem_wgrad_rows(N, L.Hin, L.Win);
             if (c.grads[L.cv[0].p_w]) {
-                LF_TRY(lf_stem_wgrad(img, X, N, L.Cin, L.Hin, L.Win, c.at(P->off_wpart), c.at(P->off_bpart), c.st));
+                LF_TRY(lf_stem_wgrad(img, X, N, L.Cin, L.Hin, L.Win, c.at(P->off_wpart), c.at(P->off_bpart), c.s16, c.st));
                 LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, Cc * L.Cin * 9, c.grads[L.cv[0].p_w], 0, c.st));
                 if (c.grads[L.cv[0].p_b])
                     LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, Cc, c.grads[L.cv[0].p_b], 0, c.st));
@@ -650,7 +655,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         } else {
             LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], c.at(L.x), X, nullptr, nullptr, 0, bit(X)));
             c.before_write(bit(F));
-            LF_TRY(lf_pool_bwd(c.at(L.x), X, N, L.Hin, L.Win, L.Cin, L.Cout, L.Cout - L.Cin, F, c.st));
+            LF_TRY(lf_pool_bwd(c.at(L.x), X, N, L.Hin, L.Win, L.Cin, L.Cout, L.Cout - L.Cin, F, c.s16, c.st));
             for (int ph = 0; ph < 4; ++ph) {
                 LfTapArgs a = lf_no_args();
                 a.add_src = F;
@@ -669,7 +674,7 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
     if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
         return lf_fail("erfnet: upload of the pack table failed");
     LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
-    if (P->precision == 1)
+    if (P->precision >= 1)
         LF_TRY(lf_pack_weights_bf16_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed16), c.st));
     return 0;
 }
@@ -691,10 +696,11 @@ int lf_erfnet_forward(const lf_erfnet_plan* P, const float* img, const float* co
     LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_forward: workspace too small");
     LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_forward: head %d out of range", head);
     Ctx c{P, (float*)workspace, params_host, nullptr, running_host, dropmask, training, (hipStream_t)stream};
+    c.s16 = P->precision == 2;
     LF_TRY(upload_and_pack(c, params_dev));
     LF_TRY(forward_layers(c, img));
     return lf_head_fwd(c.at(P->head_in), params_host[P->p_head_w[head]], params_host[P->p_head_b[head]], logits, P->N, P->H / 2,
-                       P->W / 2, P->Cout + head, c.st);   // output_conv2 has one more channel (ERFNet.py:125-126)
+                       P->W / 2, P->Cout + head, c.s16, c.st);   // output_conv2 has one more channel (ERFNet.py:125-126)
 }
 
 // Backward of the forward that last used `workspace`.  grad_logits (N,Cout,H,W) NCHW; grad_encoder: optional
@@ -709,6 +715,8 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
     LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_backward: head %d out of range", head);
     Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, 1, (hipStream_t)stream};
     c.g_enc = grad_encoder;
+    c.s16 = P->precision == 2;
+    LF_REQUIRE(!(c.s16 && grad_encoder), "lf_erfnet_backward: grad_encoder is not supported with bf16 tensors (mode 2)");
     // Measured on MI355X (batch 32): running the weight gradients concurrently with the data gradients is
     // ~5 % SLOWER than one stream (two 2-waves/SIMD kernels evict each other's L2 working set), so the side
     // stream is opt-in.
@@ -726,11 +734,11 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
     const int pw = P->p_head_w[head], pb = P->p_head_b[head];
     if (grads_host[pw]) {
         const int rows = lf_head_wgrad_rows(P->N, h, w);
-        LF_TRY(lf_head_wgrad(c.at(P->head_in), grad_logits, c.at(P->off_wpart), c.at(P->off_bpart), P->N, h, w, K, c.st));
+        LF_TRY(lf_head_wgrad(c.at(P->head_in), grad_logits, c.at(P->off_wpart), c.at(P->off_bpart), P->N, h, w, K, c.s16, c.st));
         LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, 16 * K * 4, grads_host[pw], 0, c.st));
         if (grads_host[pb]) LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, K, grads_host[pb], 0, c.st));
     }
-    LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.st));
+    LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.s16, c.st));
     LF_TRY(backward_layers(c, img, gA, gB, gC));
     c.join();          // every gradient is complete once the caller's stream reaches this point
     return 0;

@@ -44,6 +44,7 @@ void pack_conv1d(LfTapArgs& a, const float* w, float* scratch, int C, long sk, l
     if (g_ops_bf16) {
         hipLaunchKernelGGL(pack_one_bf16_kernel, dim3(64), dim3(256), 0, st, w, reinterpret_cast<__bf16*>(scratch), C, C, 3, sk, sn, flip);
         a.wp16 = scratch;
+        a.s16 = g_ops_bf16 == 2;
     } else {
         hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, sk, sn, flip);
     }
@@ -64,8 +65,9 @@ LfTapGeom conv1d_geom(int N, int H, int W, int C, int axis, int d) {
 extern "C" {
 
 void lf_debug_set_tapgemm_variant(int v) { lf_tapgemm_set_variant(v); }
-// 1: the kernel-level conv1d forward / data-gradient calls below use the bf16 matrix-core kernel (tests, kbench)
-void lf_debug_set_ops_precision(int bf16) { g_ops_bf16 = bf16; }
+// precision mode of the kernel-level conv1d calls below (tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32 tensors,
+// 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src then hold bf16 elements; w, bias, gw, gb stay fp32)
+void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = mode; }
 
 // same as lf_conv1d_fwd with per-wave phase timestamps: dbg receives 8 uint64 per wave
 // (start, tap table built, main loop done, stores retired); waves = ceil(N*H*W/256)*4*(C/64)
@@ -121,7 +123,7 @@ int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, 
     hipStream_t st = (hipStream_t)stream;
     const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
     LfWgradArgs a;
-    a.x = x; a.g = gy; a.pro_sc = nullptr; a.pro_sh = nullptr;
+    a.x = x; a.g = gy; a.pro_sc = nullptr; a.pro_sh = nullptr; a.s16 = g_ops_bf16 == 2;
     a.partial = scratch;
     a.bias_partial = gb ? scratch + (long)lf_tapwgrad_splits(g) * 3 * C * C : nullptr;
     int rc = lf_tapwgrad_launch(g, a, LF_PRO_NONE, st);

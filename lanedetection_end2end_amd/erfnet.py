@@ -118,6 +118,10 @@ def _ptr_array(tensors):
     return arr
 
 
+# lf_erfnet_set_precision modes (include/lanefit.h)
+_PRECISIONS = {"fp32": 0, "bf16_mfma": 1, "bf16": 2}
+
+
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, plan, x, head, training, dropmask, *params):
@@ -131,14 +135,19 @@ class _BackboneFn(torch.autograd.Function):
             assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
         host = _ptr_array(params)
         devarr = net._device_ptr_table(params)
-        ctx.precision = 1 if net.precision == "bf16" else 0
+        ctx.precision = _PRECISIONS[net.precision]
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         running = _ptr_array(net._running_buffers())
         _lib.check(lib.lf_erfnet_forward(plan.handle, _lib.ptr(x), host, _lib.ptr(devarr), running,
                                          _lib.ptr(dropmask), int(training), head, _lib.ptr(logits), _lib.ptr(ws),
                                          plan.ws_bytes, _lib.stream()), "lf_erfnet_forward")
         ctx.set_materialize_grads(False)
-        if net.export_encoder_output:
+        if net.export_encoder_output and ctx.precision == 2:
+            # bf16 tensors: the in-place view is bf16 and takes no gradient (the --clas heads are an fp32 path)
+            nenc = N * (H // 8) * (W // 8) * 128
+            enc = ws[4 * plan.enc_off: 4 * plan.enc_off + 2 * nenc].view(torch.bfloat16).view(N, H // 8, W // 8, 128)
+            ctx.mark_non_differentiable(enc)
+        elif net.export_encoder_output:
             # the encoder output is handed out IN PLACE: an NHWC view of the workspace (no copy, no transpose);
             # Net.forward permutes it to the reference's logical (N,128,H/8,W/8)
             nenc = N * (H // 8) * (W // 8) * 128
@@ -202,8 +211,10 @@ class Net(nn.Module):
         self._plans = {}
         self._ptr_cache = (None, None)
         self._flat_grad = None
-        # matrix-core precision of the convolutions: "fp32" (default, the parity path) or "bf16" (operands rounded
-        # to bf16 in registers, fp32 accumulation and storage; BASELINE config 3 -- the reference has no such mode)
+        # precision mode: "fp32" (default, the parity path); "bf16_mfma" (conv operands rounded to bf16 in registers,
+        # fp32 accumulation, fp32 tensors); "bf16" (bf16 matrix cores AND bf16 activation / gradient tensors in HBM;
+        # BASELINE config 3 -- the reference has no such mode).  Parameters, their gradients and the logits are fp32
+        # in every mode.
         self.precision = "fp32"
         # encoder_output (N,128,H/8,W/8) is part of the return tuple (zero-copy view); wrappers that never read it
         # may switch it off
