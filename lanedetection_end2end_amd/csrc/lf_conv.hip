@@ -738,7 +738,12 @@ __device__ __forceinline__ float wg_ld1(const float* base, unsigned off) {
     else return base[off];
 }
 
-template <bool XV, bool GV, int XT, int GT, int U, bool S16>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// BFM (bf16 tensors, 64-channel blocks on both sides): the four K=4 fp32 MFMAs of an iteration's four pixel
+// sub-steps become ONE v_mfma_f32_16x16x16_bf16 per tile -- a lane's four pixels (p+kq, +4, +8, +12) are exactly its
+// four k of the K=16 step -- with the operands assembled from the raw 8-byte loads by v_perm_b32 (no widening).
+template <bool XV, bool GV, int XT, int GT, int U, bool S16, bool BFM = false>
 __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
                                                       const long pps, const int write_bias, const int gxs) {
     constexpr int XTiles = XV ? 4 : XT, GTiles = GV ? 4 : GT;
@@ -800,7 +805,9 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     // Wl % (4U) == 0 and pps % (4U) == 0), so a single (n,i,j) -> address computation serves U loads per
     // operand.  Loads are unconditional (clamped address, masked at use) and double-buffered in two named
     // register sets: the next iteration's 2U loads are in flight during the current 16*U MFMAs.
+    static_assert(!BFM || (S16 && XV && GV && U == 4), "BFM needs bf16 tensors, vector mode, U = 4");
     struct WStep {
+        uint2 xr[BFM ? U : 1], gr[BFM ? U : 1];             // BFM: raw bf16 quads
         f32x4 x4[XV ? U : 1], g4[GV ? U : 1];
         float xs[XV ? 1 : U][XTiles], gs[GV ? 1 : U][GTiles];
         unsigned vmask, xmask;
@@ -821,7 +828,8 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
             const bool v = rowv && (p + 4 * u) < p_end;
             vm |= (v ? 1u : 0u) << u;
             const unsigned go = v ? gofs + u * gstep : gofs;
-            if constexpr (GV) S.g4[u] = wg_ld4<S16>(a.g, go);
+            if constexpr (BFM) S.gr[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const lf_bf16*>(a.g) + go);
+            else if constexpr (GV) S.g4[u] = wg_ld4<S16>(a.g, go);
             else {
 #pragma unroll
                 for (int q = 0; q < GTiles; ++q) S.gs[u][q] = wg_ld1<S16>(a.g, go + q * 16);
@@ -830,7 +838,8 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
             const bool xin = v && yin && sx >= 0 && sx < g.Ws;
             xm |= (xin ? 1u : 0u) << u;
             const unsigned xo = xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix);
-            if constexpr (XV) S.x4[u] = wg_ld4<S16>(a.x, xo);
+            if constexpr (BFM) S.xr[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const lf_bf16*>(a.x) + xo);
+            else if constexpr (XV) S.x4[u] = wg_ld4<S16>(a.x, xo);
             else {
 #pragma unroll
                 for (int r = 0; r < XTiles; ++r) S.xs[u][r] = wg_ld1<S16>(a.x, xo + r * 16);
@@ -843,7 +852,56 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
         pj += 4 * U;
         if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
     };
+    const bool need_bias = write_bias && a.bias_partial && t == 0 && cib == 0;      // workgroup-uniform
     auto compute = [&](const WStep& S) {
+        if constexpr (BFM) {
+            uint2 xq[U], gq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool v = (S.vmask >> u) & 1u, xin = (S.xmask >> u) & 1u;
+                uint2 xx = S.xr[u], gg = S.gr[u];
+                if (pro == LF_PRO_BNRELU) {          // relu(bn(x)) in fp32 on the widened quad, rounded back
+                    f32x4 t4;
+                    t4.x = __uint_as_float(xx.x << 16); t4.y = __uint_as_float(xx.x & 0xffff0000u);
+                    t4.z = __uint_as_float(xx.y << 16); t4.w = __uint_as_float(xx.y & 0xffff0000u);
+                    t4 = max0(t4 * psc + psh);
+                    lf_bf16x4 b;
+                    b[0] = (lf_bf16)t4.x; b[1] = (lf_bf16)t4.y; b[2] = (lf_bf16)t4.z; b[3] = (lf_bf16)t4.w;
+                    xx = __builtin_bit_cast(uint2, b);
+                }
+                xq[u].x = xin ? xx.x : 0u; xq[u].y = xin ? xx.y : 0u;
+                gq[u].x = v ? gg.x : 0u; gq[u].y = v ? gg.y : 0u;
+            }
+            // tile e of the x side = channels {4*row + e}: element e of every pixel's quad -> k = 4*kq + u
+            s16x4 xa[4], gb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                uint2 ax, bx;
+                if (e < 2) {
+                    ax.x = __builtin_amdgcn_perm(xq[1].x, xq[0].x, sel); ax.y = __builtin_amdgcn_perm(xq[3].x, xq[2].x, sel);
+                    bx.x = __builtin_amdgcn_perm(gq[1].x, gq[0].x, sel); bx.y = __builtin_amdgcn_perm(gq[3].x, gq[2].x, sel);
+                } else {
+                    ax.x = __builtin_amdgcn_perm(xq[1].y, xq[0].y, sel); ax.y = __builtin_amdgcn_perm(xq[3].y, xq[2].y, sel);
+                    bx.x = __builtin_amdgcn_perm(gq[1].y, gq[0].y, sel); bx.y = __builtin_amdgcn_perm(gq[3].y, gq[2].y, sel);
+                }
+                xa[e] = __builtin_bit_cast(s16x4, ax);
+                gb[e] = __builtin_bit_cast(s16x4, bx);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa[r], gb[q], acc[r][q], 0, 0, 0);
+            if (need_bias) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    bsum[0] += __uint_as_float(gq[u].x << 16); bsum[1] += __uint_as_float(gq[u].x & 0xffff0000u);
+                    bsum[2] += __uint_as_float(gq[u].y << 16); bsum[3] += __uint_as_float(gq[u].y & 0xffff0000u);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float xv[XTiles], gv[GTiles];
@@ -1088,7 +1146,8 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
     dim3 grid(c.gx * g.ntaps * (g.Cs / xb) * (g.Cd / gb));
 #define LF_WG(XV, GV, XT, GT)                                                                                     \
     do {                                                                                                          \
-        if (a.s16 && c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
+        if (a.s16 && c.u == 4 && XV && GV && !getenv("LF_WGRAD_FP32")) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true, (XV && GV)>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
+        else if (a.s16 && c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
         else if (a.s16) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);   \
         else if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, false>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
         else hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1, false>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);  \
