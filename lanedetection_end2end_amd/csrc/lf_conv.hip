@@ -58,41 +58,43 @@ __device__ __forceinline__ float sum16(float v) {
 }
 
 #define LF_TAPGEMM_EPILOGUE \
+    /* Pixel-tile outer, channel-tile inner: the NT loads of one operand tensor issued back to back cover one pixel's  \
+     * contiguous NT*16-channel run, so every cache line is touched once while it is hot (the channel-tile-outer order \
+     * revisited each line NT times with the whole grid's working set in between: 4x the HBM reads with bf16 tensors). */ \
     const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0; \
-    f32x4 s1[NT], s2[NT]; \
-_Pragma("unroll") \
-    for (int n = 0; n < NT; ++n) { s1[n] = zero4(); s2[n] = zero4(); } \
+    f32x4 s1[NT], s2[NT], bs[NT]; \
 _Pragma("unroll") \
     for (int n = 0; n < NT; ++n) { \
         const int co = cob + n * 16 + kq * 4; \
-        const f32x4 b = a.bias ? ldg4(a.bias + co) : zero4(); \
-        f32x4 msc, msh, asc, ash; \
-        if (epi & LF_EPI_MASKBN) { msc = ldg4(a.msc + co); msh = ldg4(a.msh + co); } \
-        if (epi & LF_EPI_STATS_XHAT) { asc = ldg4(a.asc + co); ash = ldg4(a.ash + co); } \
-        long doff[MT]; \
-        f32x4 la[MT], lm[MT], lx[MT], ld[MT]; \
+        s1[n] = zero4(); s2[n] = zero4(); \
+        bs[n] = a.bias ? ldg4(a.bias + co) : zero4(); \
+    } \
 _Pragma("unroll") \
-        for (int m = 0; m < MT; ++m) { \
-            doff[m] = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + g.d_choff + co; \
-            if (epi & LF_EPI_ADD) la[m] = epi_ld<S16>(a.add_src, doff[m]); \
-            if (epi & LF_EPI_MASK) lm[m] = epi_ld<S16>(a.mask_src, doff[m]); \
-            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[m] = epi_ld<S16>(a.aux, doff[m]); \
-            if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[m] = ldg4(a.dm + (long)pn[m] * g.Cd + co); \
+    for (int m = 0; m < MT; ++m) { \
+        const long dbase = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + g.d_choff + cob + kq * 4; \
+        f32x4 la[NT], lm[NT], lx[NT], ld[NT]; \
+_Pragma("unroll") \
+        for (int n = 0; n < NT; ++n) { \
+            if (epi & LF_EPI_ADD) la[n] = epi_ld<S16>(a.add_src, dbase + n * 16); \
+            if (epi & LF_EPI_MASK) lm[n] = epi_ld<S16>(a.mask_src, dbase + n * 16); \
+            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[n] = epi_ld<S16>(a.aux, dbase + n * 16); \
+            if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[n] = ldg4(a.dm + (long)pn[m] * g.Cd + cob + n * 16 + kq * 4); \
         } \
 _Pragma("unroll") \
-        for (int m = 0; m < MT; ++m) { \
-            f32x4 v = acc[n][m] + b; \
-            if (epi & LF_EPI_ADD) v += la[m]; \
-            if (epi & LF_EPI_MASK) v = keep_pos(v, lm[m]); \
-            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[m] * msc + msh); \
+        for (int n = 0; n < NT; ++n) { \
+            f32x4 v = acc[n][m] + bs[n]; \
+            if (epi & LF_EPI_ADD) v += la[n]; \
+            if (epi & LF_EPI_MASK) v = keep_pos(v, lm[n]); \
+            const int co = cob + n * 16 + kq * 4;   /* per-channel vectors: L1-resident, re-read instead of held in registers */ \
+            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[n] * ldg4(a.msc + co) + ldg4(a.msh + co)); \
             if (epi & LF_EPI_RELU) v = max0(v); \
             if (S16) v = round_bf16(v);   /* statistics are taken from the values as stored */ \
-            if (pv[m]) epi_st<S16>(a.dst, doff[m], v); \
+            if (pv[m]) epi_st<S16>(a.dst, dbase + n * 16, v); \
             if (!pv[m]) v = zero4(); \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
-                const f32x4 gm = a.dm ? v * ld[m] : v; \
-                s1[n] += gm; s2[n] += gm * (lx[m] * asc + ash); \
+                const f32x4 gm = a.dm ? v * ld[n] : v; \
+                s1[n] += gm; s2[n] += gm * (lx[n] * ldg4(a.asc + co) + ldg4(a.ash + co)); \
             } \
         } \
     } \
