@@ -62,12 +62,16 @@ __device__ __forceinline__ float sum16(float v) {
      * contiguous NT*16-channel run, so every cache line is touched once while it is hot (the channel-tile-outer order \
      * revisited each line NT times with the whole grid's working set in between: 4x the HBM reads with bf16 tensors). */ \
     const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0; \
-    f32x4 s1[NT], s2[NT], bs[NT]; \
+    f32x4 s1[NT], s2[NT], bs[NT], hv[HOISTV ? NT : 1][4]; \
 _Pragma("unroll") \
     for (int n = 0; n < NT; ++n) { \
         const int co = cob + n * 16 + kq * 4; \
         s1[n] = zero4(); s2[n] = zero4(); \
         bs[n] = a.bias ? ldg4(a.bias + co) : zero4(); \
+        if (HOISTV) { \
+            if (epi & LF_EPI_MASKBN) { hv[n][0] = ldg4(a.msc + co); hv[n][1] = ldg4(a.msh + co); } \
+            if (epi & LF_EPI_STATS_XHAT) { hv[n][2] = ldg4(a.asc + co); hv[n][3] = ldg4(a.ash + co); } \
+        } \
     } \
 _Pragma("unroll") \
     for (int m = 0; m < MT; ++m) { \
@@ -86,7 +90,7 @@ _Pragma("unroll") \
             if (epi & LF_EPI_ADD) v += la[n]; \
             if (epi & LF_EPI_MASK) v = keep_pos(v, lm[n]); \
             const int co = cob + n * 16 + kq * 4;   /* per-channel vectors: L1-resident, re-read instead of held in registers */ \
-            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[n] * ldg4(a.msc + co) + ldg4(a.msh + co)); \
+            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[n] * (HOISTV ? hv[HOISTV ? n : 0][0] : ldg4(a.msc + co)) + (HOISTV ? hv[HOISTV ? n : 0][1] : ldg4(a.msh + co))); \
             if (epi & LF_EPI_RELU) v = max0(v); \
             if (S16) v = round_bf16(v);   /* statistics are taken from the values as stored */ \
             if (pv[m]) epi_st<S16>(a.dst, dbase + n * 16, v); \
@@ -94,7 +98,7 @@ _Pragma("unroll") \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
                 const f32x4 gm = a.dm ? v * ld[n] : v; \
-                s1[n] += gm; s2[n] += gm * (lx[n] * ldg4(a.asc + co) + ldg4(a.ash + co)); \
+                s1[n] += gm; s2[n] += gm * (lx[n] * (HOISTV ? hv[HOISTV ? n : 0][2] : ldg4(a.asc + co)) + (HOISTV ? hv[HOISTV ? n : 0][3] : ldg4(a.ash + co))); \
             } \
         } \
     } \
@@ -119,9 +123,11 @@ _Pragma("unroll") \
         } \
     } \
 
+// (VAR 1 -- only reached by the handful of launches with fewer than 8 K-steps -- gets the whole register file: its
+// per-tap ping-pong state plus the epilogue operands do not fit 256 registers)
 template <int NT, int VAR, int PROC>
-__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
-    constexpr bool S16 = false;
+__global__ __launch_bounds__(256, VAR == 1 ? 1 : 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    constexpr bool S16 = false, HOISTV = false;      // the fp32 loop leaves no registers to hold the per-channel vectors
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
@@ -443,6 +449,7 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(f32x4 lo, f32x4 hi) {
 
 template <int NT, int PROC, bool S16>
 __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    constexpr bool HOISTV = true;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 // many waves per SIMD; the compiler is free to hoist the next step's loads.
 template <int NT>
 __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
-    constexpr bool S16 = false;
+    constexpr bool S16 = false, HOISTV = false;      // the fp32 loop leaves no registers to hold the per-channel vectors
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
