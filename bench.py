@@ -26,7 +26,7 @@ FLOP_PER_IMG_FWD_BWD = 39.67e9      # conv FLOPs, BASELINE.md section 2 (256x512
 # the other BASELINE.json configs, runnable with --workload (not the headline line): conv GFLOP/image fwd+bwd
 WORKLOADS = {"bev": dict(flop=39.67e9, R=256, K=2, batch=32, desc="BEV ERFNet + fused WLS fit + Area loss, 2 lanes, 256x512"),
              "bp": dict(flop=62.04e9, R=320, K=4, batch=64, desc="BP ERFNet + fused WLS fit (pixel coords, fp64 betas) + "
-                                                                 "back-projection loss, 4 lanes, 320x640 (config 3 in fp32)"),
+                                                                 "back-projection loss, 4 lanes, 320x640 (config 3 geometry)"),
              "seg": dict(flop=158.8e9, R=512, K=2, batch=16, desc="segmentation branch (end_to_end=False, early_return): ERFNet "
                                                                   "Cout=3 + class-weighted cross entropy, 512x1024 (config 5, per GPU)")}
 PEAK_FP32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
