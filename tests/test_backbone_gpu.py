@@ -485,7 +485,10 @@ def test_bf16_tensor_mode_kernel_parity():
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     try:
         lib.lf_debug_set_ops_precision(2)
-        for (C, H, W, axis, d) in ((128, 16, 32, 0, 4), (64, 24, 40, 1, 2), (16, 32, 64, 1, 1), (16, 32, 64, 0, 1)):
+        # (.., 6, 20, ..) and (.., 3, 12, ..): widths that are not multiples of 16 take the one-pixel-group weight-gradient
+        # path (widened loads, fp32 matrix cores) and partial pixel tiles in the forward / data gradient
+        for (C, H, W, axis, d) in ((128, 16, 32, 0, 4), (64, 24, 40, 1, 2), (16, 32, 64, 1, 1), (16, 32, 64, 0, 1),
+                                   (64, 6, 20, 1, 2), (128, 3, 12, 0, 1)):
             N = 3
             torch.manual_seed(C + axis)
             x = torch.randn(N, H, W, C, device="cuda").bfloat16()
@@ -596,7 +599,18 @@ def test_bf16_matrix_core_mode_network():
         g = [p.grad for p in net.parameters() if p.grad is not None]
         assert dec.dtype == torch.float32 and torch.isfinite(dec).all()
         assert all(t.dtype == torch.float32 and torch.isfinite(t).all() for t in g) and len(g) == 226
-    # the two bf16 modes differ from each other only by the storage rounding: gradients stay strongly correlated
+    # shapes whose stages are not multiples of the kernels' tiles (partial pixel tiles, one-group weight gradient)
+    for (n, h, w) in ((3, 48, 96), (1, 32, 64)):
+        xs = torch.rand(n, 3, h, w, device="cuda")
+        outs = {}
+        for mode in ("bf16_mfma", "bf16"):
+            net.precision = mode
+            net.zero_grad(set_to_none=True)
+            _, dec = net(xs, True)
+            dec.square().mean().backward()
+            assert dec.shape == (n, 2, h, w) and torch.isfinite(dec).all()
+            assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+            outs[mode] = dec.detach()
     net.precision = "fp32"
 
 
