@@ -115,6 +115,24 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": "batch 4, 256x512, 2 lanes, fp32 backbone + fp64 fit, %d steps, median" % len(times)}
 
 
+def lane_coeff_parity(model, x):
+    """Second half of the BASELINE.json metric: lane-coefficient max-abs-error vs the CPU oracle (fp64 WLS of
+    oracle/fit_oracle.py on the very logits the HIP backbone produced, same fp32 grid), over the whole bench batch.
+    Checker only: runs after the timed region, on rank 0 at N = 1."""
+    from oracle import fit_oracle
+    with torch.no_grad():
+        b0, b1, _, _, _, _, output, _, _ = model(x, True)
+    R = x.shape[2]
+    Mh, _ = fit_oracle.bev_homography()
+    grid = fit_oracle.projective_grid(R, 2 * R, Mh.astype(np.float32), True, np.float32)
+    c = fit_oracle.wls_forward(output.float().cpu().numpy(), grid, model.zero_rows, 2, 0.0, 1.0, "square")
+    beta = torch.stack([b0, b1], 1)[..., 0].double().cpu().numpy()
+    err = float(np.abs(beta - c["beta"]).max())
+    return {"lane_coeff_max_abs_err": err, "lane_coeff_max_rel_err": err / float(np.abs(c["beta"]).max()),
+            "tolerance_rel": 1e-5, "vs": "CPU oracle: fp64 WLS on the HIP logits of the bench batch (%d images x 2 lanes)"
+                                         % x.shape[0]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +193,7 @@ def main():
         dp.broadcast_parameters(model, src=0)
         reducer = dp.FlatGradAllReduce(params, flat_provider=model.net.flat_grad)
 
-    def step():
+    def step(reduce=True):
         if a.workload == "bev":
             b0, b1, _, _, _, _, _, _, _ = model(x, True)
             loss = crit(b0, gt[:, 0]) + crit(b1, gt[:, 1])
@@ -189,7 +207,7 @@ def main():
         loss.backward()
         if model.last_status is not None:
             statuses.append(model.last_status)
-        if reducer is not None:
+        if reducer is not None and reduce:
             reducer()          # one flat 8.25 MB RCCL all-reduce (sum / world)
         return loss
 
@@ -223,7 +241,7 @@ def main():
         lib.lf_erfnet_profile(plan.handle, 1)
         psteps = 3
         for _ in range(psteps):
-            step()
+            step(reduce=False)     # rank 0 only: no collective here, the other ranks are already at the final barrier
         torch.cuda.synchronize()
         buf = (ctypes.c_double * 6)()
         lib.lf_erfnet_profile_read(plan.handle, ctypes.cast(buf, ctypes.c_void_p))
@@ -265,6 +283,7 @@ def main():
                "roofline": roofline}
         if world == 1 and not a.no_cpu_baseline and a.workload == "bev":
             out["cpu_baseline"] = cpu_baseline()
+            out["parity"] = lane_coeff_parity(model, x)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
