@@ -143,7 +143,7 @@ def main():
                     help="bev = the BASELINE.json headline (default); bp / seg = configs 3 (in fp32) and 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable Dropout2d (parity-style run)")
-    ap.add_argument("--precision", choices=["fp32", "bf16_mfma", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16_mfma", "bf16", "fp32x9", "fp32x6"], default="fp32",
                     help="fp32 (default = the BASELINE headline); bf16_mfma = conv operands rounded to bf16, fp32 accumulation "
                          "and fp32 tensors; bf16 = bf16 matrix cores and bf16 activation/gradient tensors (config 3; not "
                          "parity modes, the reference is fp32 only)")
@@ -252,7 +252,7 @@ def main():
         d = fam[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         # family 0 runs on the bf16 matrix cores in --precision bf16 (the weight gradient stays fp32)
-        peak = PEAK_BF16_MFMA if (a.precision != "fp32" and dom == 0) else PEAK_FP32_MFMA
+        peak = PEAK_BF16_MFMA if (a.precision in ("bf16", "bf16_mfma") and dom == 0) else PEAK_FP32_MFMA
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak / 1e12,
                     "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4),
                     # HBM bytes per launch of the family's representative launch (128-channel 3-tap conv, batch 32:
@@ -271,7 +271,7 @@ def main():
         out = {"metric": metric, "value": round(ips, 2), "unit": "images/sec",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": {"fp32": "f32", "bf16_mfma": "bf16 MFMA operands (fp32 accumulate, fp32 tensors); weight gradient f32",
+               "dtype": {"fp32": "f32", "fp32x9": "f32 (split x9)", "fp32x6": "f32 (split x6)", "bf16_mfma": "bf16 MFMA operands (fp32 accumulate, fp32 tensors); weight gradient f32",
                          "bf16": "bf16 (MFMA operands + activation/gradient tensors; fp32 accumulate, weight gradient on "
                                  "fp32 MFMA, fp32 parameters/statistics/fit)"}[a.precision],
                "data": "synthetic",

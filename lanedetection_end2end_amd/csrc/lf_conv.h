@@ -37,6 +37,9 @@ struct LfTapArgs {
     const float* wp;        // packed weights [tap][Cs/4][Cd][4]
     int s16;                // 1: src / dst / mask_src / add_src / aux hold bf16 elements (needs wp16)
     const void* wp16;       // non-null selects the bf16 matrix-core kernel: packed bf16 weights [tap][ceil(Cs/32)*4][Cd][8]
+    int split;              // 9 or 6: fp32 on the bf16 matrix cores from 3-way split operands (tapgemm_split_kernel);
+    const void* wp48;       //   its weights, split by the pack kernel: bf16 [tap][Cs/8][Cd][3][8]; launches the split
+                            //   kernel cannot take (Cs % 32, Cd % 64) fall back to the fp32 matrix cores (wp)
     const float* bias;      // [Cd] or null
     float* dst;
     const float* pro_sc;    // prologue BN scale / shift per source channel
@@ -63,6 +66,7 @@ struct LfWgradArgs {
     const float* pro_sc;    // optional BN+ReLU recompute on x
     const float* pro_sh;
     int s16;                // 1: x and g hold bf16 elements (partials and bias rows stay fp32)
+    int split;              // 9 or 6: fp32 from 3-way split operands on the bf16 matrix cores (fp32 tensors, 64-channel blocks)
     float* partial;         // [splits][ntaps][Cs][Cd]
     float* bias_partial;    // [bias_rows][Cd] or null
 };
@@ -92,5 +96,9 @@ struct LfPackEntry {
 int lf_pack_weights_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena,
                            hipStream_t st);
 long lf_pack_bf16_elems(int Kc, int Nc, int ntaps);
+// split weights: 3 bf16 pieces per element, entry e at 3 * e.dst16_off of arena48 (entries with Kc % 32 != 0 are skipped)
+int lf_pack_weights_split_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, void* arena48,
+                                 hipStream_t st);
+bool lf_tapgemm_split_ok(const LfTapGeom& g);
 int lf_pack_weights_bf16_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, void* arena16,
                                 hipStream_t st);

@@ -579,6 +579,187 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
     LF_TAPGEMM_EPILOGUE
 }
 
+// ---------------------------------------------------------------------------------------
+// fp32 ON THE bf16 MATRIX CORES ("split" mode, LfTapArgs::split = 9 or 6).  gfx950 multiplies bf16 16x faster
+// than fp32 (v_mfma_f32_16x16x32_bf16: 16 cycles for K = 32; v_mfma_f32_16x16x4_f32: 8 x 32 cycles for the same K),
+// so an fp32 product is formed from bf16 pieces instead: every fp32 operand is split EXACTLY into three bf16 values
+//     a = a_h + a_m + a_l,   a_h = bf16(a), a_m = bf16(a - a_h), a_l = bf16(a - a_h - a_m)      (8 + 8 + 8 mantissa bits)
+// (both subtractions are exact in fp32, a_l is exact because at most 8 significant bits are left), and
+//     a * b = sum_{i,j} a_i * b_j
+// where each of the nine bf16 x bf16 products is exact in the fp32 accumulator.  TERMS = 9 keeps them all: the result
+// is an fp32 accumulation of exact products, the same contract as the fp32 FMA chain of tapgemm_kernel.  TERMS = 6
+// drops a_m*b_l, a_l*b_m, a_l*b_l (< 2^-24 |a b| together, unbiased because the pieces are rounded to nearest): below
+// the rounding of one fp32 accumulation step.  Tensors, accumulators, epilogue and statistics are fp32 as in mode 0.
+// Cost per 64 x 64 x 32 wave step: 144 (96) MFMAs x 16 cycles = 2304 (1536) cycles against 4096 on the fp32 cores.
+// The pixel operand is split in registers (v_cvt_pk_bf16_f32 + exact residuals, ~5 VALU ops per element, issued in the
+// shadow of the MFMAs); weights are split once per forward by the pack kernel ([tap][K/8][Cd][3][8] bf16) and, being
+// 3x the bytes of the fp32 form, staged ONCE per workgroup and step through LDS (double-buffered, one barrier per step)
+// instead of once per wave from L1, which would saturate the 64 B/clk L1 path at this MFMA rate.
+// ---------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// one pair of fp32 values -> their packed bf16 roundings (v_cvt_pk_bf16_f32); v becomes the exact residuals
+__device__ __forceinline__ unsigned split_pair(f32x2& v) {
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v.x -= __uint_as_float(u << 16);             // exact: the residual of a round-to-nearest fits fp32
+    v.y -= __uint_as_float(u & 0xffff0000u);
+    return u;
+}
+__device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& h, bf16x8& m, bf16x8& l) {
+    f32x2 p[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
+    u32x4 uh, um, ul;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) uh[i] = split_pair(p[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) um[i] = split_pair(p[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)     // what is left has at most 8 significant bits: the third conversion is exact
+        ul[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[i], bf16x2));
+    h = __builtin_bit_cast(bf16x8, uh); m = __builtin_bit_cast(bf16x8, um); l = __builtin_bit_cast(bf16x8, ul);
+}
+
+template <int NT, int PROC, int TERMS>
+__global__ __launch_bounds__(256, 2) void tapgemm_split_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    constexpr bool S16 = false, HOISTV = false;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
+    const int cob = blockIdx.y * NT * 16;
+    unsigned bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
+
+    int pn[MT], pi[MT], pj[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const unsigned p = tile0 + m * 16 + pl;
+        pv[m] = p < npix;
+        const unsigned q = pv[m] ? p : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj[m] = (int)(q - r * (unsigned)g.Wl);
+        pn[m] = (int)(r / (unsigned)g.Hl);
+        pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+
+    struct Raw { f32x4 xl[MT], xh[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
+    __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
+    __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
+    __shared__ u32x4 wl[2][3][4][NT * 16];          // [buffer][piece][k-block of 8][output channel]: 16 B rows, conflict-free
+    for (int t = 0; t < g.ntaps; ++t) {
+        const int dh = g.tdh[t], dw = g.tdw[t];
+        unsigned o[MT], okb = 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+            const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+            o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 8);
+            okb |= (in ? 1u : 0u) << m;
+        }
+        tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+        tab_ok[wave][t][lane] = okb;
+    }
+    const int ncb = g.Cs >> 5;                               // 32-channel steps per tap (launcher: Cs % 32 == 0)
+    const int nsteps = g.ntaps * ncb;
+    const int ntaps = g.ntaps;
+    // weight staging: thread -> (k-block, output channel) of the workgroup's NT*16-channel slab
+    const int tid = threadIdx.x;
+    const bool filler = tid < NT * 64;
+    const int f_kb = filler ? tid / (NT * 16) : 0, f_co = filler ? tid % (NT * 16) : 0;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp16) + ((long)f_kb * g.Cd + cob + f_co) * 3;
+    const int wstep = g.Cd * 4 * 3;                          // u32x4 per 32-channel step
+    int wstepi = 0;
+    u32x4 wreg[3];
+    auto wfetch = [&]() {
+        const u32x4* p = wsrc + (long)min(wstepi, nsteps - 1) * wstep;
+        wreg[0] = p[0]; wreg[1] = p[1]; wreg[2] = p[2];
+        ++wstepi;
+    };
+    auto wstore = [&](int buf) {
+        if (filler) { wl[buf][0][f_kb][f_co] = wreg[0]; wl[buf][1][f_kb][f_co] = wreg[1]; wl[buf][2][f_kb][f_co] = wreg[2]; }
+    };
+    int t_ld = 0, cb_ld = 0;
+    auto issue = [&](Raw& S) {
+        const bool live = t_ld < ntaps;
+        const int tc = live ? t_ld : ntaps - 1;
+        const uint4 o = tab_off[wave][tc][lane];
+        const unsigned okb = tab_ok[wave][tc][lane];
+        const int c32 = cb_ld * 32;
+        S.xl[0] = ldg4(a.src + o.x + c32); S.xh[0] = ldg4(a.src + o.x + c32 + 4);
+        S.xl[1] = ldg4(a.src + o.y + c32); S.xh[1] = ldg4(a.src + o.y + c32 + 4);
+        S.xl[2] = ldg4(a.src + o.z + c32); S.xh[2] = ldg4(a.src + o.z + c32 + 4);
+        S.xl[3] = ldg4(a.src + o.w + c32); S.xh[3] = ldg4(a.src + o.w + c32 + 4);
+        if constexpr (PROC == LF_PRO_BNRELU) {
+            const int c8 = c32 + kq * 8;
+            S.sc0 = ldg4(a.pro_sc + c8); S.sc1 = ldg4(a.pro_sc + c8 + 4);
+            S.sh0 = ldg4(a.pro_sh + c8); S.sh1 = ldg4(a.pro_sh + c8 + 4);
+        }
+        S.ok = live ? okb : 0u;
+        const int cbn = cb_ld + 1;
+        const bool wrap = cbn == ncb;
+        cb_ld = live ? (wrap ? 0 : cbn) : cb_ld;
+        t_ld = (live && wrap) ? t_ld + 1 : t_ld;
+    };
+    static_assert(MT == 4, "tab_off packs 4 pixel tiles");
+    static_assert(TERMS == 9 || TERMS == 6, "9 = every partial product, 6 = those above 2^-24");
+    Raw R;
+    wfetch();
+    issue(R);
+    wstore(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        bf16x8 xb[MT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool in = (R.ok >> m) & 1u;
+            f32x4 lo = R.xl[m], hi = R.xh[m];
+            if constexpr (PROC == LF_PRO_BNRELU) { lo = max0(lo * R.sc0 + R.sh0); hi = max0(hi * R.sc1 + R.sh1); }
+            lo.x = in ? lo.x : 0.f; lo.y = in ? lo.y : 0.f; lo.z = in ? lo.z : 0.f; lo.w = in ? lo.w : 0.f;
+            hi.x = in ? hi.x : 0.f; hi.y = in ? hi.y : 0.f; hi.z = in ? hi.z : 0.f; hi.w = in ? hi.w : 0.f;
+            split3(lo, hi, xb[m][0], xb[m][1], xb[m][2]);
+        }
+        wfetch();                 // next step's weights and pixels (clamped / masked past the end) fly during the MFMAs
+        issue(R);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wl[cur][0][kq][n * 16 + pl]);
+            const bf16x8 wm = __builtin_bit_cast(bf16x8, wl[cur][1][kq][n * 16 + pl]);
+            const bf16x8 wo = __builtin_bit_cast(bf16x8, wl[cur][2][kq][n * 16 + pl]);
+            // smallest terms first; consecutive MFMAs of one term go to four different accumulators
+            if constexpr (TERMS == 9) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][2], acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][2], acc[n][m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][0], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][2], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][0], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][0], acc[n][m], 0, 0, 0);
+        }
+        wstore(cur ^ 1);
+        __syncthreads();
+    }
+    LF_TAPGEMM_EPILOGUE
+}
+
 // Lean variant for 16-output-channel launches (the 128x256 stage, ~3 % of the FLOPs): these are HBM-bound
 // (0.75*C = 12 FLOP/B), so the goal is bytes in flight, not MFMA issue: no operand ring, few registers,
 // many waves per SIMD; the compiler is free to hoist the next step's loads.
@@ -666,6 +847,11 @@ int pick_nt(int Cd) {
 
 void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
 
+// launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), 16-byte aligned pixels
+bool lf_tapgemm_split_ok(const LfTapGeom& g) {
+    return g.Cs % 32 == 0 && g.Cd % 64 == 0 && g.s_pix % 4 == 0 && g.s_choff % 4 == 0;
+}
+
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;
     return lf_cdiv(npix, PIX_PER_WG);
@@ -693,6 +879,20 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
     LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
+    if (a.split && a.wp48 && !a.wp16 && !a.dbg && lf_tapgemm_split_ok(g)) {
+        LF_REQUIRE(a.split == 9 || a.split == 6, "tapgemm: split must be 9 or 6 (got %d)", a.split);
+        LfTapArgs b = a;
+        b.wp16 = a.wp48;
+        if (a.split == 9) {
+            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 9>), grid, dim3(256), 0, st, g, b, pro, epi);
+            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 9>), grid, dim3(256), 0, st, g, b, pro, epi);
+        } else {
+            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 6>), grid, dim3(256), 0, st, g, b, pro, epi);
+            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 6>), grid, dim3(256), 0, st, g, b, pro, epi);
+        }
+        LF_CHECK_LAUNCH("tapgemm_split");
+        return 0;
+    }
     LF_REQUIRE(!a.s16 || (g.s_pix % 8 == 0 && g.s_choff % 8 == 0), "tapgemm: bf16 source layout must be 16-byte aligned per pixel");
     if (a.wp16) {
 #define LF_TG16(NTV)                                                                                                     \
@@ -1286,6 +1486,34 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const LfPackEntr
     }
 }
 
+// split operand order of tapgemm_split_kernel: [tap][Kc/8][Nc][3][8] bf16, pieces h, m, l of every weight (exact:
+// h + m + l == w); entries whose Kc is not a multiple of 32 are never used by that kernel and skipped here
+__global__ __launch_bounds__(256) void pack_weights_split_kernel(const LfPackEntry* __restrict__ entries,
+                                                                const float* const* __restrict__ params,
+                                                                __bf16* __restrict__ arena) {
+    const LfPackEntry e = entries[blockIdx.x];
+    if (e.Kc % 32 != 0) return;
+    const float* w = params[e.param];
+    __bf16* dst = arena + 3 * e.dst16_off;
+    const int kb_per_tap = e.Kc >> 3;
+    const long total = (long)e.ntaps * kb_per_tap * e.Nc * 8;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const int k8 = (int)(i & 7);
+        long r = i >> 3;
+        const int n = (int)(r % e.Nc);
+        const long row = r;                       // (t * kb_per_tap + kb) * Nc + n
+        r /= e.Nc;
+        const int kb = (int)(r % kb_per_tap);
+        const int t = (int)(r / kb_per_tap);
+        const float v = w[(kb * 8 + k8) * e.sk + n * e.sn + e.tapidx[t]];
+        const __bf16 vh = (__bf16)v;
+        const float r1 = v - (float)vh;
+        const __bf16 vm = (__bf16)r1;
+        const float r2 = r1 - (float)vm;
+        dst[row * 24 + k8] = vh; dst[row * 24 + 8 + k8] = vm; dst[row * 24 + 16 + k8] = (__bf16)r2;
+    }
+}
+
 }  // namespace
 
 int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,
@@ -1321,6 +1549,14 @@ int lf_pack_weights_bf16_launch(const LfPackEntry* entries_dev, int nentries, co
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(nentries, 16), dim3(256), 0, st, entries_dev, params_dev,
                        reinterpret_cast<__bf16*>(arena16));
     LF_CHECK_LAUNCH("pack_weights_bf16");
+    return 0;
+}
+
+int lf_pack_weights_split_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, void* arena48,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(nentries, 16), dim3(256), 0, st, entries_dev, params_dev,
+                       reinterpret_cast<__bf16*>(arena48));
+    LF_CHECK_LAUNCH("pack_weights_split");
     return 0;
 }
 

@@ -56,8 +56,9 @@ struct lf_erfnet_plan {
     int n_params, n_bn, n_drop;
     int p_head_w[2], p_head_b[2], n_heads;
     long off_entries, off_packed, packed_floats;
-    long off_packed16, packed16_elems;          // bf16 operand copies of the packed weights (precision mode 1)
-    mutable int precision = 0;                  // 0 = fp32 MFMA, 1 = bf16 MFMA operands (fp32 accumulate / storage)
+    long off_packed16, packed16_elems;          // bf16 operand copies of the packed weights (precision modes 1, 2)
+    long off_packed48;                          // 3-piece bf16 split of the packed weights (modes 3, 4): 3 * packed16_elems
+    mutable int precision = 0;                  // lf_erfnet_set_precision
     long off_stat0, off_stat1, stat_floats;     // two scratch regions for BN partial rows
     long off_wpart, wpart_floats, off_bpart, bpart_floats;
     long off_gA, off_gB, off_gC, gbuf_floats;
@@ -287,6 +288,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
     P->off_packed = ws.take(P->packed_floats);
     P->off_packed16 = ws.take((P->packed16_elems + 1) / 2);
+    P->off_packed48 = ws.take((3 * P->packed16_elems + 1) / 2);
     P->off_stat0 = ws.take(P->stat_floats);
     P->off_stat1 = ws.take(P->stat_floats);
     P->off_wpart = ws.take(P->wpart_floats);
@@ -314,7 +316,8 @@ size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)P->to
 // BatchNorm statistics and the logits stay fp32).
 // Set before a forward; the matching backward must run with the same setting.
 int lf_erfnet_set_precision(const lf_erfnet_plan* P, int mode) {
-    LF_REQUIRE(P && mode >= 0 && mode <= 2, "lf_erfnet_set_precision: mode must be 0 (fp32), 1 (bf16 operands) or 2 (bf16 tensors)");
+    LF_REQUIRE(P && mode >= 0 && mode <= 4, "lf_erfnet_set_precision: mode must be 0 (fp32 cores), 1 (bf16 operands), 2 (bf16 tensors), "
+               "3 / 4 (fp32 from split operands on the bf16 cores, 9 / 6 partial products)");
     P->precision = mode;
     return 0;
 }
@@ -400,8 +403,12 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
     extra.s16 = c.s16;
-    if (c.P->precision >= 1)
+    if (c.P->precision == 1 || c.P->precision == 2)
         extra.wp16 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed16) + c.P->packs[op.pack].dst16_off;
+    if (c.P->precision >= 3) {      // fp32 from split operands on the bf16 matrix cores (9 or 6 partial products)
+        extra.split = c.P->precision == 3 ? 9 : 6;
+        extra.wp48 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed48) + 3 * c.P->packs[op.pack].dst16_off;
+    }
     ProfScope ps(c, 0, op.geom, epi | (pro << 8), c.st);
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
 }
@@ -492,6 +499,7 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     c.side_reads |= gbuf;
     LfWgradArgs a;
     a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh; a.s16 = c.s16;
+    a.split = P->precision == 3 ? 9 : (P->precision == 4 ? 6 : 0);
     a.partial = c.at(P->off_wpart);
     a.bias_partial = c.grads[cv.p_b] ? c.at(P->off_bpart) : nullptr;
     {
@@ -674,8 +682,10 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
     if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
         return lf_fail("erfnet: upload of the pack table failed");
     LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
-    if (P->precision >= 1)
+    if (P->precision == 1 || P->precision == 2)
         LF_TRY(lf_pack_weights_bf16_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed16), c.st));
+    if (P->precision >= 3)
+        LF_TRY(lf_pack_weights_split_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed48), c.st));
     return 0;
 }
 

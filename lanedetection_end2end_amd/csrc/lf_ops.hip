@@ -37,11 +37,40 @@ __global__ __launch_bounds__(256) void pack_one_bf16_kernel(const float* __restr
     }
 }
 
-int g_ops_bf16 = 0;
+// split operand order of tapgemm_split_kernel: [tap][Kc/8][Nc][3][8] bf16 (pieces h, m, l; h + m + l == w exactly)
+__global__ __launch_bounds__(256) void pack_one_split_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Kc, int Nc,
+                                                            int ntaps, long sk, long sn, int flip) {
+    const int kb_per_tap = Kc >> 3;
+    const long total = (long)ntaps * kb_per_tap * Nc * 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k8 = (int)(i & 7);
+        const long row = i >> 3;
+        long r = row;
+        const int n = (int)(r % Nc);
+        r /= Nc;
+        const int kb = (int)(r % kb_per_tap);
+        const int t = (int)(r / kb_per_tap);
+        const float v = w[(kb * 8 + k8) * sk + n * sn + (flip ? ntaps - 1 - t : t)];
+        const __bf16 vh = (__bf16)v;
+        const float r1 = v - (float)vh;
+        const __bf16 vm = (__bf16)r1;
+        dst[row * 24 + k8] = vh; dst[row * 24 + 8 + k8] = vm; dst[row * 24 + 16 + k8] = (__bf16)(r1 - (float)vm);
+    }
+}
+
+int g_ops_bf16 = 0;     // 0 fp32 cores, 1 / 2 bf16 cores (fp32 / bf16 tensors), 9 / 6 fp32 from split operands on the bf16 cores
 
 // pack into scratch in the order the selected kernel wants; returns the LfTapArgs weight fields
 void pack_conv1d(LfTapArgs& a, const float* w, float* scratch, int C, long sk, long sn, int flip, hipStream_t st) {
-    if (g_ops_bf16) {
+    if (g_ops_bf16 == 9 || g_ops_bf16 == 6) {
+        hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, sk, sn, flip);
+        if (C % 32 == 0) {
+            hipLaunchKernelGGL(pack_one_split_kernel, dim3(64), dim3(256), 0, st, w, reinterpret_cast<__bf16*>(scratch + 3L * C * C),
+                               C, C, 3, sk, sn, flip);
+            a.split = g_ops_bf16;
+            a.wp48 = scratch + 3L * C * C;
+        }
+    } else if (g_ops_bf16) {
         hipLaunchKernelGGL(pack_one_bf16_kernel, dim3(64), dim3(256), 0, st, w, reinterpret_cast<__bf16*>(scratch), C, C, 3, sk, sn, flip);
         a.wp16 = scratch;
         a.s16 = g_ops_bf16 == 2;
@@ -85,7 +114,7 @@ int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias
 // scratch floats needed by the three calls below (packed weights / split-K partials)
 long lf_conv1d_scratch_floats(int N, int H, int W, int C) {
     const LfTapGeom g = conv1d_geom(N, H, W, C, 0, 1);
-    long a = 3L * C * C;
+    long a = 8L * C * C;        // fp32-packed weights + their 3-piece bf16 split (4.5 C^2 floats)
     long b = (long)lf_tapwgrad_splits(g) * 3 * C * C + (long)lf_tapwgrad_bias_rows(g) * C;
     return a > b ? a : b;
 }
@@ -124,6 +153,7 @@ int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, 
     const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
     LfWgradArgs a;
     a.x = x; a.g = gy; a.pro_sc = nullptr; a.pro_sh = nullptr; a.s16 = g_ops_bf16 == 2;
+    a.split = (g_ops_bf16 == 9 || g_ops_bf16 == 6) ? g_ops_bf16 : 0;
     a.partial = scratch;
     a.bias_partial = gb ? scratch + (long)lf_tapwgrad_splits(g) * 3 * C * C : nullptr;
     int rc = lf_tapwgrad_launch(g, a, LF_PRO_NONE, st);

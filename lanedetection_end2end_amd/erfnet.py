@@ -119,7 +119,7 @@ def _ptr_array(tensors):
 
 
 # lf_erfnet_set_precision modes (include/lanefit.h)
-_PRECISIONS = {"fp32": 0, "bf16_mfma": 1, "bf16": 2}
+_PRECISIONS = {"fp32": 0, "bf16_mfma": 1, "bf16": 2, "fp32x9": 3, "fp32x6": 4}
 
 
 class _BackboneFn(torch.autograd.Function):

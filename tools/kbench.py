@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--bf16", action="store_true", help="bf16 matrix-core kernel for fwd / dgrad; the torch check runs on "
                     "bf16-rounded operands (products exact in fp32, so the tolerance stays at fp32 level)")
+    ap.add_argument("--split", type=int, default=0, choices=[0, 6, 9], help="fp32 from 3-way split operands on the bf16 matrix "
+                    "cores (9 or 6 partial products); checked against the plain fp32 torch result")
     ap.add_argument("--one", type=int, nargs=5, metavar=("C", "H", "W", "AXIS", "DIL"), help="run a single shape (for PMC passes)")
     a = ap.parse_args()
     lib = _lib.load()
@@ -69,7 +71,13 @@ def main():
         yr = F.conv2d(xn, wn, bn, padding=pad, dilation=dil)
         yr.backward(gy.permute(0, 3, 1, 2))
         gx_ref = xn.grad
-        lib.lf_debug_set_ops_precision(1 if a.bf16 else 0)
+        with torch.no_grad():     # fp64 truth: how far each arithmetic (fp32 cores / split operands) is from exact
+            y64 = F.conv2d(xn.detach().double(), w4.double(), b.double(), padding=pad, dilation=dil)
+            gx64 = torch.nn.grad.conv2d_input(xn.shape, w4.double(), gy.permute(0, 3, 1, 2).double().contiguous(), padding=pad,
+                                              dilation=dil)
+            gw64 = torch.nn.grad.conv2d_weight(xn.detach().double(), w4.shape, gy.permute(0, 3, 1, 2).double().contiguous(),
+                                               padding=pad, dilation=dil)
+        lib.lf_debug_set_ops_precision(a.split if a.split else (1 if a.bf16 else 0))
         if a.bf16:
             rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
             with torch.no_grad():
@@ -81,13 +89,19 @@ def main():
             f = lambda: _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 0, P(scratch), st), "fwd")
             tf = timeit(f, a.iters)
             e1 = float((y.permute(0, 3, 1, 2) - yr).abs().max() / yr.abs().max())
+            d1 = float((y.permute(0, 3, 1, 2).double() - y64).abs().max() / y64.abs().max())
+            r1 = float((y.permute(0, 3, 1, 2).double() - y64).pow(2).mean().sqrt() / y64.pow(2).mean().sqrt())
             g = lambda: _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), None, P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
             td = timeit(g, a.iters)
             e2 = float((gx.permute(0, 3, 1, 2) - gx_ref).abs().max() / gx_ref.abs().max())
+            d2 = float((gx.permute(0, 3, 1, 2).double() - gx64).abs().max() / gx64.abs().max())
             h = lambda: _lib.check(lib.lf_conv1d_bwd_weight(P(x), P(gy), P(gw), P(gb), N, H, W, C, axis, d, P(scratch), st), "wgrad")
             tw = timeit(h, a.iters)
             e3 = float((gw.view_as(wn.grad) - wn.grad).abs().max() / wn.grad.abs().max())
             e4 = float((gb - bn.grad).abs().max() / bn.grad.abs().max())
+            d3 = float((gw.view_as(gw64).double() - gw64).abs().max() / gw64.abs().max())
+            print("   vs fp64: fwd max %.2e rms %.2e | dgrad max %.2e | wgrad max %.2e   (torch fp32: fwd %.2e)"
+                  % (d1, r1, d2, d3, float((yr.double() - y64).abs().max() / y64.abs().max())), flush=True)
             print("C=%3d %3dx%3d axis %d dil %2d var %d | fwd %6.1f us %5.1f TF (%4.1f%%) err %.1e | dgrad %6.1f us %5.1f TF err %.1e | "
                   "wgrad(+reduce) %6.1f us %5.1f TF err %.1e %.1e"
                   % (C, H, W, axis, d, v, tf * 1e6, flops / tf / 1e12, 100 * flops / tf / 1e12 / PEAK, e1, td * 1e6,
