@@ -51,12 +51,34 @@ __device__ __forceinline__ f32x4 round_bf16(f32x4 v) {
     v.x = (float)(lf_bf16)v.x; v.y = (float)(lf_bf16)v.y; v.z = (float)(lf_bf16)v.z; v.w = (float)(lf_bf16)v.w;
     return v;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// one pair of fp32 values -> their packed bf16 roundings (v_cvt_pk_bf16_f32); v becomes the exact residuals
+__device__ __forceinline__ unsigned split_pair(f32x2& v) {
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v.x -= __uint_as_float(u << 16);             // exact: the residual of a round-to-nearest fits fp32
+    v.y -= __uint_as_float(u & 0xffff0000u);
+    return u;
+}
+// split copy of a tensor: [pixel][channel / 8][piece h, m, l][8] bf16 (48-byte records), v == h + m + l exactly.
+// Stores the 3 x 4 pieces of channels off .. off+3 (off % 4 == 0, in elements from the tensor base).
+__device__ __forceinline__ void split_st4(void* base48, long off, f32x4 v) {
+    f32x2 p0 = {v.x, v.y}, p1 = {v.z, v.w};
+    uint2 h, m, l;
+    h.x = split_pair(p0); h.y = split_pair(p1);
+    m.x = split_pair(p0); m.y = split_pair(p1);
+    l.x = __builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf16x2));
+    l.y = __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf16x2));
+    char* q = reinterpret_cast<char*>(base48) + (off >> 3) * 48 + ((off & 4) << 1);
+    *reinterpret_cast<uint2*>(q) = h; *reinterpret_cast<uint2*>(q + 16) = m; *reinterpret_cast<uint2*>(q + 32) = l;
+}
 // sum over the 16 lanes that share l>>4 (xor 1,2,4,8 stays inside the 16-lane group)
 __device__ __forceinline__ float sum16(float v) {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
     return v;
 }
 
+#define LF_EPI_GROUPS 1      /* 4-wave groups per workgroup; the 512-thread split kernel redefines it */
 #define LF_TAPGEMM_EPILOGUE \
     /* Pixel-tile outer, channel-tile inner: the NT loads of one operand tensor issued back to back cover one pixel's  \
      * contiguous NT*16-channel run, so every cache line is touched once while it is hot (the channel-tile-outer order \
@@ -94,6 +116,7 @@ _Pragma("unroll") \
             if (epi & LF_EPI_RELU) v = max0(v); \
             if (S16) v = round_bf16(v);   /* statistics are taken from the values as stored */ \
             if (pv[m]) epi_st<S16>(a.dst, dbase + n * 16, v); \
+            if (!S16 && a.dst48 && pv[m]) split_st4(a.dst48, dbase + n * 16, v); \
             if (!pv[m]) v = zero4(); \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
@@ -103,23 +126,26 @@ _Pragma("unroll") \
         } \
     } \
     if (stats) { \
-        __shared__ float sred[WG_WAVES][NT][4][8]; \
+        /* one partial row per 256-pixel tile: 4-wave group EG of the workgroup (EG = 0 in the 256-thread kernels) */ \
+        const int EW = wave & 3, EG = wave >> 2; \
+        __shared__ float sred[LF_EPI_GROUPS][WG_WAVES][NT][4][8]; \
 _Pragma("unroll") \
         for (int n = 0; n < NT; ++n) { \
             f32x4 r1, r2; \
             r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w); \
             r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w); \
             if (pl == 0) { \
-                float* d = sred[wave][n][kq]; \
+                float* d = sred[EG][EW][n][kq]; \
                 d[0] = r1.x; d[1] = r1.y; d[2] = r1.z; d[3] = r1.w; d[4] = r2.x; d[5] = r2.y; d[6] = r2.z; d[7] = r2.w; \
             } \
         } \
         __syncthreads(); \
-        if (threadIdx.x < NT * 4 * 8) { \
-            const int j = threadIdx.x & 7, q = (threadIdx.x >> 3) & 3, n = threadIdx.x >> 5; \
-            const float v = sred[0][n][q][j] + sred[1][n][q][j] + sred[2][n][q][j] + sred[3][n][q][j]; \
+        if ((threadIdx.x & 255) < NT * 4 * 8) { \
+            const int tg = threadIdx.x >> 8, tt = threadIdx.x & 255; \
+            const int j = tt & 7, q = (tt >> 3) & 3, n = tt >> 5; \
+            const float v = sred[tg][0][n][q][j] + sred[tg][1][n][q][j] + sred[tg][2][n][q][j] + sred[tg][3][n][q][j]; \
             const int co = cob + n * 16 + q * 4 + (j & 3); \
-            a.stats[((long)bx * 2 + (j >> 2)) * g.Cd + co] = v; \
+            a.stats[(((long)bx * LF_EPI_GROUPS + tg) * 2 + (j >> 2)) * g.Cd + co] = v; \
         } \
     } \
 
@@ -596,15 +622,6 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 // 3x the bytes of the fp32 form, staged ONCE per workgroup and step through LDS (double-buffered, one barrier per step)
 // instead of once per wave from L1, which would saturate the 64 B/clk L1 path at this MFMA rate.
 // ---------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// one pair of fp32 values -> their packed bf16 roundings (v_cvt_pk_bf16_f32); v becomes the exact residuals
-__device__ __forceinline__ unsigned split_pair(f32x2& v) {
-    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    v.x -= __uint_as_float(u << 16);             // exact: the residual of a round-to-nearest fits fp32
-    v.y -= __uint_as_float(u & 0xffff0000u);
-    return u;
-}
 __device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& h, bf16x8& m, bf16x8& l) {
     f32x2 p[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
     u32x4 uh, um, ul;
@@ -618,8 +635,218 @@ __device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& h
     h = __builtin_bit_cast(bf16x8, uh); m = __builtin_bit_cast(bf16x8, um); l = __builtin_bit_cast(bf16x8, ul);
 }
 
+// Workgroup = 512 threads = two 4-wave groups A (waves 0-3) and B (waves 4-7); waves w and w+4 share SIMD w.  A wave's
+// step has a VALU part (split the 32 pixel values it loaded, issue the next loads) and a matrix part (144 / 96 MFMAs).
+// Two waves running the same code in lockstep would both want the VALU, then both the matrix pipe; so B runs HALF A STEP
+// behind A, phase-locked by the workgroup barrier: while A multiplies, B splits, and vice versa -- the matrix pipe of every
+// SIMD always has exactly one wave streaming back-to-back MFMAs.  Group A also stages the weights: W[s+1] is written to
+// the idle LDS buffer during A's split phase (B is reading W[s-1]'s successor W[s] from the other one).
+#undef LF_EPI_GROUPS
+#define LF_EPI_GROUPS 2
+template <int NT, int PROC, int TERMS, bool PRE>
+__global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+    constexpr bool S16 = false, HOISTV = false;
+    constexpr int WAVES = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
+    const int grp = wave >> 2;
+    unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
+    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memtime();
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
+    const int cob = blockIdx.y * NT * 16;
+    unsigned bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const unsigned tile0 = (bx * WAVES + wave) * (MT * 16);
+
+    int pn[MT], pi[MT], pj[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const unsigned p = tile0 + m * 16 + pl;
+        pv[m] = p < npix;
+        const unsigned q = pv[m] ? p : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj[m] = (int)(q - r * (unsigned)g.Wl);
+        pn[m] = (int)(r / (unsigned)g.Hl);
+        pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+
+    // PRE: the source has a split copy (LfTapArgs::src48, written by its producer): a lane's operand pieces are three
+    // 16-byte loads and there is nothing to compute; otherwise 8 fp32 values are loaded and split here
+    struct Raw { f32x4 xl[PRE ? 1 : MT], xh[PRE ? 1 : MT]; u32x4 pc[PRE ? MT : 1][3]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
+    static_assert(!(PRE && PROC == LF_PRO_BNRELU), "the BN + ReLU prologue needs the fp32 values");
+    const u32x4* src48 = reinterpret_cast<const u32x4*>(a.src48);
+    __shared__ uint4 tab_off[WAVES][LF_MAX_TAPS][64];
+    __shared__ unsigned tab_ok[WAVES][LF_MAX_TAPS][64];
+    __shared__ u32x4 wl[2][3][4][NT * 16];          // [buffer][piece][k-block of 8][output channel]: 16 B rows, conflict-free
+    for (int t = 0; t < g.ntaps; ++t) {
+        const int dh = g.tdh[t], dw = g.tdw[t];
+        unsigned o[MT], okb = 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+            const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+            o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 8);
+            if constexpr (PRE) o[m] >>= 3;                   // 48-byte record (8 channels x 3 pieces) of the split copy
+            if (a.dbg_flags & 1) o[m] = PRE ? (o[m] & 63u) : (o[m] & 1016u);
+            okb |= (in ? 1u : 0u) << m;
+        }
+        tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+        tab_ok[wave][t][lane] = okb;
+    }
+    const int ncb = g.Cs >> 5;                               // 32-channel steps per tap (launcher: Cs % 32 == 0)
+    const int nsteps = g.ntaps * ncb;
+    const int ntaps = g.ntaps;
+    // weight staging by group A: thread -> (k-block, output channel) of the workgroup's NT*16-channel slab
+    const int tid = threadIdx.x;
+    const bool filler = tid < NT * 64;                       // NT = 4: exactly the 256 threads of group A
+    const int f_kb = filler ? tid / (NT * 16) : 0, f_co = filler ? tid % (NT * 16) : 0;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp16) + ((long)f_kb * g.Cd + cob + f_co) * 3;
+    const int wstep = g.Cd * 4 * 3;                          // u32x4 per 32-channel step
+    int wstepi = 0;
+    u32x4 wreg[3];
+    auto wfetch = [&]() {
+        const u32x4* p = wsrc + (long)min(wstepi, nsteps - 1) * wstep;
+        wreg[0] = p[0]; wreg[1] = p[1]; wreg[2] = p[2];
+        ++wstepi;
+    };
+    auto wstore = [&](int buf) {
+        if (filler) { wl[buf][0][f_kb][f_co] = wreg[0]; wl[buf][1][f_kb][f_co] = wreg[1]; wl[buf][2][f_kb][f_co] = wreg[2]; }
+    };
+    int t_ld = 0, cb_ld = 0;
+    auto issue = [&](Raw& S) {
+        const bool live = t_ld < ntaps;
+        const int tc = live ? t_ld : ntaps - 1;
+        const uint4 o = tab_off[wave][tc][lane];
+        const unsigned okb = tab_ok[wave][tc][lane];
+        const int c32 = cb_ld * 32;
+        if constexpr (PRE) {
+            const unsigned oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const u32x4* q = src48 + (long)(oo[m] + cb_ld * 4) * 3;
+                S.pc[m][0] = q[0]; S.pc[m][1] = q[1]; S.pc[m][2] = q[2];
+            }
+        } else {
+            S.xl[0] = ldg4(a.src + o.x + c32); S.xh[0] = ldg4(a.src + o.x + c32 + 4);
+            S.xl[1] = ldg4(a.src + o.y + c32); S.xh[1] = ldg4(a.src + o.y + c32 + 4);
+            S.xl[2] = ldg4(a.src + o.z + c32); S.xh[2] = ldg4(a.src + o.z + c32 + 4);
+            S.xl[3] = ldg4(a.src + o.w + c32); S.xh[3] = ldg4(a.src + o.w + c32 + 4);
+        }
+        if constexpr (PROC == LF_PRO_BNRELU) {
+            const int c8 = c32 + kq * 8;
+            S.sc0 = ldg4(a.pro_sc + c8); S.sc1 = ldg4(a.pro_sc + c8 + 4);
+            S.sh0 = ldg4(a.pro_sh + c8); S.sh1 = ldg4(a.pro_sh + c8 + 4);
+        }
+        S.ok = live ? okb : 0u;
+        const int cbn = cb_ld + 1;
+        const bool wrap = cbn == ncb;
+        cb_ld = live ? (wrap ? 0 : cbn) : cb_ld;
+        t_ld = (live && wrap) ? t_ld + 1 : t_ld;
+    };
+    static_assert(MT == 4, "tab_off packs 4 pixel tiles");
+    static_assert(NT == 4, "group A (256 threads) stages a 64-channel weight slab");
+    static_assert(TERMS == 9 || TERMS == 6, "9 = every partial product, 6 = those above 2^-24");
+    Raw R;
+    bf16x8 xb[MT][3];
+    if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memtime();
+    if (grp == 0) wfetch();       // W[0]
+    issue(R);                     // pixels of step 0
+    if (grp == 1) __syncthreads();            // B starts one phase late
+    for (int step = 0; step < nsteps; ++step) {
+        // ---- VALU phase: split this step's pixels, start the next loads; A publishes W[step]
+        if (grp == 0) { wstore(step & 1); wfetch(); }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool in = (R.ok >> m) & 1u;
+            if constexpr (PRE) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    u32x4 r = R.pc[m][pc];
+                    r.x = in ? r.x : 0u; r.y = in ? r.y : 0u; r.z = in ? r.z : 0u; r.w = in ? r.w : 0u;
+                    xb[m][pc] = __builtin_bit_cast(bf16x8, r);
+                }
+            } else {
+                f32x4 lo = R.xl[m], hi = R.xh[m];
+                if constexpr (PROC == LF_PRO_BNRELU) { lo = max0(lo * R.sc0 + R.sh0); hi = max0(hi * R.sc1 + R.sh1); }
+                lo.x = in ? lo.x : 0.f; lo.y = in ? lo.y : 0.f; lo.z = in ? lo.z : 0.f; lo.w = in ? lo.w : 0.f;
+                hi.x = in ? hi.x : 0.f; hi.y = in ? hi.y : 0.f; hi.z = in ? hi.z : 0.f; hi.w = in ? hi.w : 0.f;
+                split3(lo, hi, xb[m][0], xb[m][1], xb[m][2]);
+            }
+        }
+        issue(R);                 // next step's pixels (clamped / masked past the end) fly during the matrix phase
+        // the split must be DONE before the barrier: without the scheduling fence hipcc sinks the whole VALU block
+        // below s_barrier (register-only code is free to move), i.e. into this group's own matrix phase
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) asm volatile("" ::"v"(xb[m][pc]));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- matrix phase (the partner group is in its VALU phase)
+        const int cur = step & 1;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wl[cur][0][kq][n * 16 + pl]);
+            const bf16x8 wm = __builtin_bit_cast(bf16x8, wl[cur][1][kq][n * 16 + pl]);
+            const bf16x8 wo = __builtin_bit_cast(bf16x8, wl[cur][2][kq][n * 16 + pl]);
+            // smallest terms first; consecutive MFMAs of one term go to four different accumulators
+            if constexpr (TERMS == 9) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][2], acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][2], acc[n][m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][0], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][2], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][0], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][0], acc[n][m], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __syncthreads();            // A pairs B's extra first barrier (B's last matrix phase)
+    if (a.dbg) {
+        asm volatile("" ::"v"(acc[0][0][0]));
+        tstamp[2] = __builtin_amdgcn_s_memtime();
+    }
+    LF_TAPGEMM_EPILOGUE
+    if (a.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp[3] = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 8;
+            d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
+        }
+    }
+}
+#undef LF_EPI_GROUPS
+#define LF_EPI_GROUPS 1
+
+// Barrier-free form of the split kernel (256 threads, 4 independent waves, no LDS for the weights): each wave streams its
+// weight pieces L1 -> VGPR just in time -- the 3 x 16 bytes of output tile n+1 are in flight during the 36 (24) MFMAs of
+// tile n -- so nothing synchronises the waves and the two waves of a SIMD drift apart on their own (one splits while the
+// other multiplies).  Measured against the LDS-staged, phase-locked form above: see DESIGN.md.
 template <int NT, int PROC, int TERMS>
-__global__ __launch_bounds__(256, 2) void tapgemm_split_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+__global__ __launch_bounds__(256, 2) void tapgemm_split_free_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     constexpr bool S16 = false, HOISTV = false;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
@@ -650,7 +877,6 @@ __global__ __launch_bounds__(256, 2) void tapgemm_split_kernel(const LfTapGeom g
     struct Raw { f32x4 xl[MT], xh[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
     __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
     __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
-    __shared__ u32x4 wl[2][3][4][NT * 16];          // [buffer][piece][k-block of 8][output channel]: 16 B rows, conflict-free
     for (int t = 0; t < g.ntaps; ++t) {
         const int dh = g.tdh[t], dw = g.tdw[t];
         unsigned o[MT], okb = 0;
@@ -660,30 +886,20 @@ __global__ __launch_bounds__(256, 2) void tapgemm_split_kernel(const LfTapGeom g
             const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
             const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
             o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 8);
+            if (a.dbg_flags & 1) o[m] &= 1016u;
             okb |= (in ? 1u : 0u) << m;
         }
         tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
         tab_ok[wave][t][lane] = okb;
     }
-    const int ncb = g.Cs >> 5;                               // 32-channel steps per tap (launcher: Cs % 32 == 0)
+    const int ncb = g.Cs >> 5;
     const int nsteps = g.ntaps * ncb;
     const int ntaps = g.ntaps;
-    // weight staging: thread -> (k-block, output channel) of the workgroup's NT*16-channel slab
-    const int tid = threadIdx.x;
-    const bool filler = tid < NT * 64;
-    const int f_kb = filler ? tid / (NT * 16) : 0, f_co = filler ? tid % (NT * 16) : 0;
-    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp16) + ((long)f_kb * g.Cd + cob + f_co) * 3;
+    // this lane's weight rows: [step][k-block kq][output channel cob + n*16 + pl][piece] -> 3 consecutive u32x4
+    const u32x4* wrow = reinterpret_cast<const u32x4*>(a.wp16) + ((long)kq * g.Cd + cob + pl) * 3;
     const int wstep = g.Cd * 4 * 3;                          // u32x4 per 32-channel step
-    int wstepi = 0;
-    u32x4 wreg[3];
-    auto wfetch = [&]() {
-        const u32x4* p = wsrc + (long)min(wstepi, nsteps - 1) * wstep;
-        wreg[0] = p[0]; wreg[1] = p[1]; wreg[2] = p[2];
-        ++wstepi;
-    };
-    auto wstore = [&](int buf) {
-        if (filler) { wl[buf][0][f_kb][f_co] = wreg[0]; wl[buf][1][f_kb][f_co] = wreg[1]; wl[buf][2][f_kb][f_co] = wreg[2]; }
-    };
+    const int wlast = (nsteps - 1) * wstep;
+    int wofs = 0;
     int t_ld = 0, cb_ld = 0;
     auto issue = [&](Raw& S) {
         const bool live = t_ld < ntaps;
@@ -706,15 +922,40 @@ __global__ __launch_bounds__(256, 2) void tapgemm_split_kernel(const LfTapGeom g
         cb_ld = live ? (wrap ? 0 : cbn) : cb_ld;
         t_ld = (live && wrap) ? t_ld + 1 : t_ld;
     };
-    static_assert(MT == 4, "tab_off packs 4 pixel tiles");
-    static_assert(TERMS == 9 || TERMS == 6, "9 = every partial product, 6 = those above 2^-24");
+    struct W3 { u32x4 h, m, l; };
+    auto wload = [&](W3& w, int ofs, int n) {
+        const u32x4* p = wrow + ofs + n * 48;                // 16 output channels further = 16 * 3 u32x4
+        w.h = p[0]; w.m = p[1]; w.l = p[2];
+    };
+    auto mma = [&](const W3& w, const bf16x8 (&xb)[MT][3], int n) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, w.h), wm = __builtin_bit_cast(bf16x8, w.m), wo = __builtin_bit_cast(bf16x8, w.l);
+        if constexpr (TERMS == 9) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][2], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][2], acc[n][m], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][0], acc[n][m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][2], acc[n][m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][0], acc[n][m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][1], acc[n][m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][0], acc[n][m], 0, 0, 0);
+    };
+    static_assert(MT == 4 && NT == 4, "tab_off packs 4 pixel tiles; the weight ring below is written for 4 output tiles");
     Raw R;
-    wfetch();
+    W3 wa, wb;
     issue(R);
-    wstore(0);
-    __syncthreads();
+    wload(wa, 0, 0);
     for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1;
         bf16x8 xb[MT][3];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -725,37 +966,13 @@ __global__ __launch_bounds__(256, 2) void tapgemm_split_kernel(const LfTapGeom g
             hi.x = in ? hi.x : 0.f; hi.y = in ? hi.y : 0.f; hi.z = in ? hi.z : 0.f; hi.w = in ? hi.w : 0.f;
             split3(lo, hi, xb[m][0], xb[m][1], xb[m][2]);
         }
-        wfetch();                 // next step's weights and pixels (clamped / masked past the end) fly during the MFMAs
-        issue(R);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, wl[cur][0][kq][n * 16 + pl]);
-            const bf16x8 wm = __builtin_bit_cast(bf16x8, wl[cur][1][kq][n * 16 + pl]);
-            const bf16x8 wo = __builtin_bit_cast(bf16x8, wl[cur][2][kq][n * 16 + pl]);
-            // smallest terms first; consecutive MFMAs of one term go to four different accumulators
-            if constexpr (TERMS == 9) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][2], acc[n][m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][1], acc[n][m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][2], acc[n][m], 0, 0, 0);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][0], acc[n][m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][2], acc[n][m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][1], acc[n][m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][0], acc[n][m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][1], acc[n][m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][0], acc[n][m], 0, 0, 0);
-        }
-        wstore(cur ^ 1);
-        __syncthreads();
+        issue(R);                                   // next step's pixels
+        const int wnext = min(wofs + wstep, wlast);
+        wload(wb, wofs, 1); mma(wa, xb, 0);
+        wload(wa, wofs, 2); mma(wb, xb, 1);
+        wload(wb, wofs, 3); mma(wa, xb, 2);
+        wload(wa, wnext, 0); mma(wb, xb, 3);        // first tile of the next step
+        wofs = wnext;
     }
     LF_TAPGEMM_EPILOGUE
 }
@@ -845,11 +1062,15 @@ int pick_nt(int Cd) {
 
 }  // namespace
 
+int g_tap_dbg_flags = 0;
+void lf_tapgemm_set_dbg_flags(int f) { g_tap_dbg_flags = f; }
 void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
 
-// launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), 16-byte aligned pixels
+// launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
+// workgroups (its two 4-wave groups each own one 256-pixel statistics row), 16-byte aligned pixels
 bool lf_tapgemm_split_ok(const LfTapGeom& g) {
-    return g.Cs % 32 == 0 && g.Cd % 64 == 0 && g.s_pix % 4 == 0 && g.s_choff % 4 == 0;
+    return g.Cs % 32 == 0 && g.Cd % 64 == 0 && g.s_pix % 4 == 0 && g.s_choff % 4 == 0 &&
+           ((long)g.N * g.Hl * g.Wl) % (2 * PIX_PER_WG) == 0;
 }
 
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
@@ -879,17 +1100,26 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
     } while (0)
     LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
-    if (a.split && a.wp48 && !a.wp16 && !a.dbg && lf_tapgemm_split_ok(g)) {
+    if (a.split && a.wp48 && !a.wp16 && lf_tapgemm_split_ok(g)) {
         LF_REQUIRE(a.split == 9 || a.split == 6, "tapgemm: split must be 9 or 6 (got %d)", a.split);
         LfTapArgs b = a;
         b.wp16 = a.wp48;
-        if (a.split == 9) {
-            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 9>), grid, dim3(256), 0, st, g, b, pro, epi);
-            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 9>), grid, dim3(256), 0, st, g, b, pro, epi);
-        } else {
-            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 6>), grid, dim3(256), 0, st, g, b, pro, epi);
-            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 6>), grid, dim3(256), 0, st, g, b, pro, epi);
-        }
+        b.dbg_flags = g_tap_dbg_flags;
+        const dim3 grid2((unsigned)(npix / (2 * PIX_PER_WG)), g.Cd / 64);     // 512-pixel workgroups (two 4-wave groups)
+        const bool pre = a.src48 && pro != LF_PRO_BNRELU && g.s_pix % 8 == 0 && g.s_choff % 8 == 0;
+#define LF_TS(TERMSV)                                                                                                      \
+    do {                                                                                                                   \
+        if (g_tapgemm_variant == 6 && !pre && !a.dbg) {                                                                    \
+            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_free_kernel<4, 1, TERMSV>), grid, dim3(256), 0, st, g, b, pro, epi); \
+            else hipLaunchKernelGGL((tapgemm_split_free_kernel<4, 0, TERMSV>), grid, dim3(256), 0, st, g, b, pro, epi);      \
+        }                                                                                                                  \
+        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, TERMSV, false>), grid2, dim3(512), 0, st, g, b, pro, epi); \
+        else if (pre) hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, TERMSV, true>), grid2, dim3(512), 0, st, g, b, pro, epi);     \
+        else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, TERMSV, false>), grid2, dim3(512), 0, st, g, b, pro, epi);             \
+    } while (0)
+        if (a.split == 9) LF_TS(9);
+        else LF_TS(6);
+#undef LF_TS
         LF_CHECK_LAUNCH("tapgemm_split");
         return 0;
     }
@@ -1514,7 +1744,24 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(const LfPackEnt
     }
 }
 
+// split copy of a whole fp32 tensor (n % 8 == 0): one 48-byte record per thread and 8 elements
+__global__ __launch_bounds__(256) void split_tensor_kernel(const float* __restrict__ x, void* __restrict__ x48, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        split_st4(x48, i * 8, ldg4(x + i * 8));
+        split_st4(x48, i * 8 + 4, ldg4(x + i * 8 + 4));
+    }
+}
+
 }  // namespace
+
+int lf_split_tensor_launch(const float* x, void* x48, long n, hipStream_t st) {
+    LF_REQUIRE(n % 8 == 0, "split_tensor: element count must be a multiple of 8 (%ld)", n);
+    long blocks = lf_cdiv(n / 8, 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(split_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, x48, n / 8);
+    LF_CHECK_LAUNCH("split_tensor");
+    return 0;
+}
 
 int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,
                            const int* tapidx_host, const float* bias_rows, int n_bias_rows, float* bias_grad,

@@ -112,10 +112,11 @@ if __name__ == "__main__" and "--phases" not in sys.argv:
     main()
 
 
-def phases(batch=32):
+def phases(batch=32, split=0):
     """Per-wave phase breakdown of the forward tap-GEMM (s_memtime stamps): prologue / main loop / epilogue."""
     import numpy as np
     lib = _lib.load()
+    lib.lf_debug_set_ops_precision(split)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for C, H, W, axis, d in [(128, 32, 64, 1, 16), (64, 64, 128, 1, 1)]:
         N = batch
@@ -132,11 +133,12 @@ def phases(batch=32):
         t = dbg.view(nw, 8).cpu().numpy().astype(np.float64)
         t0 = t[:, 0].min()
         pro, main, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
-        print("C=%d N=%d waves=%d (s_memtime ticks): start spread %.0f | prologue %.0f | main loop %.0f (min %.0f max %.0f) | "
-              "epilogue %.0f | last end - first start %.0f" % (C, N, nw, (t[:, 0] - t0).max(), pro.mean(), main.mean(), main.min(),
+        print("split=%d C=%d N=%d waves=%d (s_memtime ticks): start spread %.0f | prologue %.0f | main loop %.0f (min %.0f max %.0f) | "
+              "epilogue %.0f | last end - first start %.0f" % (split, C, N, nw, (t[:, 0] - t0).max(), pro.mean(), main.mean(), main.min(),
                                                                main.max(), epi.mean(), t[:, 3].max() - t0), flush=True)
 
 
 if __name__ == "__main__" and "--phases" in sys.argv:
+    sp = int(sys.argv[sys.argv.index("--split") + 1]) if "--split" in sys.argv else 0
     for nb in (16, 32, 64):
-        phases(nb)
+        phases(nb, sp)
