@@ -281,6 +281,24 @@ def main():
                           "global_batch": world * B, "parallelism": "dp%d" % world,
                           "grad_allreduce": "flat fp32 bucket, RCCL" if world > 1 else "none"},
                "roofline": roofline}
+        if world == 1 and a.precision == "fp32":
+            # not the headline: the same step with the 64- / 128-channel conv products formed on the bf16 matrix cores
+            # from exact 3-way splits of both fp32 operands (all 9 partial products, fp32 accumulation)
+            model.net.precision = "fp32x9"
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            model.net.precision = a.precision
+            out["fp32_split_x9"] = {"value": round(B * a.steps / dts, 2), "unit": "images/sec",
+                                    "ms_per_step": round(1e3 * dts / a.steps, 3),
+                                    "note": "same workload, precision mode fp32x9 (fp32 tensors and accumulation, exact "
+                                            "products via bf16 x3 splits on the bf16 matrix cores; weight gradient on the "
+                                            "fp32 cores); parity tests hold it to the fp32 tolerances"}
         if world == 1 and not a.no_cpu_baseline and a.workload == "bev":
             out["cpu_baseline"] = cpu_baseline()
             out["parity"] = lane_coeff_parity(model, x)

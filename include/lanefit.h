@@ -262,17 +262,10 @@ int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, 
                          int axis, int dilation, float* scratch, void* stream);
 /* kernel A/B switch used by tools/kbench.py only (1, 2 = default, 4: see lf_conv.hip) */
 void lf_debug_set_tapgemm_variant(int v);
-/* timing experiments only (results are wrong): 1 = the split kernel's pixel operand loads all hit one 4 KB region */
-void lf_debug_set_tap_flags(int flags);
 /* precision mode of the lf_conv1d_* calls (kernel-level parity tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32
  * tensors, 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src hold bf16; w, bias, gw, gb stay fp32),
  * 9 / 6 fp32 tensors and fp32-accurate results from 3-way split operands on the bf16 matrix cores (9 or 6 partial products) */
 void lf_debug_set_ops_precision(int mode);
-/* modes 9 / 6 (fp32 from 3-way split operands on the bf16 matrix cores): hand the next lf_conv1d_fwd / lf_conv1d_bwd_data
- * calls a split copy of their source (or NULL) and a buffer that receives the split copy of their result (or NULL);
- * a split copy holds 6 bytes per element: [pixel][channel / 8][piece h, m, l][8] bf16 with h + m + l == value exactly */
-void lf_debug_set_ops_split_copies(const void* src48, void* dst48);
-int lf_debug_split_tensor(const float* x, void* x48, long n, void* stream);
 /* lf_conv1d_fwd + per-wave s_memtime stamps (start, tap table built, main loop done, stores retired; 8 words/wave) */
 int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C,
                                int axis, int dilation, float* scratch, unsigned long long* dbg, void* stream);

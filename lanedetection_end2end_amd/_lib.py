@@ -71,10 +71,7 @@ def _declare(lib):
         "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_weight": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_debug_set_tapgemm_variant": (None, [I]),
-        "lf_debug_set_tap_flags": (None, [I]),
         "lf_debug_set_ops_precision": (None, [I]),
-        "lf_debug_set_ops_split_copies": (None, [P, P]),
-        "lf_debug_split_tensor": (I, [P, P, L, P]),
         "lf_erfnet_set_precision": (I, [P, I]),
         "lf_debug_conv1d_fwd_phases": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P]),
         "lf_erfnet_profile": (I, [P, I]),

@@ -40,9 +40,6 @@ struct LfTapArgs {
     int split;              // 9 or 6: fp32 on the bf16 matrix cores from 3-way split operands (tapgemm_split_kernel);
     const void* wp48;       //   its weights, split by the pack kernel: bf16 [tap][Cs/8][Cd][3][8]; launches the split
                             //   kernel cannot take (Cs % 32, Cd % 64) fall back to the fp32 matrix cores (wp)
-    const void* src48;      //   optional split copy of src (same geometry; [pixel][channel/8][3][8] bf16, piece h, m, l):
-                            //   when its producer wrote one the kernel loads operand pieces instead of splitting fp32 values
-    void* dst48;            //   optional: also write the result as a split copy (for the consumers of dst)
     const float* bias;      // [Cd] or null
     float* dst;
     const float* pro_sc;    // prologue BN scale / shift per source channel
@@ -56,11 +53,9 @@ struct LfTapArgs {
     const float* ash;
     const float* dm;        // optional Dropout2d keep-mask [N][Cd] applied to the STATS_XHAT sums only (gm = v * dm)
     float* stats;           // [rows][2][Cd] per-workgroup partial sums, rows = lf_tapgemm_stat_rows()
-    int dbg_flags;          // timing experiments only (results are wrong): 1 = every pixel operand load hits one 4 KB region
     unsigned long long* dbg;  // optional: per-wave phase timestamps (s_memtime), 8 words per wave (tools/kbench.py --phases)
 };
 
-void lf_tapgemm_set_dbg_flags(int f);
 void lf_tapgemm_set_variant(int v);   // kernel A/B switch for tools/kbench.py (1, 2 = default, 4)
 int lf_tapgemm_stat_rows(const LfTapGeom& g);
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);
@@ -105,7 +100,5 @@ long lf_pack_bf16_elems(int Kc, int Nc, int ntaps);
 int lf_pack_weights_split_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, void* arena48,
                                  hipStream_t st);
 bool lf_tapgemm_split_ok(const LfTapGeom& g);
-// x48 = split copy of the fp32 tensor x (n elements, n % 8 == 0; 6 bytes per element)
-int lf_split_tensor_launch(const float* x, void* x48, long n, hipStream_t st);
 int lf_pack_weights_bf16_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, void* arena16,
                                 hipStream_t st);

@@ -60,18 +60,6 @@ __device__ __forceinline__ unsigned split_pair(f32x2& v) {
     v.y -= __uint_as_float(u & 0xffff0000u);
     return u;
 }
-// split copy of a tensor: [pixel][channel / 8][piece h, m, l][8] bf16 (48-byte records), v == h + m + l exactly.
-// Stores the 3 x 4 pieces of channels off .. off+3 (off % 4 == 0, in elements from the tensor base).
-__device__ __forceinline__ void split_st4(void* base48, long off, f32x4 v) {
-    f32x2 p0 = {v.x, v.y}, p1 = {v.z, v.w};
-    uint2 h, m, l;
-    h.x = split_pair(p0); h.y = split_pair(p1);
-    m.x = split_pair(p0); m.y = split_pair(p1);
-    l.x = __builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf16x2));
-    l.y = __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf16x2));
-    char* q = reinterpret_cast<char*>(base48) + (off >> 3) * 48 + ((off & 4) << 1);
-    *reinterpret_cast<uint2*>(q) = h; *reinterpret_cast<uint2*>(q + 16) = m; *reinterpret_cast<uint2*>(q + 32) = l;
-}
 // sum over the 16 lanes that share l>>4 (xor 1,2,4,8 stays inside the 16-lane group)
 __device__ __forceinline__ float sum16(float v) {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
@@ -116,7 +104,6 @@ _Pragma("unroll") \
             if (epi & LF_EPI_RELU) v = max0(v); \
             if (S16) v = round_bf16(v);   /* statistics are taken from the values as stored */ \
             if (pv[m]) epi_st<S16>(a.dst, dbase + n * 16, v); \
-            if (!S16 && a.dst48 && pv[m]) split_st4(a.dst48, dbase + n * 16, v); \
             if (!pv[m]) v = zero4(); \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
@@ -643,7 +630,7 @@ __device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& h
 // the idle LDS buffer during A's split phase (B is reading W[s-1]'s successor W[s] from the other one).
 #undef LF_EPI_GROUPS
 #define LF_EPI_GROUPS 2
-template <int NT, int PROC, int TERMS, bool PRE>
+template <int NT, int PROC, int TERMS>
 __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     constexpr bool S16 = false, HOISTV = false;
     constexpr int WAVES = 8;
@@ -676,11 +663,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
 
-    // PRE: the source has a split copy (LfTapArgs::src48, written by its producer): a lane's operand pieces are three
-    // 16-byte loads and there is nothing to compute; otherwise 8 fp32 values are loaded and split here
-    struct Raw { f32x4 xl[PRE ? 1 : MT], xh[PRE ? 1 : MT]; u32x4 pc[PRE ? MT : 1][3]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
-    static_assert(!(PRE && PROC == LF_PRO_BNRELU), "the BN + ReLU prologue needs the fp32 values");
-    const u32x4* src48 = reinterpret_cast<const u32x4*>(a.src48);
+    struct Raw { f32x4 xl[MT], xh[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
     __shared__ uint4 tab_off[WAVES][LF_MAX_TAPS][64];
     __shared__ unsigned tab_ok[WAVES][LF_MAX_TAPS][64];
     __shared__ u32x4 wl[2][3][4][NT * 16];          // [buffer][piece][k-block of 8][output channel]: 16 B rows, conflict-free
@@ -693,8 +676,6 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
             const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
             const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
             o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 8);
-            if constexpr (PRE) o[m] >>= 3;                   // 48-byte record (8 channels x 3 pieces) of the split copy
-            if (a.dbg_flags & 1) o[m] = PRE ? (o[m] & 63u) : (o[m] & 1016u);
             okb |= (in ? 1u : 0u) << m;
         }
         tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -726,19 +707,10 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
         const uint4 o = tab_off[wave][tc][lane];
         const unsigned okb = tab_ok[wave][tc][lane];
         const int c32 = cb_ld * 32;
-        if constexpr (PRE) {
-            const unsigned oo[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const u32x4* q = src48 + (long)(oo[m] + cb_ld * 4) * 3;
-                S.pc[m][0] = q[0]; S.pc[m][1] = q[1]; S.pc[m][2] = q[2];
-            }
-        } else {
-            S.xl[0] = ldg4(a.src + o.x + c32); S.xh[0] = ldg4(a.src + o.x + c32 + 4);
-            S.xl[1] = ldg4(a.src + o.y + c32); S.xh[1] = ldg4(a.src + o.y + c32 + 4);
-            S.xl[2] = ldg4(a.src + o.z + c32); S.xh[2] = ldg4(a.src + o.z + c32 + 4);
-            S.xl[3] = ldg4(a.src + o.w + c32); S.xh[3] = ldg4(a.src + o.w + c32 + 4);
-        }
+        S.xl[0] = ldg4(a.src + o.x + c32); S.xh[0] = ldg4(a.src + o.x + c32 + 4);
+        S.xl[1] = ldg4(a.src + o.y + c32); S.xh[1] = ldg4(a.src + o.y + c32 + 4);
+        S.xl[2] = ldg4(a.src + o.z + c32); S.xh[2] = ldg4(a.src + o.z + c32 + 4);
+        S.xl[3] = ldg4(a.src + o.w + c32); S.xh[3] = ldg4(a.src + o.w + c32 + 4);
         if constexpr (PROC == LF_PRO_BNRELU) {
             const int c8 = c32 + kq * 8;
             S.sc0 = ldg4(a.pro_sc + c8); S.sc1 = ldg4(a.pro_sc + c8 + 4);
@@ -762,24 +734,22 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
     for (int step = 0; step < nsteps; ++step) {
         // ---- VALU phase: split this step's pixels, start the next loads; A publishes W[step]
         if (grp == 0) { wstore(step & 1); wfetch(); }
+        if constexpr (PROC == LF_PRO_BNRELU) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const bool in = (R.ok >> m) & 1u;
-            if constexpr (PRE) {
+            for (int m = 0; m < MT; ++m) { R.xl[m] = max0(R.xl[m] * R.sc0 + R.sh0); R.xh[m] = max0(R.xh[m] * R.sc1 + R.sh1); }
+        }
+        if (__builtin_amdgcn_ballot_w64(R.ok != 15u) != 0ull) {      // wave-uniform: only tiles that touch the padding mask
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    u32x4 r = R.pc[m][pc];
-                    r.x = in ? r.x : 0u; r.y = in ? r.y : 0u; r.z = in ? r.z : 0u; r.w = in ? r.w : 0u;
-                    xb[m][pc] = __builtin_bit_cast(bf16x8, r);
-                }
-            } else {
+            for (int m = 0; m < MT; ++m) {
+                const bool in = (R.ok >> m) & 1u;
                 f32x4 lo = R.xl[m], hi = R.xh[m];
-                if constexpr (PROC == LF_PRO_BNRELU) { lo = max0(lo * R.sc0 + R.sh0); hi = max0(hi * R.sc1 + R.sh1); }
                 lo.x = in ? lo.x : 0.f; lo.y = in ? lo.y : 0.f; lo.z = in ? lo.z : 0.f; lo.w = in ? lo.w : 0.f;
                 hi.x = in ? hi.x : 0.f; hi.y = in ? hi.y : 0.f; hi.z = in ? hi.z : 0.f; hi.w = in ? hi.w : 0.f;
-                split3(lo, hi, xb[m][0], xb[m][1], xb[m][2]);
+                R.xl[m] = lo; R.xh[m] = hi;
             }
         }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) split3(R.xl[m], R.xh[m], xb[m][0], xb[m][1], xb[m][2]);
         issue(R);                 // next step's pixels (clamped / masked past the end) fly during the matrix phase
         // the split must be DONE before the barrier: without the scheduling fence hipcc sinks the whole VALU block
         // below s_barrier (register-only code is free to move), i.e. into this group's own matrix phase
@@ -840,142 +810,6 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
 }
 #undef LF_EPI_GROUPS
 #define LF_EPI_GROUPS 1
-
-// Barrier-free form of the split kernel (256 threads, 4 independent waves, no LDS for the weights): each wave streams its
-// weight pieces L1 -> VGPR just in time -- the 3 x 16 bytes of output tile n+1 are in flight during the 36 (24) MFMAs of
-// tile n -- so nothing synchronises the waves and the two waves of a SIMD drift apart on their own (one splits while the
-// other multiplies).  Measured against the LDS-staged, phase-locked form above: see DESIGN.md.
-template <int NT, int PROC, int TERMS>
-__global__ __launch_bounds__(256, 2) void tapgemm_split_free_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
-    constexpr bool S16 = false, HOISTV = false;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pl = lane & 15, kq = lane >> 4;
-    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
-    const int cob = blockIdx.y * NT * 16;
-    unsigned bx = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
-    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
-
-    int pn[MT], pi[MT], pj[MT];
-    bool pv[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const unsigned p = tile0 + m * 16 + pl;
-        pv[m] = p < npix;
-        const unsigned q = pv[m] ? p : 0u;
-        const unsigned r = q / (unsigned)g.Wl;
-        pj[m] = (int)(q - r * (unsigned)g.Wl);
-        pn[m] = (int)(r / (unsigned)g.Hl);
-        pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
-    }
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
-
-    struct Raw { f32x4 xl[MT], xh[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
-    __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
-    __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
-    for (int t = 0; t < g.ntaps; ++t) {
-        const int dh = g.tdh[t], dw = g.tdw[t];
-        unsigned o[MT], okb = 0;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
-            const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-            const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-            o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 8);
-            if (a.dbg_flags & 1) o[m] &= 1016u;
-            okb |= (in ? 1u : 0u) << m;
-        }
-        tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
-        tab_ok[wave][t][lane] = okb;
-    }
-    const int ncb = g.Cs >> 5;
-    const int nsteps = g.ntaps * ncb;
-    const int ntaps = g.ntaps;
-    // this lane's weight rows: [step][k-block kq][output channel cob + n*16 + pl][piece] -> 3 consecutive u32x4
-    const u32x4* wrow = reinterpret_cast<const u32x4*>(a.wp16) + ((long)kq * g.Cd + cob + pl) * 3;
-    const int wstep = g.Cd * 4 * 3;                          // u32x4 per 32-channel step
-    const int wlast = (nsteps - 1) * wstep;
-    int wofs = 0;
-    int t_ld = 0, cb_ld = 0;
-    auto issue = [&](Raw& S) {
-        const bool live = t_ld < ntaps;
-        const int tc = live ? t_ld : ntaps - 1;
-        const uint4 o = tab_off[wave][tc][lane];
-        const unsigned okb = tab_ok[wave][tc][lane];
-        const int c32 = cb_ld * 32;
-        S.xl[0] = ldg4(a.src + o.x + c32); S.xh[0] = ldg4(a.src + o.x + c32 + 4);
-        S.xl[1] = ldg4(a.src + o.y + c32); S.xh[1] = ldg4(a.src + o.y + c32 + 4);
-        S.xl[2] = ldg4(a.src + o.z + c32); S.xh[2] = ldg4(a.src + o.z + c32 + 4);
-        S.xl[3] = ldg4(a.src + o.w + c32); S.xh[3] = ldg4(a.src + o.w + c32 + 4);
-        if constexpr (PROC == LF_PRO_BNRELU) {
-            const int c8 = c32 + kq * 8;
-            S.sc0 = ldg4(a.pro_sc + c8); S.sc1 = ldg4(a.pro_sc + c8 + 4);
-            S.sh0 = ldg4(a.pro_sh + c8); S.sh1 = ldg4(a.pro_sh + c8 + 4);
-        }
-        S.ok = live ? okb : 0u;
-        const int cbn = cb_ld + 1;
-        const bool wrap = cbn == ncb;
-        cb_ld = live ? (wrap ? 0 : cbn) : cb_ld;
-        t_ld = (live && wrap) ? t_ld + 1 : t_ld;
-    };
-    struct W3 { u32x4 h, m, l; };
-    auto wload = [&](W3& w, int ofs, int n) {
-        const u32x4* p = wrow + ofs + n * 48;                // 16 output channels further = 16 * 3 u32x4
-        w.h = p[0]; w.m = p[1]; w.l = p[2];
-    };
-    auto mma = [&](const W3& w, const bf16x8 (&xb)[MT][3], int n) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, w.h), wm = __builtin_bit_cast(bf16x8, w.m), wo = __builtin_bit_cast(bf16x8, w.l);
-        if constexpr (TERMS == 9) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][2], acc[n][m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][1], acc[n][m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][2], acc[n][m], 0, 0, 0);
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][0], acc[n][m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][2], acc[n][m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][1], acc[n][m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][0], acc[n][m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][1], acc[n][m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb[m][0], acc[n][m], 0, 0, 0);
-    };
-    static_assert(MT == 4 && NT == 4, "tab_off packs 4 pixel tiles; the weight ring below is written for 4 output tiles");
-    Raw R;
-    W3 wa, wb;
-    issue(R);
-    wload(wa, 0, 0);
-    for (int step = 0; step < nsteps; ++step) {
-        bf16x8 xb[MT][3];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const bool in = (R.ok >> m) & 1u;
-            f32x4 lo = R.xl[m], hi = R.xh[m];
-            if constexpr (PROC == LF_PRO_BNRELU) { lo = max0(lo * R.sc0 + R.sh0); hi = max0(hi * R.sc1 + R.sh1); }
-            lo.x = in ? lo.x : 0.f; lo.y = in ? lo.y : 0.f; lo.z = in ? lo.z : 0.f; lo.w = in ? lo.w : 0.f;
-            hi.x = in ? hi.x : 0.f; hi.y = in ? hi.y : 0.f; hi.z = in ? hi.z : 0.f; hi.w = in ? hi.w : 0.f;
-            split3(lo, hi, xb[m][0], xb[m][1], xb[m][2]);
-        }
-        issue(R);                                   // next step's pixels
-        const int wnext = min(wofs + wstep, wlast);
-        wload(wb, wofs, 1); mma(wa, xb, 0);
-        wload(wa, wofs, 2); mma(wb, xb, 1);
-        wload(wb, wofs, 3); mma(wa, xb, 2);
-        wload(wa, wnext, 0); mma(wb, xb, 3);        // first tile of the next step
-        wofs = wnext;
-    }
-    LF_TAPGEMM_EPILOGUE
-}
 
 // Lean variant for 16-output-channel launches (the 128x256 stage, ~3 % of the FLOPs): these are HBM-bound
 // (0.75*C = 12 FLOP/B), so the goal is bytes in flight, not MFMA issue: no operand ring, few registers,
@@ -1062,8 +896,6 @@ int pick_nt(int Cd) {
 
 }  // namespace
 
-int g_tap_dbg_flags = 0;
-void lf_tapgemm_set_dbg_flags(int f) { g_tap_dbg_flags = f; }
 void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
 
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
@@ -1104,22 +936,14 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         LF_REQUIRE(a.split == 9 || a.split == 6, "tapgemm: split must be 9 or 6 (got %d)", a.split);
         LfTapArgs b = a;
         b.wp16 = a.wp48;
-        b.dbg_flags = g_tap_dbg_flags;
         const dim3 grid2((unsigned)(npix / (2 * PIX_PER_WG)), g.Cd / 64);     // 512-pixel workgroups (two 4-wave groups)
-        const bool pre = a.src48 && pro != LF_PRO_BNRELU && g.s_pix % 8 == 0 && g.s_choff % 8 == 0;
-#define LF_TS(TERMSV)                                                                                                      \
-    do {                                                                                                                   \
-        if (g_tapgemm_variant == 6 && !pre && !a.dbg) {                                                                    \
-            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_free_kernel<4, 1, TERMSV>), grid, dim3(256), 0, st, g, b, pro, epi); \
-            else hipLaunchKernelGGL((tapgemm_split_free_kernel<4, 0, TERMSV>), grid, dim3(256), 0, st, g, b, pro, epi);      \
-        }                                                                                                                  \
-        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, TERMSV, false>), grid2, dim3(512), 0, st, g, b, pro, epi); \
-        else if (pre) hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, TERMSV, true>), grid2, dim3(512), 0, st, g, b, pro, epi);     \
-        else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, TERMSV, false>), grid2, dim3(512), 0, st, g, b, pro, epi);             \
-    } while (0)
-        if (a.split == 9) LF_TS(9);
-        else LF_TS(6);
-#undef LF_TS
+        if (a.split == 9) {
+            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 9>), grid2, dim3(512), 0, st, g, b, pro, epi);
+            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 9>), grid2, dim3(512), 0, st, g, b, pro, epi);
+        } else {
+            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 6>), grid2, dim3(512), 0, st, g, b, pro, epi);
+            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 6>), grid2, dim3(512), 0, st, g, b, pro, epi);
+        }
         LF_CHECK_LAUNCH("tapgemm_split");
         return 0;
     }
@@ -1744,24 +1568,7 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(const LfPackEnt
     }
 }
 
-// split copy of a whole fp32 tensor (n % 8 == 0): one 48-byte record per thread and 8 elements
-__global__ __launch_bounds__(256) void split_tensor_kernel(const float* __restrict__ x, void* __restrict__ x48, long n8) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        split_st4(x48, i * 8, ldg4(x + i * 8));
-        split_st4(x48, i * 8 + 4, ldg4(x + i * 8 + 4));
-    }
-}
-
 }  // namespace
-
-int lf_split_tensor_launch(const float* x, void* x48, long n, hipStream_t st) {
-    LF_REQUIRE(n % 8 == 0, "split_tensor: element count must be a multiple of 8 (%ld)", n);
-    long blocks = lf_cdiv(n / 8, 256);
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(split_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, x48, n / 8);
-    LF_CHECK_LAUNCH("split_tensor");
-    return 0;
-}
 
 int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,
                            const int* tapidx_host, const float* bias_rows, int n_bias_rows, float* bias_grad,

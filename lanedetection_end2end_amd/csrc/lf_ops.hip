@@ -58,8 +58,6 @@ __global__ __launch_bounds__(256) void pack_one_split_kernel(const float* __rest
     }
 }
 
-const void* g_ops_src48 = nullptr;   // split copies handed to the next lf_conv1d_fwd / lf_conv1d_bwd_data (split modes)
-void* g_ops_dst48 = nullptr;
 int g_ops_bf16 = 0;     // 0 fp32 cores, 1 / 2 bf16 cores (fp32 / bf16 tensors), 9 / 6 fp32 from split operands on the bf16 cores
 
 // pack into scratch in the order the selected kernel wants; returns the LfTapArgs weight fields
@@ -71,8 +69,6 @@ void pack_conv1d(LfTapArgs& a, const float* w, float* scratch, int C, long sk, l
                                C, C, 3, sk, sn, flip);
             a.split = g_ops_bf16;
             a.wp48 = scratch + 3L * C * C;
-            a.src48 = g_ops_src48;
-            a.dst48 = g_ops_dst48;
         }
     } else if (g_ops_bf16) {
         hipLaunchKernelGGL(pack_one_bf16_kernel, dim3(64), dim3(256), 0, st, w, reinterpret_cast<__bf16*>(scratch), C, C, 3, sk, sn, flip);
@@ -98,15 +94,9 @@ LfTapGeom conv1d_geom(int N, int H, int W, int C, int axis, int d) {
 extern "C" {
 
 void lf_debug_set_tapgemm_variant(int v) { lf_tapgemm_set_variant(v); }
-// timing experiments (wrong results): 1 = pixel operand loads of the split kernel all hit one 4 KB region
-void lf_debug_set_tap_flags(int f) { lf_tapgemm_set_dbg_flags(f); }
 // precision mode of the kernel-level conv1d calls below (tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32 tensors,
 // 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src then hold bf16 elements; w, bias, gw, gb stay fp32)
 void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = mode; }
-// split modes: optional split copy of the source of / for the result of the next lf_conv1d_fwd / lf_conv1d_bwd_data calls
-void lf_debug_set_ops_split_copies(const void* src48, void* dst48) { g_ops_src48 = src48; g_ops_dst48 = dst48; }
-// x48 = split copy of x (n fp32 elements, 6 bytes each in x48)
-int lf_debug_split_tensor(const float* x, void* x48, long n, void* stream) { return lf_split_tensor_launch(x, x48, n, (hipStream_t)stream); }
 
 // same as lf_conv1d_fwd with per-wave phase timestamps: dbg receives 8 uint64 per wave
 // (start, tap table built, main loop done, stores retired); waves = ceil(N*H*W/256)*4*(C/64)

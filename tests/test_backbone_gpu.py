@@ -98,13 +98,17 @@ def fetch_all(net, plan, ws, N, H, W):
     return out
 
 
-@pytest.mark.parametrize("out_channels", [2, 4])
-def test_backbone_vs_golden_and_grads(golden_backbone, out_channels):
+@pytest.mark.parametrize("out_channels,precision", [(2, "fp32"), (4, "fp32"), (2, "fp32x9"), (2, "fp32x6")])
+def test_backbone_vs_golden_and_grads(golden_backbone, out_channels, precision):
     """Forward vs the fp64 oracle / the reference goldens at the fp32 noise floor; backward SHARPLY:
     the fp64 oracle is evaluated straight-through at the engine's own forward state (same ReLU masks,
-    pool arg-maxes and saved tensors), so gradient differences are backward arithmetic only."""
-    N, H, W = 2, 64, 128
+    pool arg-maxes and saved tensors), so gradient differences are backward arithmetic only.
+    The split modes (fp32 products formed from 3-way bf16 splits on the bf16 matrix cores) are held to the SAME
+    tolerances as the fp32 matrix cores; batch 4 so that every 64- and 128-channel layer is a whole number of the split
+    kernel's 512-pixel workgroups."""
+    N, H, W = (2 if precision == "fp32" else 4), 64, 128
     net, P = build(out_channels=out_channels)
+    net.precision = precision
     for m in net.modules():
         if isinstance(m, torch.nn.Dropout2d):
             m.p = 0
@@ -116,7 +120,7 @@ def test_backbone_vs_golden_and_grads(golden_backbone, out_channels):
     (dec * gy.cuda()).sum().backward()
     enc64, dec64, _, stats, _ = run_oracle(x, P, torch.float64)
     _, dec32, _, _, _ = run_oracle(x, P, torch.float32)
-    if out_channels == 2:
+    if out_channels == 2 and N == 2:
         assert relerr(dec64.detach(), golden_backbone["bb_train_dec_f64"]) < 1e-9      # oracle == reference
         print("logits |hip - reference fp32| %.2e" % relerr(dec.detach().cpu(), golden_backbone["bb_train_dec_f32"]))
     e = relerr(dec.detach().cpu(), dec64.detach())
@@ -151,8 +155,9 @@ def test_backbone_vs_golden_and_grads(golden_backbone, out_channels):
         worst = max(worst, e)
         if e > 2e-4:
             bad.append((k, e))
-    print("worst parameter-gradient error vs straight-through fp64 oracle: %.2e" % worst)
+    print("[%s] worst parameter-gradient error vs straight-through fp64 oracle: %.2e" % (precision, worst))
     assert not bad, bad
+    assert worst < 2e-5         # measured 3.5e-6 (fp32 matrix cores), the split modes are held to the same bound
 
 
 def test_eval_mode_and_no_grad(golden_backbone):
@@ -519,6 +524,49 @@ def test_bf16_tensor_mode_kernel_parity():
             e3, e4 = relerr(gw.view_as(w4).cpu(), wref.cpu()), relerr(gb.cpu(), gn.sum((0, 2, 3)).cpu())
             print("bf16 tensors C=%d axis %d dil %d: fwd/dgrad within 1 bf16 ulp, wgrad %.1e bias %.1e" % (C, axis, d, e3, e4))
             assert e3 < 3e-6 and e4 < 3e-6
+    finally:
+        lib.lf_debug_set_ops_precision(0)
+
+
+def test_split_mode_kernel_parity():
+    """Precision modes "fp32x9" / "fp32x6": fp32 tensors, fp32 accumulation, every product formed on the bf16 matrix
+    cores from exact 3-way splits of both operands (9 = all partial products, 6 = those above 2^-24).  Contract: as close
+    to the exact (fp64) convolution as the fp32 matrix cores are -- checked per kernel against the SAME launch in mode 0,
+    on inputs with a wide dynamic range, with the ReLU / mask epilogues."""
+    import torch.nn.functional as F
+    from lanedetection_end2end_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    try:
+        for (C, H, W, axis, d) in ((128, 16, 32, 0, 4), (128, 16, 32, 1, 16), (64, 16, 32, 0, 1), (64, 16, 32, 1, 2)):
+            N = 4                                       # N*H*W is a multiple of 512: the split kernel takes the launch
+            torch.manual_seed(C + axis)
+            x = torch.randn(N, H, W, C, device="cuda") * torch.exp(2 * torch.randn(N, H, W, C, device="cuda"))
+            gy = torch.randn(N, H, W, C, device="cuda") * torch.exp(2 * torch.randn(N, H, W, C, device="cuda"))
+            w = torch.randn(C, C, 3, device="cuda") * (2.0 / (3 * C)) ** 0.5
+            b = torch.randn(C, device="cuda")
+            scratch = torch.full((lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096,), float("nan"), device="cuda")
+            w4 = w.view(C, C, 3, 1) if axis == 0 else w.view(C, C, 1, 3)
+            pad, dil = ((d, 0), (d, 1)) if axis == 0 else ((0, d), (1, d))
+            xn = x.permute(0, 3, 1, 2).contiguous()
+            gn = gy.permute(0, 3, 1, 2).contiguous()
+            ref = torch.relu(F.conv2d(xn.double(), w4.double(), b.double(), padding=pad, dilation=dil))
+            gref = torch.nn.grad.conv2d_input(xn.shape, w4.double(), gn.double(), padding=pad, dilation=dil) * (xn > 0)
+            err = {}
+            for mode in (0, 9, 6):
+                lib.lf_debug_set_ops_precision(mode)
+                y, gx = torch.empty_like(x), torch.empty_like(x)
+                _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 1, P(scratch), st), "fwd")
+                _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), P(x), P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
+                err[mode] = (relerr(y.permute(0, 3, 1, 2).cpu(), ref.cpu()), relerr(gx.permute(0, 3, 1, 2).cpu(), gref.cpu()),
+                             y.clone())
+            print("split C=%d axis %d dil %d: fwd/dgrad error vs fp64  fp32 cores %.1e %.1e | x9 %.1e %.1e | x6 %.1e %.1e"
+                  % (C, axis, d, err[0][0], err[0][1], err[9][0], err[9][1], err[6][0], err[6][1]))
+            for mode in (9, 6):
+                assert err[mode][0] < 1.25 * err[0][0] + 1e-7 and err[mode][1] < 1.25 * err[0][1] + 1e-7
+                assert err[mode][0] < 2e-6 and err[mode][1] < 2e-6
+            assert not torch.equal(err[9][2], err[0][2])          # the split kernel really ran (different rounding order)
     finally:
         lib.lf_debug_set_ops_precision(0)
 
