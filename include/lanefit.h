@@ -137,7 +137,12 @@ void lf_erfnet_plan_destroy(lf_erfnet_plan* plan);
  * reference for it -- the reference is fp32 only): 0 = fp32 MFMA (default; the parity path), 1 = operands
  * rounded to bf16 (RNE) in registers, v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 tensors in HBM,
  * 2 = mode 1 with every activation / gradient tensor of the workspace stored as bf16 (weight gradient on the fp32
- * matrix cores from widened operands; parameters, their gradients, BN statistics, logits stay fp32). */
+ * matrix cores from widened operands; parameters, their gradients, BN statistics, logits stay fp32),
+ * 3 / 4 = fp32 results on the bf16 matrix cores: tensors and accumulation as in mode 0, but every product of the 64- and
+ * 128-channel convolutions and data gradients is formed from exact 3-way bf16 splits of both fp32 operands (3 = all 9
+ * partial products, i.e. exact products; 4 = the 6 above 2^-24); parity as mode 0 (tests/test_backbone_gpu.py); launches
+ * the split kernel cannot take (other channel counts, pixel counts not a multiple of 512) and the weight gradient run
+ * on the fp32 matrix cores. */
 int lf_erfnet_set_precision(const lf_erfnet_plan* plan, int mode);
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* plan);
 int lf_erfnet_num_params(const lf_erfnet_plan* plan);

@@ -213,8 +213,10 @@ class Net(nn.Module):
         self._flat_grad = None
         # precision mode: "fp32" (default, the parity path); "bf16_mfma" (conv operands rounded to bf16 in registers,
         # fp32 accumulation, fp32 tensors); "bf16" (bf16 matrix cores AND bf16 activation / gradient tensors in HBM;
-        # BASELINE config 3 -- the reference has no such mode).  Parameters, their gradients and the logits are fp32
-        # in every mode.
+        # BASELINE config 3 -- the reference has no such mode); "fp32x9" / "fp32x6" (fp32 tensors and accumulation, the
+        # products of the 64- / 128-channel convs formed on the bf16 matrix cores from exact 3-way bf16 splits of both
+        # operands: all 9 partial products, or the 6 above 2^-24 -- fp32 accuracy, held to the fp32 tolerances by the
+        # tests).  Parameters, their gradients and the logits are fp32 in every mode.
         self.precision = "fp32"
         # encoder_output (N,128,H/8,W/8) is part of the return tuple (zero-copy view); wrappers that never read it
         # may switch it off
