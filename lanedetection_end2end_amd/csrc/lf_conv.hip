@@ -14,6 +14,7 @@
 // fp32 MFMA runs at the vector rate (157 TF), 1/16 of bf16, so one dwordx4 per operand tile per
 // 16 MFMAs (512 cycles) is far below what the load path sustains.
 #include <stdlib.h>
+#include <string.h>
 
 #include "lf_conv.h"
 #include "lf_types.h"
@@ -1482,6 +1483,59 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
 }
 
+struct ReduceBatch { LfReduceJob j[LF_REDUCE_BATCH]; };
+constexpr int RB_BLOCKS = 48;            // workgroups per job (grid-stride over its ntaps*Cs*Cd outputs, then its bias)
+
+// same arithmetic and summation order as wgrad_reduce_kernel (bitwise identical results), job = blockIdx.x / RB_BLOCKS
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceBatch B) {
+    constexpr int SG = 16;
+    __shared__ float sw[SG][64];
+    const LfReduceJob& J = B.j[blockIdx.x / RB_BLOCKS];
+    const int blk = blockIdx.x % RB_BLOCKS;
+    const int og = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const float* __restrict__ partial = J.partial;
+    const long per = (long)J.ntaps * J.Cs * J.Cd;
+    const int splits = J.splits, Cd = J.Cd, Cs = J.Cs;
+    for (long base = (long)blk * 64; base < per; base += (long)RB_BLOCKS * 64) {
+        const long i = base + og;
+        float s0 = 0.f, s1 = 0.f;
+        if (i < per) {
+            int r = sg;
+            for (; r + SG < splits; r += 2 * SG) { s0 += partial[(long)r * per + i]; s1 += partial[(long)(r + SG) * per + i]; }
+            for (; r < splits; r += SG) s0 += partial[(long)r * per + i];
+        }
+        sw[sg][og] = s0 + s1;
+        __syncthreads();
+        if (sg == 0 && i < per) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < SG; ++k) v += sw[k][og];
+            const int n = (int)(i % Cd);
+            const long r2 = i / Cd;
+            const int k2 = (int)(r2 % Cs), t = (int)(r2 / Cs);
+            J.grad[k2 * J.sk + n * J.sn + J.tapidx[t]] = v;
+        }
+        __syncthreads();
+    }
+    if (J.bias_rows && J.bias_grad) {
+        for (int cb = blk; cb * 64 < Cd; cb += RB_BLOCKS) {
+            const int c = cb * 64 + og;
+            float s = 0.f;
+            if (c < Cd)
+                for (int r = sg; r < J.n_bias_rows; r += SG) s += J.bias_rows[(long)r * Cd + c];
+            sw[sg][og] = s;
+            __syncthreads();
+            if (sg == 0 && c < Cd) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < SG; ++k) v += sw[k][og];
+                J.bias_grad[c] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ rows, int nrows, int C,
                                                          float* __restrict__ dst, int accumulate) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
@@ -1582,6 +1636,18 @@ int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(1024), 0, st, partial, splits, ntaps, Cs, Cd, grad,
                        sk, sn, ti, wblocks, bias_rows, n_bias_rows, bias_grad, bias_accumulate);
     LF_CHECK_LAUNCH("wgrad_reduce");
+    return 0;
+}
+
+int lf_wgrad_reduce_batch_launch(const LfReduceJob* jobs_host, int njobs, hipStream_t st) {
+    for (int j0 = 0; j0 < njobs; j0 += LF_REDUCE_BATCH) {
+        const int n = njobs - j0 < LF_REDUCE_BATCH ? njobs - j0 : LF_REDUCE_BATCH;
+        ReduceBatch B;
+        memset(&B, 0, sizeof(B));
+        for (int i = 0; i < n; ++i) B.j[i] = jobs_host[j0 + i];
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(n * RB_BLOCKS), dim3(1024), 0, st, B);
+        LF_CHECK_LAUNCH("wgrad_reduce_batch");
+    }
     return 0;
 }
 

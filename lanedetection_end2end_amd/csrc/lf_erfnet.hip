@@ -61,6 +61,7 @@ struct lf_erfnet_plan {
     mutable int precision = 0;                  // lf_erfnet_set_precision
     long off_stat0, off_stat1, stat_floats;     // two scratch regions for BN partial rows
     long off_wpart, wpart_floats, off_bpart, bpart_floats;
+    long off_wpart_all, wpart_all_floats, off_bpart_all, bpart_all_floats;   // one region per weight gradient (batched reduce)
     long off_gA, off_gB, off_gC, gbuf_floats;
     long total_floats;
     long head_in;                               // activation feeding the head
@@ -178,6 +179,8 @@ void account_fwd_stats(lf_erfnet_plan* P, const LfTapGeom& g) {
 void account_wgrad(lf_erfnet_plan* P, const LfTapGeom& g) {
     P->wpart_floats = lf_maxl(P->wpart_floats, (long)lf_tapwgrad_splits(g) * g.ntaps * g.Cs * g.Cd);
     P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_tapwgrad_bias_rows(g) * g.Cd);
+    P->wpart_all_floats += (long)lf_tapwgrad_splits(g) * g.ntaps * g.Cs * g.Cd;
+    P->bpart_all_floats += (long)lf_tapwgrad_bias_rows(g) * g.Cd;
 }
 
 }  // namespace
@@ -197,6 +200,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     lf_erfnet_plan* P = new lf_erfnet_plan();
     P->N = N; P->H = H; P->W = W; P->Cin = in_channels; P->Cout = out_channels; P->n_heads = n_heads;
     P->packed_floats = 0; P->packed16_elems = 0; P->stat_floats = 0; P->wpart_floats = 0; P->bpart_floats = 0; P->drop_floats = 0;
+    P->wpart_all_floats = 0; P->bpart_all_floats = 0;
     LfBump ws;
     int param = 0, bn = 0, drop = 0;
     long cur = -1;
@@ -293,6 +297,8 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     P->off_stat1 = ws.take(P->stat_floats);
     P->off_wpart = ws.take(P->wpart_floats);
     P->off_bpart = ws.take(P->bpart_floats);
+    P->off_wpart_all = ws.take(P->wpart_all_floats);
+    P->off_bpart_all = ws.take(P->bpart_all_floats);
     P->gbuf_floats = (long)N * (H / 2) * (W / 2) * 16;          // largest activation (= N*(H/4)*(W/4)*64)
     P->off_gA = ws.take(P->gbuf_floats);
     P->off_gB = ws.take(P->gbuf_floats);
@@ -363,6 +369,9 @@ struct Ctx {
     int s16 = 0;                     // precision mode 2: activation / gradient tensors hold bf16 elements
     hipStream_t side = nullptr;          // null: everything on st
     mutable unsigned side_reads = 0;     // gradient buffers (bit 0 gA, 1 gB, 2 gC) an in-flight side-stream kernel reads
+    // weight-gradient reductions deferred to the end of the backward pass (one batched launch per LF_REDUCE_BATCH jobs)
+    mutable std::vector<LfReduceJob> reduce_jobs;
+    mutable long wpart_used = 0, bpart_used = 0;
     // side stream may start once everything enqueued on the main stream so far has finished
     void fork() const {
         if (!side) return;
@@ -491,7 +500,7 @@ int forward_layers(const Ctx& c, const float* img) {
 // weight + bias gradient of one forward-geometry GEMM; runs on the side stream (concurrently with the data
 // gradient of the same layer).  gbuf = bit of the gradient buffer it reads (see Ctx::side_reads).
 int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x, const float* g, const float* pro_sc,
-              const float* pro_sh, int bias_accumulate, unsigned gbuf) {
+              const float* pro_sh, int bias_accumulate, unsigned gbuf, bool batch_off = false) {
     const lf_erfnet_plan* P = c.P;
     if (!c.grads[cv.p_w]) return 0;
     hipStream_t ws = c.side ? c.side : c.st;
@@ -500,13 +509,32 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     LfWgradArgs a;
     a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh; a.s16 = c.s16;
     a.split = P->precision == 3 ? 9 : (P->precision == 4 ? 6 : 0);
-    a.partial = c.at(P->off_wpart);
-    a.bias_partial = c.grads[cv.p_b] ? c.at(P->off_bpart) : nullptr;
+    // Batched mode (default): this weight gradient keeps its partial rows in its own region and its reduction joins the
+    // one launch at the end of the pass.  Immediate mode: the transposed-conv phases (their bias rows accumulate in
+    // order), the side-stream option, LF_REDUCE_IMMEDIATE (A/B).
+    static const bool immediate_env = getenv("LF_REDUCE_IMMEDIATE") != nullptr;
+    const long wneed = (long)lf_tapwgrad_splits(op.geom) * op.geom.ntaps * op.geom.Cs * op.geom.Cd;
+    const long bneed = (long)lf_tapwgrad_bias_rows(op.geom) * op.geom.Cd;
+    const bool batched = !immediate_env && !c.side && !bias_accumulate && !batch_off &&
+                         c.wpart_used + wneed <= P->wpart_all_floats && c.bpart_used + bneed <= P->bpart_all_floats;
+    a.partial = batched ? c.at(P->off_wpart_all + c.wpart_used) : c.at(P->off_wpart);
+    a.bias_partial = c.grads[cv.p_b] ? (batched ? c.at(P->off_bpart_all + c.bpart_used) : c.at(P->off_bpart)) : nullptr;
     {
         ProfScope ps(c, 1, op.geom, 0, ws);
         LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, ws));
     }
     const LfPackEntry& e = P->packs[op.pack];
+    if (batched) {
+        c.wpart_used += wneed; c.bpart_used += bneed;
+        LfReduceJob j;
+        memset(&j, 0, sizeof(j));
+        j.partial = a.partial; j.grad = c.grads[cv.p_w]; j.bias_rows = a.bias_partial; j.bias_grad = c.grads[cv.p_b];
+        j.sk = e.sk; j.sn = e.sn; j.splits = lf_tapwgrad_splits(op.geom); j.ntaps = op.geom.ntaps; j.Cs = op.geom.Cs; j.Cd = op.geom.Cd;
+        j.n_bias_rows = lf_tapwgrad_bias_rows(op.geom);
+        for (int t = 0; t < op.geom.ntaps; ++t) j.tapidx[t] = e.tapidx[t];
+        c.reduce_jobs.push_back(j);
+        return 0;
+    }
     LF_TRY(lf_wgrad_reduce_launch(a.partial, lf_tapwgrad_splits(op.geom), op.geom.ntaps, op.geom.Cs, op.geom.Cd,
                                   c.grads[cv.p_w], e.sk, e.sn, e.tapidx, a.bias_partial, lf_tapwgrad_bias_rows(op.geom),
                                   c.grads[cv.p_b], bias_accumulate, ws));
@@ -637,7 +665,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             if (can_prep) { prepped = true; prep_rows = lf_tapgemm_stat_rows(L.cv[0].dg[0].geom); }
         } else if (L.kind == K_UP) {
             for (int ph = 0; ph < 4; ++ph)
-                LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, ph > 0, bit(X)));
+                LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, ph > 0, bit(X), true));
             LfTapArgs a = lf_no_args();
             int epi = 0;
             if (c.g_enc && L.x == lf_erfnet_encoder_offset(P)) {   // gradient of the --clas heads joins here
@@ -750,6 +778,7 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
     }
     LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.s16, c.st));
     LF_TRY(backward_layers(c, img, gA, gB, gC));
+    if (!c.reduce_jobs.empty()) LF_TRY(lf_wgrad_reduce_batch_launch(c.reduce_jobs.data(), (int)c.reduce_jobs.size(), c.st));
     c.join();          // every gradient is complete once the caller's stream reaches this point
     return 0;
 }
