@@ -1483,55 +1483,45 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
 }
 
-struct ReduceBatch { LfReduceJob j[LF_REDUCE_BATCH]; };
-constexpr int RB_BLOCKS = 48;            // workgroups per job (grid-stride over its ntaps*Cs*Cd outputs, then its bias)
+struct ReduceBatch { LfReduceJob j[LF_REDUCE_BATCH]; int blk0[LF_REDUCE_BATCH + 1]; };
 
-// same arithmetic and summation order as wgrad_reduce_kernel (bitwise identical results), job = blockIdx.x / RB_BLOCKS
-__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceBatch B) {
-    constexpr int SG = 16;
-    __shared__ float sw[SG][64];
-    const LfReduceJob& J = B.j[blockIdx.x / RB_BLOCKS];
-    const int blk = blockIdx.x % RB_BLOCKS;
+// One workgroup = 64 outputs x 4 split groups; a thread sums every 4th partial row in four independent chains, the
+// groups are combined through LDS in a fixed order (deterministic; not the summation order of wgrad_reduce_kernel).
+// The workgroups of a job come first for its ntaps*Cs*Cd outputs, then one per 64 bias columns.
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch B) {
+    __shared__ float sw[4][64];
+    int jb = 0;
+    while (jb + 1 < LF_REDUCE_BATCH && (int)blockIdx.x >= B.blk0[jb + 1]) ++jb;      // uniform scan, <= 32 entries
+    const LfReduceJob& J = B.j[jb];
+    const int blk = blockIdx.x - B.blk0[jb];
     const int og = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const float* __restrict__ partial = J.partial;
     const long per = (long)J.ntaps * J.Cs * J.Cd;
-    const int splits = J.splits, Cd = J.Cd, Cs = J.Cs;
-    for (long base = (long)blk * 64; base < per; base += (long)RB_BLOCKS * 64) {
-        const long i = base + og;
-        float s0 = 0.f, s1 = 0.f;
-        if (i < per) {
-            int r = sg;
-            for (; r + SG < splits; r += 2 * SG) { s0 += partial[(long)r * per + i]; s1 += partial[(long)(r + SG) * per + i]; }
-            for (; r < splits; r += SG) s0 += partial[(long)r * per + i];
+    const int wblocks = (int)((per + 63) / 64);
+    const float* __restrict__ rows;
+    long width, i;
+    int nrows;
+    if (blk < wblocks) { rows = J.partial; width = per; i = (long)blk * 64 + og; nrows = J.splits; }
+    else { rows = J.bias_rows; width = J.Cd; i = (long)(blk - wblocks) * 64 + og; nrows = J.n_bias_rows; }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < width) {
+        int r = sg;
+        for (; r + 12 < nrows; r += 16) {
+            s0 += rows[(long)r * width + i]; s1 += rows[(long)(r + 4) * width + i];
+            s2 += rows[(long)(r + 8) * width + i]; s3 += rows[(long)(r + 12) * width + i];
         }
-        sw[sg][og] = s0 + s1;
-        __syncthreads();
-        if (sg == 0 && i < per) {
-            float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < SG; ++k) v += sw[k][og];
-            const int n = (int)(i % Cd);
-            const long r2 = i / Cd;
-            const int k2 = (int)(r2 % Cs), t = (int)(r2 / Cs);
-            J.grad[k2 * J.sk + n * J.sn + J.tapidx[t]] = v;
-        }
-        __syncthreads();
+        for (; r < nrows; r += 4) s0 += rows[(long)r * width + i];
     }
-    if (J.bias_rows && J.bias_grad) {
-        for (int cb = blk; cb * 64 < Cd; cb += RB_BLOCKS) {
-            const int c = cb * 64 + og;
-            float s = 0.f;
-            if (c < Cd)
-                for (int r = sg; r < J.n_bias_rows; r += SG) s += J.bias_rows[(long)r * Cd + c];
-            sw[sg][og] = s;
-            __syncthreads();
-            if (sg == 0 && c < Cd) {
-                float v = 0.f;
-#pragma unroll
-                for (int k = 0; k < SG; ++k) v += sw[k][og];
-                J.bias_grad[c] = v;
-            }
-            __syncthreads();
+    sw[sg][og] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sg == 0 && i < width) {
+        const float v = (sw[0][og] + sw[1][og]) + (sw[2][og] + sw[3][og]);
+        if (blk < wblocks) {
+            const int n = (int)(i % J.Cd);
+            const long r2 = i / J.Cd;
+            const int k2 = (int)(r2 % J.Cs), t = (int)(r2 / J.Cs);
+            J.grad[k2 * J.sk + n * J.sn + J.tapidx[t]] = v;
+        } else {
+            J.bias_grad[i] = v;
         }
     }
 }
@@ -1644,8 +1634,16 @@ int lf_wgrad_reduce_batch_launch(const LfReduceJob* jobs_host, int njobs, hipStr
         const int n = njobs - j0 < LF_REDUCE_BATCH ? njobs - j0 : LF_REDUCE_BATCH;
         ReduceBatch B;
         memset(&B, 0, sizeof(B));
-        for (int i = 0; i < n; ++i) B.j[i] = jobs_host[j0 + i];
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(n * RB_BLOCKS), dim3(1024), 0, st, B);
+        int blocks = 0;
+        for (int i = 0; i < LF_REDUCE_BATCH; ++i) {
+            B.blk0[i] = blocks;
+            if (i >= n) continue;
+            const LfReduceJob& J = jobs_host[j0 + i];
+            B.j[i] = J;
+            blocks += lf_cdiv((long)J.ntaps * J.Cs * J.Cd, 64) + ((J.bias_rows && J.bias_grad) ? lf_cdiv(J.Cd, 64) : 0);
+        }
+        B.blk0[LF_REDUCE_BATCH] = blocks;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, B);
         LF_CHECK_LAUNCH("wgrad_reduce_batch");
     }
     return 0;

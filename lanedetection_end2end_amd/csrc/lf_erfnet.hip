@@ -240,7 +240,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
         L.bn[1].p_g = param++; L.bn[1].p_b = param++; L.bn[1].idx = bn++; L.bn[1].C = c;
         bn_alloc(ws, L.bn[0]); bn_alloc(ws, L.bn[1]);
         account_fwd_stats(P, L.cv[0].fwd.geom);
-        account_wgrad(P, L.cv[0].fwd.geom);
+        for (int i = 0; i < 4; ++i) account_wgrad(P, L.cv[i].fwd.geom);     // one partial region per weight gradient
         if (L.drop_idx >= 0) { P->drop_off.push_back(P->drop_floats); P->drop_floats += (long)N * c; }
         P->layers.push_back(L);
         cur = L.b[4];
