@@ -73,6 +73,8 @@ struct LfWgradArgs {
 // number of k-split rows the kernel will write for this geometry
 int lf_tapwgrad_splits(const LfTapGeom& g);
 int lf_tapwgrad_bias_rows(const LfTapGeom& g);
+// rows the launch with these arguments writes (<= lf_tapwgrad_splits: the split-arithmetic kernel uses fewer, larger splits)
+int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro);
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st);
 
 // dst[k*sk + n*sn + tapidx[t]] = sum_s partial[s][t][k][n]

@@ -1261,6 +1261,195 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight gradient in the split arithmetic (precision modes fp32x9 / fp32x6, see tapgemm_split_kernel): fp32 tensors and
+// accumulators, every product X*G formed on the bf16 matrix cores from exact 3-way splits of BOTH operands (they are both
+// activations, so both are split in registers).  v_mfma_f32_16x16x32_bf16: a lane's k-block = its 8 pixels
+// (p + kq + 4u, u = 0..7, one image row) -- an iteration covers 32 pixels -- and, as in the fp32 kernel, the float4 a lane
+// loads per pixel (channels 4*pl .. 4*pl+3) feeds four tiles (tile r = channels {4*row + r}).  64 x 64 channel blocks only.
+// Workgroup = 512 threads = two 4-wave groups on the same four SIMDs, group B half an iteration behind A (workgroup
+// barrier as phase lock): one wave of a SIMD streams its 144 (96) MFMAs while its partner splits the next 64 values and
+// issues the following loads.  All eight waves split K (pixels) and are reduced through LDS at the end.
+// ---------------------------------------------------------------------------------------
+template <int TERMS>
+__global__ __launch_bounds__(512, 2) void tapwgrad_split_kernel(const LfTapGeom g, const LfWgradArgs a, const long pps,
+                                                                const int write_bias) {
+    constexpr int WAVES = 8, U = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
+    const int grp = wave >> 2;
+    const int ncob = g.Cd / 64;
+    unsigned ord = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) ord = (ord & 7u) * (gridDim.x >> 3) + (ord >> 3);
+    const unsigned nz = (unsigned)((g.Cs / 64) * ncob);
+    const int t = (int)(ord % (unsigned)g.ntaps);
+    const int bz = (int)((ord / (unsigned)g.ntaps) % nz);
+    const unsigned bxs = ord / ((unsigned)g.ntaps * nz);
+    const int cib = bz / ncob, cob = bz % ncob;
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    const long p_begin = ((long)bxs * WAVES + wave) * pps;
+    long p_end = p_begin + pps;
+    if (p_end > npix) p_end = npix;
+    const int niter = (int)(pps / (4 * U));          // the same for every wave of the workgroup (barriers in the loop)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r][q] = zero4();
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    long p = p_begin + kq;
+    int pj, pi, pn;
+    {
+        const unsigned q = p < npix ? (unsigned)p : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj = (int)(q - r * (unsigned)g.Wl);
+        pn = (int)(r / (unsigned)g.Hl);
+        pi = (int)(r - (unsigned)pn * (unsigned)g.Hl);
+    }
+    const int dh = g.tdh[t], dw = g.tdw[t];
+    const int xch = g.s_choff + cib * 64 + 4 * pl;
+    const int gch = g.d_choff + cob * 64 + 4 * pl;
+    const bool need_bias = write_bias && a.bias_partial && t == 0 && cib == 0;      // workgroup-uniform
+
+    struct Raw { f32x4 x4[U], g4[U]; unsigned vmask, xmask; };
+    auto wload = [&](Raw& S) {
+        unsigned vm = 0, xm = 0;
+        const bool rowv = (p - kq) < p_end;
+        const int nn = rowv ? pn : 0, ii = rowv ? pi : 0, jj = rowv ? pj : 0;
+        const unsigned gofs = (unsigned)(((nn * g.Hd + ii * g.dsh + g.dah) * g.Wd + jj * g.dsw + g.daw) * g.d_pix + gch);
+        const unsigned gstep = (unsigned)(4 * g.dsw * g.d_pix);
+        const int sy = ii * g.ssh + dh;
+        const bool yin = sy >= 0 && sy < g.Hs;
+        const int syc = min(max(sy, 0), g.Hs - 1);
+        const unsigned xrow = (unsigned)((nn * g.Hs + syc) * g.Ws * g.s_pix + xch);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool v = rowv && (p + 4 * u) < p_end;
+            vm |= (v ? 1u : 0u) << u;
+            S.g4[u] = ldg4(a.g + (v ? gofs + u * gstep : gofs));
+            const int sx = (jj + 4 * u) * g.ssw + dw;
+            const bool xin = v && yin && sx >= 0 && sx < g.Ws;
+            xm |= (xin ? 1u : 0u) << u;
+            S.x4[u] = ldg4(a.x + xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix));
+        }
+        S.vmask = vm; S.xmask = xm;
+    };
+    auto advance = [&]() {
+        p += 4 * U;
+        pj += 4 * U;
+        if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
+    };
+
+    Raw R;
+    bf16x8 xp[4][3], gp[4][3];
+    wload(R);
+    if (grp == 1) __syncthreads();                  // B starts one phase late
+    for (int it = 0; it < niter; ++it) {
+        // ---- VALU phase: mask (only where the wave touches padding or its end), split, start the next loads
+        if (__builtin_amdgcn_ballot_w64(R.vmask != 255u || R.xmask != 255u) != 0ull) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool v = (R.vmask >> u) & 1u, xin = (R.xmask >> u) & 1u;
+                f32x4 gg = R.g4[u], xx = R.x4[u];
+                gg.x = v ? gg.x : 0.f; gg.y = v ? gg.y : 0.f; gg.z = v ? gg.z : 0.f; gg.w = v ? gg.w : 0.f;
+                xx.x = xin ? xx.x : 0.f; xx.y = xin ? xx.y : 0.f; xx.z = xin ? xx.z : 0.f; xx.w = xin ? xx.w : 0.f;
+                R.g4[u] = gg; R.x4[u] = xx;
+            }
+        }
+        if (need_bias) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { bsum[0] += R.g4[u].x; bsum[1] += R.g4[u].y; bsum[2] += R.g4[u].z; bsum[3] += R.g4[u].w; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {               // tile e = element e of every pixel's quad; k = the lane's 8 pixels
+            const f32x4 xlo = {R.x4[0][e], R.x4[1][e], R.x4[2][e], R.x4[3][e]}, xhi = {R.x4[4][e], R.x4[5][e], R.x4[6][e], R.x4[7][e]};
+            const f32x4 glo = {R.g4[0][e], R.g4[1][e], R.g4[2][e], R.g4[3][e]}, ghi = {R.g4[4][e], R.g4[5][e], R.g4[6][e], R.g4[7][e]};
+            split3(xlo, xhi, xp[e][0], xp[e][1], xp[e][2]);
+            split3(glo, ghi, gp[e][0], gp[e][1], gp[e][2]);
+        }
+        advance();
+        wload(R);                                   // past the end: clamped, fully masked
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) asm volatile("" ::"v"(xp[e][pc]), "v"(gp[e][pc]));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- matrix phase
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (TERMS == 9) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][2], gp[q][2], acc[r][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][2], gp[q][1], acc[r][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][1], gp[q][2], acc[r][q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][2], gp[q][0], acc[r][q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][0], gp[q][2], acc[r][q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][1], gp[q][1], acc[r][q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][1], gp[q][0], acc[r][q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][0], gp[q][1], acc[r][q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][0], gp[q][0], acc[r][q], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __syncthreads();                  // pairs B's extra first barrier
+
+    // ---- reduce the 8 waves through LDS, wave 0 writes one partial row
+    __shared__ float red[WAVES - 1][64][64];
+    __shared__ float bred[WAVES][4][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave - 1][(r * 4 + q) * 4 + e][lane] = acc[r][q][e];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bred[wave][q][lane] = bsum[q];
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.partial + ((long)bxs * g.ntaps + t) * g.Cs * g.Cd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[r][q][e];
+#pragma unroll
+                    for (int w = 0; w < WAVES - 1; ++w) v += red[w][(r * 4 + q) * 4 + e][lane];
+                    const int i = 4 * kq + e;
+                    out[(long)(cib * 64 + 4 * i + r) * g.Cd + cob * 64 + 4 * pl + q] = v;
+                }
+        if (need_bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) v += bred[w][q][lane];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (kq == 0) a.bias_partial[(long)bxs * g.Cd + cob * 64 + 4 * pl + q] = v;
+            }
+        }
+    }
+}
+
 // 16 x 16 channel weight gradient with ALL taps in one wave (the 128x256 stage): one pass over G and X
 // instead of one per tap -- these launches are HBM-bound, the per-tap split tripled their traffic.
 template <int NTAPS, bool S16>
@@ -1388,19 +1577,53 @@ WgradCfg wgrad_cfg(const LfTapGeom& g) {
     return c;
 }
 
+// split-arithmetic kernel: 64-channel blocks, 32-pixel iterations, fp32 tensors, no BN prologue on the x side
+bool wgrad_split_ok(const LfTapGeom& g, const LfWgradArgs* a, int pro) {
+    if (a && (!a->split || a->s16)) return false;
+    return pro == LF_PRO_NONE && g.Cs % 64 == 0 && g.Cd % 64 == 0 && g.Wl % 32 == 0;
+}
+WgradCfg wgrad_split_cfg(const LfTapGeom& g) {
+    WgradCfg c = wgrad_cfg(g);
+    const int jobs = g.ntaps * (g.Cs / 64) * (g.Cd / 64);
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    int gx = 256 / jobs;                                    // one 8-wave workgroup per CU
+    if (gx < 1) gx = 1;
+    long pps = (npix + (long)gx * 8 - 1) / ((long)gx * 8);
+    pps = (pps + 31) / 32 * 32;
+    c.gx = (int)((npix + pps * 8 - 1) / (pps * 8));
+    c.pps = pps;
+    return c;
+}
+
 }  // namespace
 
-int lf_tapwgrad_splits(const LfTapGeom& g) { return wgrad_cfg(g).gx; }
-int lf_tapwgrad_bias_rows(const LfTapGeom& g) { return wgrad_cfg(g).gx; }
+int lf_tapwgrad_splits(const LfTapGeom& g) {
+    const int a = wgrad_cfg(g).gx;
+    const int b = wgrad_split_ok(g, nullptr, LF_PRO_NONE) ? wgrad_split_cfg(g).gx : 0;
+    return a > b ? a : b;                                   // sizes the partial rows for either kernel
+}
+int lf_tapwgrad_bias_rows(const LfTapGeom& g) { return lf_tapwgrad_splits(g); }
+int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro) {
+    return wgrad_split_ok(g, &a, pro) ? wgrad_split_cfg(g).gx : wgrad_cfg(g).gx;
+}
 
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st) {
     LF_REQUIRE(g.Cs % 16 == 0 && g.Cd % 16 == 0, "tapwgrad: channels must be multiples of 16");
     LF_REQUIRE(g.Wl % 4 == 0, "tapwgrad: logical width %d must be a multiple of 4", g.Wl);
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31) && (long)g.N * g.Hd * g.Wd * g.d_pix < (1L << 31),
                "tapwgrad: tensor too large for 32-bit offsets");
+    const int wb = a.bias_partial != nullptr;
+    if (wgrad_split_ok(g, &a, pro)) {
+        LF_REQUIRE(a.split == 9 || a.split == 6, "tapwgrad: split must be 9 or 6 (got %d)", a.split);
+        const WgradCfg cs = wgrad_split_cfg(g);
+        dim3 grid(cs.gx * g.ntaps * (g.Cs / 64) * (g.Cd / 64));
+        if (a.split == 9) hipLaunchKernelGGL(tapwgrad_split_kernel<9>, grid, dim3(512), 0, st, g, a, cs.pps, wb);
+        else hipLaunchKernelGGL(tapwgrad_split_kernel<6>, grid, dim3(512), 0, st, g, a, cs.pps, wb);
+        LF_CHECK_LAUNCH("tapwgrad_split");
+        return 0;
+    }
     const WgradCfg c = wgrad_cfg(g);
     const int xb = c.xt * 16, gb = c.gt * 16;
-    const int wb = a.bias_partial != nullptr;
     if (g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0) {
         if (a.s16) hipLaunchKernelGGL((tapwgrad16_kernel<3, true>), dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);
         else hipLaunchKernelGGL((tapwgrad16_kernel<3, false>), dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);

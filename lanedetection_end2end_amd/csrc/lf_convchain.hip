@@ -245,15 +245,17 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
         wa.x = i == 0 ? x : ws + P->z[i - 1];
         wa.g = gz;
         wa.s16 = 0;
+        wa.split = 0;                   // the heads stay on the fp32 matrix cores
         wa.pro_sc = i == 0 ? nullptr : ws + P->sc[i - 1];
         wa.pro_sh = i == 0 ? nullptr : ws + P->sh[i - 1];
         wa.partial = ws + P->off_wpart;
         wa.bias_partial = ws + P->off_bpart;
         LF_TRY(lf_tapwgrad_launch(P->fwd[i], wa, i == 0 ? LF_PRO_NONE : LF_PRO_BNRELU, st));
         const LfPackEntry& e = P->packs[P->pk_fwd[i]];
-        LF_TRY(lf_wgrad_reduce_launch(wa.partial, lf_tapwgrad_splits(P->fwd[i]), P->fwd[i].ntaps, P->fwd[i].Cs, P->fwd[i].Cd,
+        const int nsplit = lf_tapwgrad_splits_for(P->fwd[i], wa, i == 0 ? LF_PRO_NONE : LF_PRO_BNRELU);
+        LF_TRY(lf_wgrad_reduce_launch(wa.partial, nsplit, P->fwd[i].ntaps, P->fwd[i].Cs, P->fwd[i].Cd,
                                       grads_host[4 * i], e.sk, e.sn, e.tapidx, wa.bias_partial,
-                                      lf_tapwgrad_bias_rows(P->fwd[i]), grads_host[4 * i + 1], 0, st));
+                                      nsplit, grads_host[4 * i + 1], 0, st));
         // data gradient
         LfTapArgs a = lf_no_args();
         a.src = gz;

@@ -524,19 +524,20 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
         LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, ws));
     }
     const LfPackEntry& e = P->packs[op.pack];
+    const int nsplit = lf_tapwgrad_splits_for(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE);   // rows this launch wrote
     if (batched) {
         c.wpart_used += wneed; c.bpart_used += bneed;
         LfReduceJob j;
         memset(&j, 0, sizeof(j));
         j.partial = a.partial; j.grad = c.grads[cv.p_w]; j.bias_rows = a.bias_partial; j.bias_grad = c.grads[cv.p_b];
-        j.sk = e.sk; j.sn = e.sn; j.splits = lf_tapwgrad_splits(op.geom); j.ntaps = op.geom.ntaps; j.Cs = op.geom.Cs; j.Cd = op.geom.Cd;
-        j.n_bias_rows = lf_tapwgrad_bias_rows(op.geom);
+        j.sk = e.sk; j.sn = e.sn; j.splits = nsplit; j.ntaps = op.geom.ntaps; j.Cs = op.geom.Cs; j.Cd = op.geom.Cd;
+        j.n_bias_rows = nsplit;
         for (int t = 0; t < op.geom.ntaps; ++t) j.tapidx[t] = e.tapidx[t];
         c.reduce_jobs.push_back(j);
         return 0;
     }
-    LF_TRY(lf_wgrad_reduce_launch(a.partial, lf_tapwgrad_splits(op.geom), op.geom.ntaps, op.geom.Cs, op.geom.Cd,
-                                  c.grads[cv.p_w], e.sk, e.sn, e.tapidx, a.bias_partial, lf_tapwgrad_bias_rows(op.geom),
+    LF_TRY(lf_wgrad_reduce_launch(a.partial, nsplit, op.geom.ntaps, op.geom.Cs, op.geom.Cd,
+                                  c.grads[cv.p_w], e.sk, e.sn, e.tapidx, a.bias_partial, nsplit,
                                   c.grads[cv.p_b], bias_accumulate, ws));
     return 0;
 }

@@ -159,8 +159,8 @@ int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, 
     int rc = lf_tapwgrad_launch(g, a, LF_PRO_NONE, st);
     if (rc) return rc;
     const int idx[3] = {0, 1, 2};
-    return lf_wgrad_reduce_launch(a.partial, lf_tapwgrad_splits(g), 3, C, C, gw, 3L, 3L * C, idx, a.bias_partial,
-                                  lf_tapwgrad_bias_rows(g), gb, 0, st);
+    const int nsplit = lf_tapwgrad_splits_for(g, a, LF_PRO_NONE);
+    return lf_wgrad_reduce_launch(a.partial, nsplit, 3, C, C, gw, 3L, 3L * C, idx, a.bias_partial, nsplit, gb, 0, st);
 }
 
 }  // extern "C"
