@@ -1578,8 +1578,11 @@ WgradCfg wgrad_cfg(const LfTapGeom& g) {
 }
 
 // split-arithmetic kernel: 64-channel blocks, 32-pixel iterations, fp32 tensors, no BN prologue on the x side
+// Used for 6 terms only: both operands are split in registers (~450 VALU per 144 / 96 MFMAs) and a VALU instruction beside
+// the partner's MFMA stream issues only every ~12 cycles -- measured 79 us (x9) / 71-77 us (x6) against 75-81 us on the fp32
+// cores for the 128- / 64-channel launches of the network.
 bool wgrad_split_ok(const LfTapGeom& g, const LfWgradArgs* a, int pro) {
-    if (a && (!a->split || a->s16)) return false;
+    if (a && (a->split != 6 || a->s16)) return false;
     return pro == LF_PRO_NONE && g.Cs % 64 == 0 && g.Cd % 64 == 0 && g.Wl % 32 == 0;
 }
 WgradCfg wgrad_split_cfg(const LfTapGeom& g) {
