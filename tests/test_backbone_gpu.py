@@ -407,11 +407,14 @@ def test_segmentation_branch_cross_entropy():
     assert len(out) == 9 and out[0].shape == (N, 3, 1)
 
 
-@pytest.mark.parametrize("N,H,W", [(3, 48, 96), (1, 32, 64)])
-def test_ragged_shapes(N, H, W):
+@pytest.mark.parametrize("N,H,W,precision", [(3, 48, 96, "fp32"), (1, 32, 64, "fp32"), (3, 48, 96, "fp32x6"), (2, 64, 64, "fp32x9")])
+def test_ragged_shapes(N, H, W, precision):
     """Tile tails: pixel counts that are not multiples of the 256-pixel workgroup tile, widths that are not
-    multiples of 16 (the weight-gradient kernel's 4-pixel path), batch 1 and 3."""
+    multiples of 16 (the weight-gradient kernel's 4-pixel path), batch 1 and 3.  In the split modes these are the
+    launches the split kernels cannot take (pixel counts that are not whole 512-pixel workgroups, rows shorter than the
+    weight gradient's 32-pixel iteration): a mix of split and fp32-core launches inside one network."""
     net, P = build(out_channels=2, seed=11)
+    net.precision = precision
     for m in net.modules():
         if isinstance(m, torch.nn.Dropout2d):
             m.p = 0
@@ -442,13 +445,15 @@ def test_ragged_shapes(N, H, W):
         assert float((p.grad.cpu().double() - g64).abs().max()) / scale < 5e-4, k
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("precision", ["fp32", "fp32x9", "fp32x6"])
+def test_full_size_properties(precision):
     """Config C2 size (32x3x256x512, the bench workload): properties that need no CPU reference --
     bit-identical repeat runs (no atomics anywhere), exact linearity of the backward pass in the output
     gradient (scaling by 2 is exact in fp32), and, in eval mode, independence of an image's logits from
     the rest of the batch (same per-pixel summation order whatever the tiling)."""
     N, H, W = 32, 256, 512
     net, P = build(out_channels=2, seed=21)
+    net.precision = precision         # the split modes share every property: splitting 2a gives twice the pieces of a
     for m in net.modules():
         if isinstance(m, torch.nn.Dropout2d):
             m.p = 0
