@@ -844,6 +844,44 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
         for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
     const int ncg = g.Cs >> 4;
     const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;
+    if (g.Cs == 16 && g.ntaps == 3) {
+        // the 16 -> 16 channel 1-D convs (24 launches per step): all three taps' operands are requested before the first
+        // MFMA -- one memory round trip per wave instead of three (these launches are HBM-bound, a wave is ~0.2 us of MFMAs)
+        f32x4 w3[3][NT], x3[3][MT];
+        bool in3[3][MT];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int dh = g.tdh[t], dw = g.tdw[t];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) w3[t][n] = ldg4(wp + (long)t * g.Cd * 16 + n * 64);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
+                in3[t][m] = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+                const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
+                x3[t][m] = ldg4(a.src + (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4));
+            }
+        }
+        f32x4 sc = zero4(), sh = zero4();
+        if (pro == LF_PRO_BNRELU) { sc = ldg4(a.pro_sc + kq * 4); sh = ldg4(a.pro_sh + kq * 4); }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = x3[t][m];
+                if (pro == LF_PRO_BNRELU) v = max0(v * sc + sh);
+                v.x = in3[t][m] ? v.x : 0.f; v.y = in3[t][m] ? v.y : 0.f; v.z = in3[t][m] ? v.z : 0.f; v.w = in3[t][m] ? v.w : 0.f;
+                x3[t][m] = v;
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[t][n][s4], x3[t][m][s4], acc[n][m], 0, 0, 0);
+        }
+    } else
     for (int t = 0; t < g.ntaps; ++t) {
         const int dh = g.tdh[t], dw = g.tdw[t];
         unsigned xo[MT];
