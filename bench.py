@@ -154,11 +154,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-    torch.cuda.set_device(local)
+    # test hooks for a 1-GPU box (control flow of the N > 1 path only; never set by the driver): every rank on device 0,
+    # collectives over gloo -- RCCL refuses two ranks on one GPU
+    single_dev = os.environ.get("LF_BENCH_SINGLE_DEVICE") == "1"
+    torch.cuda.set_device(0 if single_dev else local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")      # RCCL over xGMI
+        dist.init_process_group(os.environ.get("LF_BENCH_BACKEND", "nccl"))      # "nccl" = RCCL over xGMI
 
     from lanedetection_end2end_amd import _lib
     from oracle import inputs
@@ -282,7 +285,7 @@ def main():
                                       "%s, train mode (BN batch stats, Dropout2d %s), fwd+bwd, optimizer excluded"
                                       % (wl["desc"], B, a.precision, "off" if a.no_dropout else "on"),
                           "global_batch": world * B, "parallelism": "dp%d" % world,
-                          "grad_allreduce": "flat fp32 bucket, RCCL" if world > 1 else "none"},
+                          "grad_allreduce": ("flat fp32 bucket, %s" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "none"},
                "roofline": roofline}
         if world == 1 and a.precision == "fp32":
             # not the headline: the same step with the 64- / 128-channel conv products formed on the bf16 matrix cores
