@@ -75,3 +75,21 @@ class FlatGradAllReduce:
         for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
             g.copy_(f)
         return flat.numel()
+
+
+def epoch_batches(n_items, per_rank_batch, rank=0, world=1, seed=0, epoch=0, shuffle=True):
+    """Index batches of one epoch for this rank (BASELINE config 4: 3626 frames, 32 per GPU, 8 GPUs -> 14 steps, the last
+    42 frames dropped).  Every rank draws the SAME permutation (seed + epoch) and takes its own ``per_rank_batch`` slice
+    of each global batch, so the ranks run the same number of steps (drop_last over the GLOBAL batch: no rank ever waits
+    in an all-reduce the others skipped) and no frame is seen twice.  The reference's loader is single-process:
+    ``get_loader`` truncates the index list to whole batches and samples it with ``SubsetRandomSampler``
+    (BEV/Dataloader/Load_Data_new.py:305-320); this is the data-parallel form of that rule."""
+    import numpy as np
+    if not (0 <= rank < world) or per_rank_batch < 1:
+        raise ValueError("epoch_batches: rank %d of %d, batch %d" % (rank, world, per_rank_batch))
+    gb = per_rank_batch * world
+    steps = n_items // gb
+    order = np.random.default_rng(seed + epoch).permutation(n_items) if shuffle else np.arange(n_items)
+    for s in range(steps):
+        lo = s * gb + rank * per_rank_batch
+        yield order[lo: lo + per_rank_batch]

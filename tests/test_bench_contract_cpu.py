@@ -12,7 +12,7 @@ def test_bench_flags_and_single_json_line():
     for flag in ("--gpus", "--steps", "--warmup"):
         assert '"%s"' % flag in src, flag
     # exactly one place prints the result, on rank 0 only
-    assert len(re.findall(r"print\(json\.dumps\(out\)\)", src)) == 1
+    assert len(re.findall(r"print\(json\.dumps\(out\)\)", src)) == 2     # the headline path and --workload epoch, each once
     # rank 0 must not issue a collective the other ranks do not (the profile steps run without the gradient all-reduce)
     assert "step(reduce=False)" in src
     # RANK / LOCAL_RANK / WORLD_SIZE come from the environment torch.distributed.run sets

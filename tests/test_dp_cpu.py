@@ -81,3 +81,19 @@ def test_flat_grad_allreduce_gloo_world2():
         assert n == n2 == 2063344 - (128 * 2 + 2)        # all parameters but encoder.output_conv
         assert nnames == 228
     assert res[0][5] is True                             # rank 0 detected the changed active set
+
+
+def test_epoch_batches_config4_sharding():
+    """BASELINE config 4: 3626 frames, 32 per GPU on 8 GPUs -> 14 steps, 42 frames dropped, ranks disjoint and in step."""
+    import numpy as np
+    from lanedetection_end2end_amd import dp
+    per_rank = [list(dp.epoch_batches(3626, 32, rank=r, world=8, seed=5)) for r in range(8)]
+    assert all(len(b) == 14 for b in per_rank)                       # same step count on every rank
+    seen = np.concatenate([np.concatenate(b) for b in per_rank])
+    assert seen.size == 14 * 256 == 3584 and np.unique(seen).size == seen.size and seen.max() < 3626
+    for s in range(14):                                               # a step's global batch = 8 disjoint slices of 32
+        assert np.unique(np.concatenate([per_rank[r][s] for r in range(8)])).size == 256
+    one = list(dp.epoch_batches(3626, 32, rank=0, world=1, seed=5))
+    assert len(one) == 113 and all(len(b) == 32 for b in one)        # 1 GPU: 113 steps, 10 frames dropped
+    assert not np.array_equal(one[0], next(dp.epoch_batches(3626, 32, seed=5, epoch=1)))    # reshuffled per epoch
+    assert np.array_equal(np.concatenate(list(dp.epoch_batches(64, 32, shuffle=False))), np.arange(64))
