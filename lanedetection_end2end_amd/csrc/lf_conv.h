@@ -1,4 +1,5 @@
-// Internal interface of the tap-GEMM convolution kernels (gfx950, fp32 MFMA 16x16x4).
+// Internal interface of the tap-GEMM convolution kernels (gfx950; fp32 MFMA 16x16x4 by default, bf16 MFMA 16x16x32 in the
+// bf16 and split precision modes).
 //
 // Every convolution-like layer of the ERFNet backbone (1-D factorised 3x1 / 1x3 convs with
 // dilation, 3x3 stride-2 convs, 3x3 stride-2 transposed convs by sub-pixel phase, and all of

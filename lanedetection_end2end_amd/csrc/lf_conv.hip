@@ -13,6 +13,12 @@
 // straight into VGPRs, one (tap, 16-channel) step prefetched ahead of the MFMAs that use it.
 // fp32 MFMA runs at the vector rate (157 TF), 1/16 of bf16, so one dwordx4 per operand tile per
 // 16 MFMAs (512 cycles) is far below what the load path sustains.
+//
+// Kernels in this file: tapgemm_kernel (fp32 matrix cores; the default path), tapgemm_lean_kernel (16-channel layers,
+// HBM-bound), tapgemm_bf16_kernel (precision modes bf16_mfma / bf16), tapgemm_split_kernel (modes fp32x9 / fp32x6: fp32
+// results from exact 3-way bf16 splits on the bf16 matrix cores), tapwgrad_kernel / tapwgrad16_kernel / tapwgrad_split_kernel
+// (weight gradients, split-K over pixels), the split-K reductions (one per weight gradient, or batched per backward pass)
+// and the weight-packing kernels.  They share one epilogue (LF_TAPGEMM_EPILOGUE: bias, ReLU, masks, residual, BN sums).
 #include <stdlib.h>
 #include <string.h>
 
