@@ -946,8 +946,12 @@ void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
 // workgroups (its two 4-wave groups each own one 256-pixel statistics row), 16-byte aligned pixels
 bool lf_tapgemm_split_ok(const LfTapGeom& g) {
-    return g.Cs % 32 == 0 && g.Cd % 64 == 0 && g.s_pix % 4 == 0 && g.s_choff % 4 == 0 &&
-           ((long)g.N * g.Hl * g.Wl) % (2 * PIX_PER_WG) == 0;
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    // its 512-pixel workgroups run one per CU: a launch that cannot put one on (most of) the 256 CUs is faster on the fp32
+    // cores with their 256-pixel workgroups, two per CU (batch 16: 1412 vs 1484 images/s before this rule)
+    const long wgs = npix / (2 * PIX_PER_WG) * (g.Cd / 64);
+    return g.Cs % 32 == 0 && g.Cd % 64 == 0 && g.s_pix % 4 == 0 && g.s_choff % 4 == 0 && npix % (2 * PIX_PER_WG) == 0 &&
+           (wgs >= 192 || getenv("LF_SPLIT_ANY_SIZE") != nullptr);
 }
 
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
