@@ -358,9 +358,9 @@ def main():
                                             "tflops": round(fam[i]["flops"] / max(fam[i]["ms"], 1e-9) / 1e9, 2)}
                                  for i in range(2)},
                     "whole_step_frac_of_conv_roofline": round(ips * wl["flop"] / world / PEAK_FP32_MFMA, 4),
-                    # back-to-back v_mfma_f32_16x16x4_f32 on every SIMD sustain 15.4 ns per instruction on this chip (power-
-                    # limited clock; tools/mfma_rate.hip) = 136 TFLOP/s, 86 % of the datasheet peak above
-                    "peak_sustained_measured": 136.0}
+                    # at 100 % matrix duty (tools/mfma_rate.hip) the chip clocks down to 136 TFLOP/s; during this workload
+                    # rocm-smi shows sclk 2.39 GHz / 1.09 kW, i.e. the datasheet peak above is the right roof
+                    "peak_at_full_matrix_duty": 136.0}
         metric = "images/sec fwd+bwd, 256x512 2-lane bs32" if a.workload == "bev" else \
             "images/sec fwd+bwd, %s" % a.workload
         out = {"metric": metric, "value": round(ips, 2), "unit": "images/sec",
