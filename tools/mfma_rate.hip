@@ -127,7 +127,15 @@ __global__ __launch_bounds__(256, 2) void probe_loop(unsigned long long* out, fl
     issue(A);
     for (int it = 0; it < iters / 4; ++it) {            // 128 MFMAs per iteration, as the kernel's step pair
         finish(A); mma(A, 0); issue(B); mma(A, 1); mma(A, 2); mma(A, 3);
+        if constexpr (F & 8) {      // scheduling hint: one VMEM read after every 8 MFMAs instead of a burst of 8
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        }
         finish(B); mma(B, 0); issue(A); mma(B, 1); mma(B, 2); mma(B, 3);
+        if constexpr (F & 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        }
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -177,11 +185,11 @@ int main() {
         hipMemset(buf, 0, (size_t)512 * 4 * 65536 * 4);
         float* sink2; hipMalloc(&sink2, 512 * 256 * 4);
         typedef void (*LoopFn)(unsigned long long*, float*, int, int, const float*, unsigned, int);
-        const LoopFn fns[] = {probe_loop<0>, probe_loop<1>, probe_loop<3>, probe_loop<7>, probe_loop<2>};
-        const char* nm[] = {"MFMAs only", "+ 8 streaming loads / step", "+ loads + 16 cndmask", "+ loads + cndmask + LDS table", "+ 16 cndmask only"};
+        const LoopFn fns[] = {probe_loop<0>, probe_loop<1>, probe_loop<3>, probe_loop<7>, probe_loop<2>, probe_loop<9>};
+        const char* nm[] = {"MFMAs only", "+ 8 streaming loads / step", "+ loads + 16 cndmask", "+ loads + cndmask + LDS table", "+ 16 cndmask only", "+ 8 loads, one per 8 MFMAs"};
         const int wins[] = {2048, 128, 16, 1};          // 512 MB (HBM), 32 MB (Infinity Cache), 4 MB (L2), 256 KB
         for (int wi = 0; wi < 4; ++wi)
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < 6; ++c) {
             if (wi > 0 && (c == 0 || c == 4)) continue;
             float msl = 0.f;
             for (int rep = 0; rep < 2; ++rep) {
