@@ -1,18 +1,8 @@
-"""Backbone registry -- same surface as BEV/Networks/__init__.py:9-20."""
+"""Backbone registry of this tree -- the surface of BEV/Networks/__init__.py:9-20, bound to the shared table."""
 from lanedetection_end2end_amd._refpath import extend as _extend
+from lanedetection_end2end_amd.registry import make_registry
 from .ERFNet import Net
 
-model_dict = {'erfnet': Net}
-
-
-def allowed_models():
-    return model_dict.keys()
-
-
-def define_model(mod, **kwargs):
-    if mod not in allowed_models():
-        raise KeyError("The requested model: {} is not implemented".format(mod))
-    return model_dict[mod](**kwargs)
-
+model_dict, allowed_models, define_model = make_registry(erfnet=Net)
 
 _extend(__path__, "Birds_Eye_View_Loss")
