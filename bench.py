@@ -336,7 +336,7 @@ def main():
             step(reduce=False)     # rank 0 only: no collective here, the other ranks are already at the final barrier
         torch.cuda.synchronize()
         buf = (ctypes.c_double * 6)()
-        lib.lf_erfnet_profile_read(plan.handle, ctypes.cast(buf, ctypes.c_void_p))
+        lib.lf_erfnet_profile_read(plan.handle, ctypes.cast(buf, ctypes.c_void_p), os.environ.get("LF_PROFILE_CSV", "").encode() or None)
         lib.lf_erfnet_profile(plan.handle, 0)
         fam = [dict(ms=buf[i * 3], flops=buf[i * 3 + 1], launches=buf[i * 3 + 2]) for i in range(2)]
         names = ["tapgemm_kernel (conv forward + data gradient)", "tapwgrad_kernel (weight gradient)"]

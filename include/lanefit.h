@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 2
+#define LF_ABI_VERSION 3
 
 /* activation applied to the backbone logits: BEV/Networks/LSQ_layer.py:43-63 */
 enum { LF_ACT_SQUARE = 0, LF_ACT_ABS = 1, LF_ACT_RELU = 2, LF_ACT_SIGMOID = 3,
@@ -158,16 +158,20 @@ int lf_erfnet_forward(const lf_erfnet_plan* plan, const float* img, const float*
                       int training, int head, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 /* Gradients are written (not accumulated) into grads_host[i]; NULL entries are skipped.
  * grad_encoder: optional (N,H/8,W/8,128) NHWC gradient w.r.t. the encoder output (`shared_encoder`,
- * BP/Networks/LSQ_layer.py:275), added where the decoder's gradient reaches the encoder; NULL = none. */
+ * BP/Networks/LSQ_layer.py:275), added where the decoder's gradient reaches the encoder; NULL = none.
+ * training: the mode the matching forward ran in.  1 = batch statistics (autograd of nn.BatchNorm2d in train mode);
+ * 0 = running statistics (net.eval() with gradients enabled, e.g. fine-tuning with frozen statistics): BatchNorm is then
+ * a per-channel affine map and its data gradient is gamma * rstd * dy, as torch computes it. */
 int lf_erfnet_backward(const lf_erfnet_plan* plan, const float* img, const float* grad_logits,
                        const float* grad_encoder, const float* const* params_host, float* const* grads_host,
-                       const float* dropmask, int head, void* workspace, size_t workspace_bytes, void* stream);
+                       const float* dropmask, int training, int head, void* workspace, size_t workspace_bytes, void* stream);
 int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream);
 /* Roofline instrumentation (bench.py): HIP event pairs around every matrix-core launch of the engine.
  * out6 = {ms, algorithmic FLOPs, launches} for family 0 (tap-GEMM forward + data gradient) and
  * family 1 (weight gradient), accumulated since the last read. */
 int lf_erfnet_profile(const lf_erfnet_plan* plan, int enable);
-int lf_erfnet_profile_read(const lf_erfnet_plan* plan, double* out6_host);
+/* csv_path_host: optional file receiving one line per recorded launch (family, layer, shape, us, TFLOP/s); NULL = none */
+int lf_erfnet_profile_read(const lf_erfnet_plan* plan, double* out6_host, const char* csv_path_host);
 
 /* ------------------------------------------------------------------------------------
  * Fused Adam step over all parameter tensors in ONE launch ("next" row 8f-1).  Replaces optimizer.step() of the
@@ -200,9 +204,10 @@ size_t lf_convchain_workspace_bytes(const lf_convchain_plan* plan);
 int lf_convchain_forward(const lf_convchain_plan* plan, const float* x, const float* const* params_host,
                          const float* const* params_dev, float* const* running_host, int training, float momentum,
                          float eps, float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* training = the mode of the matching forward (0: running statistics; see lf_erfnet_backward) */
 int lf_convchain_backward(const lf_convchain_plan* plan, const float* x, const float* y, const float* gy,
-                          const float* const* params_host, float* const* grads_host, float* gx, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          const float* const* params_host, float* const* grads_host, float* gx, int training,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* Pool + flatten in front of the heads' fully connected layers (LSQ_layer.py:183-187,197-201):
  * mode 0 = MaxPool2d(2,2) -> (N, C*(H/2)*(W/2)); mode 1 = AvgPool2d((1,W)) -> (N, C*H); input NHWC,
  * output in the NCHW flatten order nn.Linear's weights expect.  The Linear layers themselves are plain
@@ -265,16 +270,6 @@ int lf_conv1d_bwd_data(const float* gy, const float* w, const float* mask_src, f
                        int C, int axis, int dilation, float* scratch, void* stream);
 int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, int N, int H, int W, int C,
                          int axis, int dilation, float* scratch, void* stream);
-/* kernel A/B switch used by tools/kbench.py only (1, 2 = default, 4: see lf_conv.hip) */
-void lf_debug_set_tapgemm_variant(int v);
-/* precision mode of the lf_conv1d_* calls (kernel-level parity tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32
- * tensors, 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src hold bf16; w, bias, gw, gb stay fp32),
- * 9 / 6 fp32 tensors and fp32-accurate results from 3-way split operands on the bf16 matrix cores (9 or 6 partial products) */
-void lf_debug_set_ops_precision(int mode);
-/* lf_conv1d_fwd + per-wave s_memtime stamps (start, tap table built, main loop done, stores retired; 8 words/wave) */
-int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C,
-                               int axis, int dilation, float* scratch, unsigned long long* dbg, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

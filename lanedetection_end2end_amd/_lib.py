@@ -45,12 +45,12 @@ def _declare(lib):
         "lf_erfnet_encoder_offset": (L, [P]),
         "lf_erfnet_activation_offset": (L, [P, I, I]),
         "lf_erfnet_forward": (I, [P, P, P, P, P, P, I, I, P, P, c_size_t, P]),
-        "lf_erfnet_backward": (I, [P, P, P, P, P, P, P, I, P, c_size_t, P]),
+        "lf_erfnet_backward": (I, [P, P, P, P, P, P, P, I, I, P, c_size_t, P]),
         "lf_convchain_plan_create": (P, [I, I, I, I, P, P]),
         "lf_convchain_plan_destroy": (None, [P]),
         "lf_convchain_workspace_bytes": (c_size_t, [P]),
         "lf_convchain_forward": (I, [P, P, P, P, P, I, ctypes.c_float, ctypes.c_float, P, P, c_size_t, P]),
-        "lf_convchain_backward": (I, [P, P, P, P, P, P, P, P, c_size_t, P]),
+        "lf_convchain_backward": (I, [P, P, P, P, P, P, P, I, P, c_size_t, P]),
         "lf_poolflat_fwd": (I, [P, I, I, I, I, I, P, P]),
         "lf_poolflat_bwd": (I, [P, P, I, I, I, I, I, P, P]),
         "lf_lane_decode": (I, [P, P, P, P, D, P, P, D, D, D, I, I, I, I, P, P, P]),
@@ -70,17 +70,23 @@ def _declare(lib):
         "lf_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_weight": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
-        "lf_debug_set_tapgemm_variant": (None, [I]),
-        "lf_debug_set_ops_precision": (None, [I]),
         "lf_erfnet_set_precision": (I, [P, I]),
-        "lf_debug_conv1d_fwd_phases": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P]),
         "lf_erfnet_profile": (I, [P, I]),
-        "lf_erfnet_profile_read": (I, [P, P]),
+        "lf_erfnet_profile_read": (I, [P, P, c_char_p]),
     }
-    for name, (res, args) in sig.items():
-        fn = getattr(lib, name)
-        fn.restype = res
-        fn.argtypes = args
+    # test / tooling hooks (csrc/lf_debug.h; not part of include/lanefit.h)
+    dbg = {
+        "lf_debug_set_tapgemm_variant": (None, [I]),
+        "lf_debug_set_split_any_size": (None, [I]),
+        "lf_debug_set_lds_ablate": (None, [I]),
+        "lf_debug_set_ops_precision": (None, [I]),
+        "lf_debug_conv1d_fwd_phases": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P]),
+    }
+    for table in (sig, dbg):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     return sig
 
 

@@ -63,6 +63,7 @@ class _ConvChainFn(torch.autograd.Function):
                                             running, int(training), float(bns[0].momentum), float(bns[0].eps), _lib.ptr(y),
                                             _lib.ptr(ws), plan.ws_bytes, _lib.stream()), "lf_convchain_forward")
         ctx.plan, ctx.ws, ctx.x, ctx.y, ctx.params = plan, ws, x, y, params
+        ctx.training = int(training)
         return y
 
     @staticmethod
@@ -77,7 +78,7 @@ class _ConvChainFn(torch.autograd.Function):
             off += p.numel()
         gx = torch.empty_like(ctx.x) if ctx.needs_input_grad[2] else None
         _lib.check(lib.lf_convchain_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(ctx.y), _lib.ptr(gy), _ptr_array(params),
-                                             _ptr_array(grads), _lib.ptr(gx), _lib.ptr(ctx.ws), plan.ws_bytes,
+                                             _ptr_array(grads), _lib.ptr(gx), ctx.training, _lib.ptr(ctx.ws), plan.ws_bytes,
                                              _lib.stream()), "lf_convchain_backward")
         ctx.ws = None
         return (None, None, gx, None) + tuple(grads)

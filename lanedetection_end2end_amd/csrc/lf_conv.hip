@@ -14,7 +14,8 @@
 // fp32 MFMA runs at the vector rate (157 TF), 1/16 of bf16, so one dwordx4 per operand tile per
 // 16 MFMAs (512 cycles) is far below what the load path sustains.
 //
-// Kernels in this file: tapgemm_kernel (fp32 matrix cores; the default path), tapgemm_lean_kernel (16-channel layers,
+// Kernels in this file: tapgemm_kernel (fp32 matrix cores, operands streamed L2 -> VGPR; the 64- / 128-channel launches of the
+// default path run on the LDS-tiled kernel of lf_convlds.hip instead), tapgemm_lean_kernel (16-channel layers,
 // HBM-bound), tapgemm_bf16_kernel (precision modes bf16_mfma / bf16), tapgemm_split_kernel (modes fp32x9 / fp32x6: fp32
 // results from exact 3-way bf16 splits on the bf16 matrix cores), tapwgrad_kernel / tapwgrad16_kernel / tapwgrad_split_kernel
 // (weight gradients, split-K over pixels), the split-K reductions (one per weight gradient, or batched per backward pass)
@@ -143,15 +144,13 @@ _Pragma("unroll") \
         } \
     } \
 
-// (VAR 1 -- only reached by the handful of launches with fewer than 8 K-steps -- gets the whole register file: its
-// per-tap ping-pong state plus the epilogue operands do not fit 256 registers)
-template <int NT, int VAR, int PROC>
-__global__ __launch_bounds__(256, VAR == 1 ? 1 : 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+template <int NT, int PROC>
+__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
     constexpr bool S16 = false, HOISTV = false;      // the fp32 loop leaves no registers to hold the per-channel vectors
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
-    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memtime();
+    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memrealtime();
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);       // < 2^31, checked by the launcher
     // Workgroup b runs on XCD b % 8 (observed dispatch order).  Give every XCD a CONTIGUOUS range of pixel
     // tiles so that the halo rows neighbouring tiles share (and both halves of blockIdx.y) meet in one L2.
@@ -184,171 +183,8 @@ __global__ __launch_bounds__(256, VAR == 1 ? 1 : 2) void tapgemm_kernel(const Lf
     const int ncg = g.Cs >> 4;
     const int nsteps = g.ntaps * ncg;
 
-    if constexpr (VAR == 1) {
-        // VAR 1: per-tap address setup (once per tap instead of once per 16 channels), pointer-increment
-        // operand streams, two named register sets (no copy), next step's loads issued behind the first
-        // quarter of the current step's MFMAs so that a single wave keeps the matrix pipe fed.
-        struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
-        unsigned xoff[MT];      // element offset of (pixel, tap) channel group 0 for the tap being loaded
-        unsigned okbits = 0;
-        auto tap_setup = [&](int t) {
-            const int dh = g.tdh[t], dw = g.tdw[t];
-            okbits = 0;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
-                const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-                const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-                xoff[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4);
-                okbits |= (in ? 1u : 0u) << m;
-            }
-        };
-        const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;     // + 16*Cd floats per 16-channel step
-        const long wstep = (long)g.Cd * 16;
-        int t_ld = 0, cg_ld = 0;
-        tap_setup(0);
-        auto issue = [&](Step& S) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) S.w[n] = ldg4(wp + n * 64);
-            wp += wstep;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) S.x[m] = ldg4(a.src + xoff[m] + cg_ld * 16);
-            if (pro == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + cg_ld * 16 + kq * 4); S.sh = ldg4(a.pro_sh + cg_ld * 16 + kq * 4); }
-            S.ok = okbits;
-            if (++cg_ld == ncg) { cg_ld = 0; if (++t_ld < g.ntaps) tap_setup(t_ld); }
-        };
-        auto finish = [&](Step& S) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x4 v = S.x[m];
-                if (pro == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
-                const bool in = (S.ok >> m) & 1u;
-                v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
-                S.x[m] = v;
-            }
-        };
-        auto mma = [&](const Step& S, int s) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
-        };
-        Step A, B;
-        issue(A);
-        for (int step = 0; step < nsteps; step += 2) {
-            finish(A);
-            mma(A, 0);
-            if (step + 1 < nsteps) issue(B);
-            mma(A, 1); mma(A, 2); mma(A, 3);
-            if (step + 1 < nsteps) {
-                finish(B);
-                mma(B, 0);
-                if (step + 2 < nsteps) issue(A);
-                mma(B, 1); mma(B, 2); mma(B, 3);
-            }
-        }
-    } else if constexpr (VAR == 4) {
-        // VAR 4: as VAR 2, but the weight tile of each K-step (16 channels x NT*16 outputs = NT KB) is staged
-        // ONCE per workgroup in LDS (double-buffered, one barrier per step) instead of once per wave from L1/L2:
-        // one dwordx4 per thread fills it, 4x fewer weight bytes leave the L2, and the weight operands no longer
-        // need a register ring.
-        struct XStep { f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
-        __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
-        __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
-        __shared__ f32x4 wl[2][4][NT * 16];
-        for (int t = 0; t < g.ntaps; ++t) {
-            const int dh = g.tdh[t], dw = g.tdw[t];
-            unsigned o[MT], okb = 0;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
-                const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-                const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-                o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4);
-                okb |= (in ? 1u : 0u) << m;
-            }
-            tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
-            tab_ok[wave][t][lane] = okb;
-        }
-        const int tid = threadIdx.x;
-        const bool filler = tid < NT * 64;
-        const int f_kb = filler ? tid / (NT * 16) : 0, f_co = filler ? tid % (NT * 16) : 0;
-        const float* wsrc = a.wp + ((long)f_kb * g.Cd + cob + f_co) * 4;
-        const int wstep = g.Cd * 16;
-        const int ntaps = g.ntaps;
-        int t_ld = 0, cg_ld = 0, wstepi = 0;
-        auto wfetch = [&]() -> f32x4 {              // weights of the next K-step (clamped past the end)
-            const f32x4 v = ldg4(wsrc + (long)min(wstepi, nsteps - 1) * wstep);
-            ++wstepi;
-            return v;
-        };
-        auto issue = [&](XStep& S) {
-            const bool live = t_ld < ntaps;
-            const int tc = live ? t_ld : ntaps - 1;
-            const uint4 o = tab_off[wave][tc][lane];
-            const unsigned okb = tab_ok[wave][tc][lane];
-            const int c16 = cg_ld * 16;
-            S.x[0] = ldg4(a.src + o.x + c16);
-            S.x[1] = ldg4(a.src + o.y + c16);
-            S.x[2] = ldg4(a.src + o.z + c16);
-            S.x[3] = ldg4(a.src + o.w + c16);
-            if constexpr (PROC == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + c16 + kq * 4); S.sh = ldg4(a.pro_sh + c16 + kq * 4); }
-            S.ok = live ? okb : 0u;
-            const int cgn = cg_ld + 1;
-            const bool wrap = cgn == ncg;
-            cg_ld = live ? (wrap ? 0 : cgn) : cg_ld;
-            t_ld = (live && wrap) ? t_ld + 1 : t_ld;
-        };
-        auto finish = [&](XStep& S) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x4 v = S.x[m];
-                if constexpr (PROC == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
-                const bool in = (S.ok >> m) & 1u;
-                v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
-                S.x[m] = v;
-            }
-        };
-        auto mma = [&](const f32x4 (&w)[NT], const XStep& S, int s) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
-        };
-        static_assert(MT == 4, "tab_off packs 4 pixel tiles");
-        XStep A, B;
-        f32x4 wreg = wfetch();
-        issue(A);
-        if (filler) wl[0][f_kb][f_co] = wreg;
-        __syncthreads();
-        const int npairs = (nsteps + 1) >> 1;
-        for (int pr = 0; pr < npairs; ++pr) {
-            f32x4 w[NT];
-            // ---- step A: weights in buffer 0
-            wreg = wfetch();
-#pragma unroll
-            for (int n = 0; n < NT; ++n) w[n] = wl[0][kq][n * 16 + pl];
-            finish(A);
-            mma(w, A, 0);
-            issue(B);
-            mma(w, A, 1); mma(w, A, 2); mma(w, A, 3);
-            if (filler) wl[1][f_kb][f_co] = wreg;
-            __syncthreads();
-            // ---- step B: weights in buffer 1
-            wreg = wfetch();
-#pragma unroll
-            for (int n = 0; n < NT; ++n) w[n] = wl[1][kq][n * 16 + pl];
-            finish(B);
-            mma(w, B, 0);
-            issue(A);
-            mma(w, B, 1); mma(w, B, 2); mma(w, B, 3);
-            if (filler) wl[0][f_kb][f_co] = wreg;
-            __syncthreads();
-        }
-    } else {
-        // VAR 2 (default): branch-free main loop.  Per-tap source offsets and validity bits are computed ONCE
+    {
+        // Branch-free main loop.  Per-tap source offsets and validity bits are computed ONCE
         // into an LDS table (one 16-byte row per lane and tap); the loop body is one basic block of two
         // K-steps (128 MFMAs + ~20 loads) with scalar selects for the (tap, channel-group) counters, so the
         // accumulators stay in place and the scheduler is free to sink loads between MFMAs.  Steps past the
@@ -415,7 +251,7 @@ __global__ __launch_bounds__(256, VAR == 1 ? 1 : 2) void tapgemm_kernel(const Lf
                     acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
         };
         static_assert(MT == 4, "tab_off packs 4 pixel tiles");
-        if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memtime();
+        if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memrealtime();
         Step A, B;
         issue(A);
         const int npairs = (nsteps + 1) >> 1;
@@ -433,12 +269,12 @@ __global__ __launch_bounds__(256, VAR == 1 ? 1 : 2) void tapgemm_kernel(const Lf
 
     if (a.dbg) {   // make the stamp wait for the last MFMA: touch one accumulator
         asm volatile("" ::"v"(acc[0][0][0]));
-        tstamp[2] = __builtin_amdgcn_s_memtime();
+        tstamp[2] = __builtin_amdgcn_s_memrealtime();
     }
     LF_TAPGEMM_EPILOGUE
     if (a.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tstamp[3] = __builtin_amdgcn_s_memtime();
+        tstamp[3] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
             unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WG_WAVES + wave) * 8;
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
@@ -645,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
     const int pl = lane & 15, kq = lane >> 4;
     const int grp = wave >> 2;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
-    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memtime();
+    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memrealtime();
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
     const int cob = blockIdx.y * NT * 16;
     unsigned bx = blockIdx.x;
@@ -734,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
     static_assert(TERMS == 9 || TERMS == 6, "9 = every partial product, 6 = those above 2^-24");
     Raw R;
     bf16x8 xb[MT][3];
-    if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memtime();
+    if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memrealtime();
     if (grp == 0) wfetch();       // W[0]
     issue(R);                     // pixels of step 0
     if (grp == 1) __syncthreads();            // B starts one phase late
@@ -803,12 +639,12 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
     if (grp == 0) __syncthreads();            // A pairs B's extra first barrier (B's last matrix phase)
     if (a.dbg) {
         asm volatile("" ::"v"(acc[0][0][0]));
-        tstamp[2] = __builtin_amdgcn_s_memtime();
+        tstamp[2] = __builtin_amdgcn_s_memrealtime();
     }
     LF_TAPGEMM_EPILOGUE
     if (a.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tstamp[3] = __builtin_amdgcn_s_memtime();
+        tstamp[3] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
             unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 8;
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
@@ -928,8 +764,8 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
     LF_TAPGEMM_EPILOGUE
 }
 
-int g_tapgemm_variant = 2;     // 1 ping-pong with per-tap setup (also used for < 8 K-steps), 2 (default) branch-free loop with LDS
-                               // tap table, 4 = 2 + weights staged through LDS (LF_TAPGEMM_VARIANT / tools/kbench.py --variants)
+int g_tapgemm_variant = 2;     // 2 = streaming kernels (shipped), 0 = LDS-tiled kernel where it applies (lf_convlds.hip; tools/kbench.py A/B)
+int g_split_any_size = 0;      // kernel-level tests only: let the split kernel take launches below its shipped size rule
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -942,6 +778,7 @@ int pick_nt(int Cd) {
 }  // namespace
 
 void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
+void lf_tapgemm_set_split_any_size(int v) { g_split_any_size = v; }
 
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
 // workgroups (its two 4-wave groups each own one 256-pixel statistics row), 16-byte aligned pixels
@@ -951,12 +788,24 @@ bool lf_tapgemm_split_ok(const LfTapGeom& g) {
     // cores with their 256-pixel workgroups, two per CU (batch 16: 1412 vs 1484 images/s before this rule)
     const long wgs = npix / (2 * PIX_PER_WG) * (g.Cd / 64);
     return g.Cs % 32 == 0 && g.Cd % 64 == 0 && g.s_pix % 4 == 0 && g.s_choff % 4 == 0 && npix % (2 * PIX_PER_WG) == 0 &&
-           (wgs >= 192 || getenv("LF_SPLIT_ANY_SIZE") != nullptr);
+           (wgs >= 192 || g_split_any_size);
 }
+
+namespace {
+bool use_lds_kernel(const LfTapGeom& g, const LfTapArgs& a) {
+    return g_tapgemm_variant == 0 && a.wp32 && !a.wp16 && !a.split && !a.s16 && lf_tapgemm_lds_ok(g);
+}
+}  // namespace
 
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;
-    return lf_cdiv(npix, PIX_PER_WG);
+    const int rows = lf_cdiv(npix, PIX_PER_WG);
+    const int lds = lf_tapgemm_lds_ok(g) ? lf_tapgemm_lds_grid(g) : 0;
+    return rows > lds ? rows : lds;
+}
+int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a) {
+    if (use_lds_kernel(g, a)) return lf_tapgemm_lds_grid(g);
+    return lf_cdiv((long)g.N * g.Hl * g.Wl, PIX_PER_WG);
 }
 
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st) {
@@ -968,17 +817,11 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     const int nt = pick_nt(g.Cd);
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31), "tapgemm: source tensor too large for 32-bit offsets");
-    const int nsteps = g.ntaps * (g.Cs / 16);      // short loops: the LDS tap table of VAR 2 does not pay off
-    static const bool env_once = [] { if (const char* e = getenv("LF_TAPGEMM_VARIANT")) g_tapgemm_variant = atoi(e); return true; }();
-    (void)env_once;
+    if (use_lds_kernel(g, a)) return lf_tapgemm_lds_launch(g, a, pro, epi, st);
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
-        if (g_tapgemm_variant == 1) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else if (nsteps < 8) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1, 0>), grid, dim3(256), 0, st, g, a, pro, epi);    \
-        else if (g_tapgemm_variant == 4 && pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 4, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else if (g_tapgemm_variant == 4) hipLaunchKernelGGL((tapgemm_kernel<NTV, 4, 0>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 2, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                   \
+        if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), 0, st, g, a, pro, epi);  \
+        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                       \
     } while (0)
     LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
     if (a.split && a.wp48 && !a.wp16 && lf_tapgemm_split_ok(g)) {
@@ -1021,7 +864,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         case 3: LF_TG(3); break;
         case 2: LF_TG(2); break;
         default:
-            if (g_tapgemm_variant >= 2 && !a.dbg) hipLaunchKernelGGL(tapgemm_lean_kernel<1>, grid, dim3(256), 0, st, g, a, pro, epi);
+            if (!a.dbg) hipLaunchKernelGGL(tapgemm_lean_kernel<1>, grid, dim3(256), 0, st, g, a, pro, epi);
             else LF_TG(1);
             break;
     }
@@ -1684,7 +1527,7 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
     dim3 grid(c.gx * g.ntaps * (g.Cs / xb) * (g.Cd / gb));
 #define LF_WG(XV, GV, XT, GT)                                                                                     \
     do {                                                                                                          \
-        if (a.s16 && c.u == 4 && XV && GV && !getenv("LF_WGRAD_FP32")) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true, (XV && GV)>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
+        if (a.s16 && c.u == 4 && XV && GV) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true, (XV && GV)>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
         else if (a.s16 && c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
         else if (a.s16) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);   \
         else if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, false>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \

@@ -208,7 +208,7 @@ int lf_convchain_forward(const lf_convchain_plan* P, const float* x, const float
         int pro = LF_PRO_NONE;
         if (i > 0) { a.pro_sc = ws + P->sc[i - 1]; a.pro_sh = ws + P->sh[i - 1]; pro = LF_PRO_BNRELU; }
         LF_TRY(lf_tapgemm_launch(P->fwd[i], a, pro, training ? LF_EPI_STATS_SQ : 0, st));
-        LfStatPart part = {stat, lf_tapgemm_stat_rows(P->fwd[i]), P->C[i + 1], 0};
+        LfStatPart part = {stat, lf_tapgemm_stat_rows_for(P->fwd[i], a), P->C[i + 1], 0};
         LF_TRY(lf_bn_finalize_fwd(&part, 1, P->C[i + 1], (double)npix, params_host[4 * i + 2], params_host[4 * i + 3],
                                   running_host[2 * i], running_host[2 * i + 1], momentum, eps, training, ws + P->sc[i],
                                   ws + P->sh[i], ws + P->asc[i], ws + P->ash[i], st));
@@ -218,9 +218,10 @@ int lf_convchain_forward(const lf_convchain_plan* P, const float* x, const float
 }
 
 // Backward of the forward that last used `workspace`.  gy (N,H,W,C_L) NHWC; grads_host: 4*L device pointers
-// (written, not accumulated; all must be non-null); gx (N,H,W,C0) NHWC or NULL when the input needs no gradient.
+// (written, not accumulated; all must be non-null); gx (N,H,W,C0) NHWC or NULL when the input needs no gradient;
+// training = the mode of that forward (0: BatchNorm used its running statistics, its backward is the affine map's).
 int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const float* y, const float* gy,
-                          const float* const* params_host, float* const* grads_host, float* gx, void* workspace,
+                          const float* const* params_host, float* const* grads_host, float* gx, int training, void* workspace,
                           size_t workspace_bytes, void* stream) {
     LF_REQUIRE(P && x && y && gy && params_host && grads_host && workspace, "lf_convchain_backward: null pointer");
     LF_REQUIRE(workspace_bytes >= lf_convchain_workspace_bytes(P), "lf_convchain_backward: workspace too small");
@@ -235,7 +236,7 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
     LF_TRY(lf_bn_bwd_reduce(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], nullptr, stat, npix, P->C[l + 1], ppi, 0, st));
     LfStatPart rp = {stat, lf_bn_bwd_reduce_rows(npix), P->C[l + 1], 0};
     LF_TRY(lf_bn_bwd_finalize(&rp, 1, P->C[l + 1], (double)npix, ws + P->c1[l], ws + P->c2[l], grads_host[4 * l + 2],
-                              grads_host[4 * l + 3], st));
+                              grads_host[4 * l + 3], training, st));
     LF_TRY(lf_bn_bwd_apply(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], params_host[4 * l + 2], ws + P->c1[l],
                            ws + P->c2[l], nullptr, A, nullptr, npix, P->C[l + 1], ppi, 0, st));
     float *gz = A, *other = B;      // gz = d loss / d z_i
@@ -269,9 +270,9 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
         a.aux = ws + P->z[j]; a.msc = ws + P->sc[j]; a.msh = ws + P->sh[j]; a.asc = ws + P->asc[j]; a.ash = ws + P->ash[j];
         a.stats = stat;
         LF_TRY(lf_tapgemm_launch(P->dg[i], a, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, st));
-        LfStatPart sp = {stat, lf_tapgemm_stat_rows(P->dg[i]), P->C[i], 0};
+        LfStatPart sp = {stat, lf_tapgemm_stat_rows_for(P->dg[i], a), P->C[i], 0};
         LF_TRY(lf_bn_bwd_finalize(&sp, 1, P->C[i], (double)npix, ws + P->c1[j], ws + P->c2[j], grads_host[4 * j + 2],
-                                  grads_host[4 * j + 3], st));
+                                  grads_host[4 * j + 3], training, st));
         LF_TRY(lf_bn_bwd_apply(other, nullptr, ws + P->z[j], ws + P->asc[j], ws + P->ash[j], params_host[4 * j + 2],
                                ws + P->c1[j], ws + P->c2[j], nullptr, gz, nullptr, npix, P->C[i], ppi, 0, st));
         // gz now holds d loss / d z_{i-1} (written over the consumed gradient), `other` is scratch again

@@ -21,9 +21,10 @@ int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm,
 int lf_bn_bwd_reduce_rows(long npix);
 int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* dm,
                      float* rows, long npix, int C, long pix_per_image, int s16, hipStream_t st);
-// partial rows -> c1 = sum/M, c2 = sumx/M, and the parameter gradients ggamma = sumx, gbeta = sum
+// partial rows -> c1 = sum/M, c2 = sumx/M (both 0 when the forward ran in eval mode: running statistics, no mean terms),
+// and the parameter gradients ggamma = sumx, gbeta = sum
 int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count, float* c1, float* c2, float* ggamma,
-                       float* gbeta, hipStream_t st);
+                       float* gbeta, int training, hipStream_t st);
 // g_t = gamma*rstd*(gm - c1 - xhat*c2); optionally g_z = g*[y>0]
 int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* gamma,
                     const float* c1, const float* c2, const float* dm, float* g_t, float* g_z, long npix, int C,

@@ -56,6 +56,7 @@ struct lf_erfnet_plan {
     int n_params, n_bn, n_drop;
     int p_head_w[2], p_head_b[2], n_heads;
     long off_entries, off_packed, packed_floats;
+    long off_packed32;                          // the same weights in the LDS-tiled kernel's order (lf_convlds.hip), same dst_off
     long off_packed16, packed16_elems;          // bf16 operand copies of the packed weights (precision modes 1, 2)
     long off_packed48;                          // 3-piece bf16 split of the packed weights (modes 3, 4): 3 * packed16_elems
     mutable int precision = 0;                  // lf_erfnet_set_precision
@@ -71,9 +72,6 @@ struct lf_erfnet_plan {
     mutable int prof_on = 0;
     struct ProfRec { hipEvent_t a, b; int family; double flops; int layer; int Cs, Cd, ntaps; long npix; int epi; };
     mutable int prof_layer = -1;
-    // side stream for weight gradients (they only READ the gradient buffers the main stream ping-pongs)
-    mutable hipStream_t side = nullptr;
-    mutable hipEvent_t ev_main = nullptr, ev_side = nullptr;
     mutable std::vector<ProfRec> prof;
 };
 
@@ -291,6 +289,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
 
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
     P->off_packed = ws.take(P->packed_floats);
+    P->off_packed32 = ws.take(P->packed_floats);
     P->off_packed16 = ws.take((P->packed16_elems + 1) / 2);
     P->off_packed48 = ws.take((3 * P->packed16_elems + 1) / 2);
     P->off_stat0 = ws.take(P->stat_floats);
@@ -309,9 +308,6 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
 
 void lf_erfnet_plan_destroy(lf_erfnet_plan* P) {
     if (!P) return;
-    if (P->side) (void)hipStreamDestroy(P->side);
-    if (P->ev_main) (void)hipEventDestroy(P->ev_main);
-    if (P->ev_side) (void)hipEventDestroy(P->ev_side);
     delete P;
 }
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)P->total_floats * sizeof(float); }
@@ -367,27 +363,13 @@ struct Ctx {
     hipStream_t st;
     const float* g_enc = nullptr;    // backward: extra gradient w.r.t. the encoder output (NHWC) or null
     int s16 = 0;                     // precision mode 2: activation / gradient tensors hold bf16 elements
-    hipStream_t side = nullptr;          // null: everything on st
-    mutable unsigned side_reads = 0;     // gradient buffers (bit 0 gA, 1 gB, 2 gC) an in-flight side-stream kernel reads
     // weight-gradient reductions deferred to the end of the backward pass (one batched launch per LF_REDUCE_BATCH jobs)
     mutable std::vector<LfReduceJob> reduce_jobs;
     mutable long wpart_used = 0, bpart_used = 0;
-    // side stream may start once everything enqueued on the main stream so far has finished
-    void fork() const {
-        if (!side) return;
-        (void)hipEventRecord(P->ev_main, st);
-        (void)hipStreamWaitEvent(side, P->ev_main, 0);
-    }
-    // main stream waits for everything enqueued on the side stream so far
-    void join() const {
-        if (!side) return;
-        (void)hipEventRecord(P->ev_side, side);
-        (void)hipStreamWaitEvent(st, P->ev_side, 0);
-        side_reads = 0;
-    }
-    void before_write(unsigned bufs) const { if (side_reads & bufs) join(); }
+    mutable int last_rows = 0;           // BatchNorm partial rows the last run_gemm wrote (depends on the kernel it selected)
     float* at(long off) const { return ws + off; }
     const float* packed(int pack) const { return ws + P->off_packed + P->packs[pack].dst_off; }
+    const float* packed32(int pack) const { return ws + P->off_packed32 + P->packs[pack].dst_off; }
 };
 
 double gemm_flops(const LfTapGeom& g) { return 2.0 * (double)g.N * g.Hl * g.Wl * g.Cs * g.Cd * g.ntaps; }
@@ -412,12 +394,14 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
     extra.s16 = c.s16;
+    if (c.P->precision == 0) extra.wp32 = c.packed32(op.pack);
     if (c.P->precision == 1 || c.P->precision == 2)
         extra.wp16 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed16) + c.P->packs[op.pack].dst16_off;
     if (c.P->precision >= 3) {      // fp32 from split operands on the bf16 matrix cores (9 or 6 partial products)
         extra.split = c.P->precision == 3 ? 9 : 6;
         extra.wp48 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed48) + 3 * c.P->packs[op.pack].dst16_off;
     }
+    c.last_rows = lf_tapgemm_stat_rows_for(op.geom, extra);
     ProfScope ps(c, 0, op.geom, epi | (pro << 8), c.st);
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
 }
@@ -449,7 +433,7 @@ int forward_layers(const Ctx& c, const float* img) {
                 a.stats = stat0;
                 LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
-                parts[np++] = {stat0, lf_tapgemm_stat_rows(L.cv[0].fwd.geom), L.Cout - L.Cin, 0};
+                parts[np++] = {stat0, c.last_rows, L.Cout - L.Cin, 0};
                 LF_TRY(lf_pool_concat_fwd(c.at(L.x), N, L.Hin, L.Win, L.Cin, c.at(L.b[0]), L.Cout, L.Cout - L.Cin,
                                           c.training ? stat1 : nullptr, c.s16, c.st));
                 parts[np++] = {stat1, lf_pool_rows(npo), L.Cin, L.Cout - L.Cin};
@@ -458,13 +442,12 @@ int forward_layers(const Ctx& c, const float* img) {
             LF_TRY(lf_bn_act(c.at(L.b[0]), c.at(L.bn[0].sc), c.at(L.bn[0].sh), nullptr, nullptr, c.at(L.b[1]), npo, L.Cout,
                              (long)L.Hout * L.Wout, c.s16, c.st));
         } else if (L.kind == K_NB) {
-            const int srows = lf_tapgemm_stat_rows(L.cv[0].fwd.geom);
             LfTapArgs a = lf_no_args();
             LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE, LF_EPI_RELU, a));
             a.stats = stat0;
             LF_TRY(run_gemm(c, L.cv[1].fwd, c.at(L.b[0]), c.at(L.b[1]), c.params[L.cv[1].p_b], LF_PRO_NONE,
                             c.training ? LF_EPI_STATS_SQ : 0, a));
-            LfStatPart p0 = {stat0, srows, L.Cout, 0};
+            LfStatPart p0 = {stat0, c.last_rows, L.Cout, 0};
             LF_TRY(bn_finalize(c, L.bn[0], &p0, 1, (double)npo));
             a = lf_no_args();
             a.pro_sc = c.at(L.bn[0].sc); a.pro_sh = c.at(L.bn[0].sh);
@@ -473,6 +456,7 @@ int forward_layers(const Ctx& c, const float* img) {
             a.stats = stat0;
             LF_TRY(run_gemm(c, L.cv[3].fwd, c.at(L.b[2]), c.at(L.b[3]), c.params[L.cv[3].p_b], LF_PRO_NONE,
                             c.training ? LF_EPI_STATS_SQ : 0, a));
+            p0.nrows = c.last_rows;
             LF_TRY(bn_finalize(c, L.bn[1], &p0, 1, (double)npo));
             const float* dm = (c.training && L.drop_idx >= 0 && c.dropmask) ? c.dropmask + P->drop_off[L.drop_idx] : nullptr;
             LF_TRY(lf_bn_act(c.at(L.b[3]), c.at(L.bn[1].sc), c.at(L.bn[1].sh), dm, c.at(L.x), c.at(L.b[4]), npo, L.Cout,
@@ -486,7 +470,7 @@ int forward_layers(const Ctx& c, const float* img) {
                 a.stats = stat0 + (long)rows * 2 * L.Cout;
                 LF_TRY(run_gemm(c, L.cv[0].fph[ph], c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
-                rows += lf_tapgemm_stat_rows(L.cv[0].fph[ph].geom);
+                rows += c.last_rows;
             }
             parts[0] = {stat0, rows, L.Cout, 0};
             LF_TRY(bn_finalize(c, L.bn[0], parts, 1, (double)npo));
@@ -497,25 +481,20 @@ int forward_layers(const Ctx& c, const float* img) {
     return 0;
 }
 
-// weight + bias gradient of one forward-geometry GEMM; runs on the side stream (concurrently with the data
-// gradient of the same layer).  gbuf = bit of the gradient buffer it reads (see Ctx::side_reads).
+// weight + bias gradient of one forward-geometry GEMM
 int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x, const float* g, const float* pro_sc,
-              const float* pro_sh, int bias_accumulate, unsigned gbuf, bool batch_off = false) {
+              const float* pro_sh, int bias_accumulate, bool batch_off = false) {
     const lf_erfnet_plan* P = c.P;
     if (!c.grads[cv.p_w]) return 0;
-    hipStream_t ws = c.side ? c.side : c.st;
-    c.fork();
-    c.side_reads |= gbuf;
+    hipStream_t ws = c.st;
     LfWgradArgs a;
     a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh; a.s16 = c.s16;
     a.split = P->precision == 3 ? 9 : (P->precision == 4 ? 6 : 0);
     // Batched mode (default): this weight gradient keeps its partial rows in its own region and its reduction joins the
-    // one launch at the end of the pass.  Immediate mode: the transposed-conv phases (their bias rows accumulate in
-    // order), the side-stream option, LF_REDUCE_IMMEDIATE (A/B).
-    static const bool immediate_env = getenv("LF_REDUCE_IMMEDIATE") != nullptr;
+    // one launch at the end of the pass.  Immediate mode: the transposed-conv phases (their bias rows accumulate in order).
     const long wneed = (long)lf_tapwgrad_splits(op.geom) * op.geom.ntaps * op.geom.Cs * op.geom.Cd;
     const long bneed = (long)lf_tapwgrad_bias_rows(op.geom) * op.geom.Cd;
-    const bool batched = !immediate_env && !c.side && !bias_accumulate && !batch_off &&
+    const bool batched = !bias_accumulate && !batch_off &&
                          c.wpart_used + wneed <= P->wpart_all_floats && c.bpart_used + bneed <= P->bpart_all_floats;
     a.partial = batched ? c.at(P->off_wpart_all + c.wpart_used) : c.at(P->off_wpart);
     a.bias_partial = c.grads[cv.p_b] ? (batched ? c.at(P->off_bpart_all + c.bpart_used) : c.at(P->off_bpart)) : nullptr;
@@ -545,7 +524,7 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
 int bn_bwd_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int nparts, double count) {
     // parameter gradients go straight to bn.weight.grad / bn.bias.grad; c1/c2 stay in the workspace
     if (!c.grads[b.p_g] || !c.grads[b.p_b]) return lf_fail("erfnet backward: BatchNorm weight/bias must both require grad");
-    return lf_bn_bwd_finalize(parts, nparts, b.C, count, c.at(b.c1), c.at(b.c2), c.grads[b.p_g], c.grads[b.p_b], c.st);
+    return lf_bn_bwd_finalize(parts, nparts, b.C, count, c.at(b.c1), c.at(b.c2), c.grads[b.p_g], c.grads[b.p_b], c.training, c.st);
 }
 
 // What the LAST data-gradient launch of layer L can do on behalf of layer L-1 (whose output it differentiates):
@@ -576,11 +555,9 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
     const int N = P->N;
     float* stat0 = c.at(P->off_stat0);
     float* bufs[3] = {g0, g1, g2};
-    auto bit = [&](const float* p) -> unsigned { return p == bufs[0] ? 1u : (p == bufs[1] ? 2u : 4u); };
     float* in = g0;
     bool prepped = false;        // `in` already masked by the layer's output ReLU, BN sums in stat0
     int prep_rows = 0;
-    const bool fuse = !getenv("LF_NO_BWD_FUSE");
     for (int li = (int)P->layers.size() - 1; li >= 0; --li) {
         const Layer& L = P->layers[li];
         P->prof_layer = 100 + li;
@@ -591,7 +568,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         float* Y = bufs[(iin + 2) % 3];
         // gradient preparation the final dgrad of THIS layer performs for the previous one
         Prep nx;
-        const bool can_prep = fuse && li > 0 && (L.kind == K_NB || L.kind == K_UP);
+        const bool can_prep = li > 0 && (L.kind == K_NB || L.kind == K_UP);
         if (can_prep) nx = prep_for(c, P->layers[li - 1]);
         auto add_prep = [&](LfTapArgs& a, int& epi) {
             if (!can_prep) return;
@@ -609,7 +586,6 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             LF_TRY(lf_bn_bwd_reduce(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), dm, stat0, npo, L.Cout, ppi, c.s16, c.st));
             LfStatPart rp = {stat0, lf_bn_bwd_reduce_rows(npo), L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, blast, &rp, 1, (double)npo));
-            c.before_write(bit(X) | bit(Y));
             LF_TRY(lf_bn_bwd_apply(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), c.params[blast.p_g], c.at(blast.c1),
                                    c.at(blast.c2), dm, X, L.kind == K_NB ? Y : nullptr, npo, L.Cout, ppi, c.s16, c.st));
             gz = Y;
@@ -617,7 +593,6 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         } else {
             LfStatPart rp = {stat0, prep_rows, L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, blast, &rp, 1, (double)npo));
-            c.before_write(bit(X));
             LF_TRY(lf_bn_bwd_apply(in, nullptr, prelast, c.at(blast.asc), c.at(blast.ash), c.params[blast.p_g], c.at(blast.c1),
                                    c.at(blast.c2), dm, X, nullptr, npo, L.Cout, ppi, c.s16, c.st));
             gz = in;
@@ -631,42 +606,37 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             const float *t1 = c.at(L.b[0]), *t2 = c.at(L.b[1]), *t3 = c.at(L.b[2]);
             const BNRef& b1 = L.bn[0];
             // conv1x3_2: wgrad(t3, g_t4 = X); dgrad -> g_t3 = (.) * [t3 > 0] -> F
-            LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, X, nullptr, nullptr, 0, bit(X)));
+            LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, X, nullptr, nullptr, 0));
             LfTapArgs a = lf_no_args();
             a.mask_src = t3;
-            c.before_write(bit(F));
             LF_TRY(run_gemm(c, L.cv[3].dg[0], X, F, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
             // conv3x1_2: input relu(bn1(t2)) recomputed on the fly; g_y1 -> X with the bn1-backward sums
-            LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, F, c.at(b1.sc), c.at(b1.sh), 0, bit(F)));
+            LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, F, c.at(b1.sc), c.at(b1.sh), 0));
             a = lf_no_args();
             a.aux = t2; a.msc = c.at(b1.sc); a.msh = c.at(b1.sh); a.asc = c.at(b1.asc); a.ash = c.at(b1.ash);
             a.stats = stat0;
-            c.before_write(bit(X));
             LF_TRY(run_gemm(c, L.cv[2].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, a));
-            LfStatPart sp = {stat0, lf_tapgemm_stat_rows(L.cv[2].dg[0].geom), L.Cout, 0};
+            LfStatPart sp = {stat0, c.last_rows, L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, b1, &sp, 1, (double)npo));
-            c.before_write(bit(F));
             LF_TRY(lf_bn_bwd_apply(X, nullptr, t2, c.at(b1.asc), c.at(b1.ash), c.params[b1.p_g], c.at(b1.c1), c.at(b1.c2),
                                    nullptr, F /*g_t2*/, nullptr, npo, L.Cout, ppi, c.s16, c.st));
             // conv1x3_1: g_t1 -> X
-            LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, F, nullptr, nullptr, 0, bit(F)));
+            LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, F, nullptr, nullptr, 0));
             a = lf_no_args();
             a.mask_src = t1;
-            c.before_write(bit(X));
             LF_TRY(run_gemm(c, L.cv[1].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
             // conv3x1_1 (+ residual branch gradient g_z) -> F, optionally prepared for the previous layer
-            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, X, nullptr, nullptr, 0, bit(X)));
+            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, X, nullptr, nullptr, 0));
             a = lf_no_args();
             a.add_src = gz;
             int epi = LF_EPI_ADD;
             add_prep(a, epi);
-            c.before_write(bit(F));
             LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a));
             out = F;
-            if (can_prep) { prepped = true; prep_rows = lf_tapgemm_stat_rows(L.cv[0].dg[0].geom); }
+            if (can_prep) { prepped = true; prep_rows = c.last_rows; }
         } else if (L.kind == K_UP) {
             for (int ph = 0; ph < 4; ++ph)
-                LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, ph > 0, bit(X), true));
+                LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, ph > 0, true));
             LfTapArgs a = lf_no_args();
             int epi = 0;
             if (c.g_enc && L.x == lf_erfnet_encoder_offset(P)) {   // gradient of the --clas heads joins here
@@ -674,13 +644,11 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
                 epi |= LF_EPI_ADD;
             }
             add_prep(a, epi);
-            c.before_write(bit(F));
             LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a));
             out = F;
-            if (can_prep) { prepped = true; prep_rows = lf_tapgemm_stat_rows(L.cv[0].dg[0].geom); }
+            if (can_prep) { prepped = true; prep_rows = c.last_rows; }
         } else if (L.x < 0) {
-            // stem: weight gradient only (the image needs no gradient); shares the split-K scratch -> join first
-            c.join();
+            // stem: weight gradient only (the image needs no gradient)
             const int Cc = 16 - L.Cin, rows = lf_stem_wgrad_rows(N, L.Hin, L.Win);
             if (c.grads[L.cv[0].p_w]) {
                 LF_TRY(lf_stem_wgrad(img, X, N, L.Cin, L.Hin, L.Win, c.at(P->off_wpart), c.at(P->off_bpart), c.s16, c.st));
@@ -690,8 +658,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             }
             out = F;
         } else {
-            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], c.at(L.x), X, nullptr, nullptr, 0, bit(X)));
-            c.before_write(bit(F));
+            LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], c.at(L.x), X, nullptr, nullptr, 0));
             LF_TRY(lf_pool_bwd(c.at(L.x), X, N, L.Hin, L.Win, L.Cin, L.Cout, L.Cout - L.Cin, F, c.s16, c.st));
             for (int ph = 0; ph < 4; ++ph) {
                 LfTapArgs a = lf_no_args();
@@ -711,6 +678,8 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
     if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
         return lf_fail("erfnet: upload of the pack table failed");
     LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
+    if (P->precision == 0)
+        LF_TRY(lf_pack_weights_lds_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed32), c.st));
     if (P->precision == 1 || P->precision == 2)
         LF_TRY(lf_pack_weights_bf16_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed16), c.st));
     if (P->precision >= 3)
@@ -744,30 +713,19 @@ int lf_erfnet_forward(const lf_erfnet_plan* P, const float* img, const float* co
 
 // Backward of the forward that last used `workspace`.  grad_logits (N,Cout,H,W) NCHW; grad_encoder: optional
 // (N,H/8,W/8,128) NHWC gradient w.r.t. the encoder output (the `shared_encoder` the --clas heads consume);
+// training: the mode the forward ran in (0 = running statistics: BatchNorm backward is then the affine map's);
 // grads_host: n_params device pointers receiving d loss / d param (NULL entries are skipped:
 // encoder.output_conv, the unused head).  Gradients are WRITTEN, not accumulated.
 int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* grad_logits,
                        const float* grad_encoder, const float* const* params_host, float* const* grads_host,
-                       const float* dropmask, int head, void* workspace, size_t workspace_bytes, void* stream) {
+                       const float* dropmask, int training, int head, void* workspace, size_t workspace_bytes, void* stream) {
     LF_REQUIRE(P && img && grad_logits && params_host && grads_host && workspace, "lf_erfnet_backward: null pointer");
     LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_backward: workspace too small");
     LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_backward: head %d out of range", head);
-    Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, 1, (hipStream_t)stream};
+    Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, training, (hipStream_t)stream};
     c.g_enc = grad_encoder;
     c.s16 = P->precision == 2;
     LF_REQUIRE(!(c.s16 && grad_encoder), "lf_erfnet_backward: grad_encoder is not supported with bf16 tensors (mode 2)");
-    // Measured on MI355X (batch 32): running the weight gradients concurrently with the data gradients is
-    // ~5 % SLOWER than one stream (two 2-waves/SIMD kernels evict each other's L2 working set), so the side
-    // stream is opt-in.
-    if (getenv("LF_SIDE_STREAM")) {
-        if (!P->side) {
-            if (hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&P->ev_main, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&P->ev_side, hipEventDisableTiming) != hipSuccess)
-                return lf_fail("lf_erfnet_backward: could not create the side stream");
-        }
-        c.side = P->side;
-    }
     float *gA = c.at(P->off_gA), *gB = c.at(P->off_gB), *gC = c.at(P->off_gC);
     const int h = P->H / 2, w = P->W / 2, K = P->Cout + head;
     const int pw = P->p_head_w[head], pb = P->p_head_b[head];
@@ -780,7 +738,6 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
     LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.s16, c.st));
     LF_TRY(backward_layers(c, img, gA, gB, gC));
     if (!c.reduce_jobs.empty()) LF_TRY(lf_wgrad_reduce_batch_launch(c.reduce_jobs.data(), (int)c.reduce_jobs.size(), c.st));
-    c.join();          // every gradient is complete once the caller's stream reaches this point
     return 0;
 }
 
@@ -789,11 +746,11 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
 // forward/backward calls; lf_erfnet_profile_read waits for them, adds up elapsed ms, algorithmic FLOPs
 // (2 * pixels * Cs * Cd * taps) and launch counts per family (3 doubles each), and clears the records.
 int lf_erfnet_profile(const lf_erfnet_plan* P, int enable) { P->prof_on = enable; return 0; }
-int lf_erfnet_profile_read(const lf_erfnet_plan* P, double* out6) {
+int lf_erfnet_profile_read(const lf_erfnet_plan* P, double* out6, const char* csv_path) {
     for (int i = 0; i < 6; ++i) out6[i] = 0.0;
     FILE* f = nullptr;
-    if (const char* path = getenv("LF_PROFILE_CSV")) {
-        f = fopen(path, "w");
+    if (csv_path) {
+        f = fopen(csv_path, "w");
         if (f) fprintf(f, "family,layer,Cs,Cd,ntaps,npix,epi,us,tflops\n");
     }
     for (auto& r : P->prof) {

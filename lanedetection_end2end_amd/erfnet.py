@@ -157,6 +157,7 @@ class _BackboneFn(torch.autograd.Function):
             ctx.mark_non_differentiable(enc)
         ctx.net, ctx.plan, ctx.head, ctx.ws, ctx.x, ctx.dropmask = net, plan, head, ws, x, dropmask
         ctx.params = params
+        ctx.training = int(training)        # BatchNorm backward follows the mode the forward ran in
         return logits, enc
 
     @staticmethod
@@ -185,8 +186,8 @@ class _BackboneFn(torch.autograd.Function):
         glogits = glogits.contiguous()
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _lib.ptr(genc),
-                                          _ptr_array(params), _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.head,
-                                          _lib.ptr(ctx.ws), plan.ws_bytes, _lib.stream()), "lf_erfnet_backward")
+                                          _ptr_array(params), _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.training,
+                                          ctx.head, _lib.ptr(ctx.ws), plan.ws_bytes, _lib.stream()), "lf_erfnet_backward")
         ctx.ws = None
         return (None, None, None, None, None, None) + tuple(grads)
 

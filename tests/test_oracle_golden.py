@@ -197,3 +197,35 @@ def test_backbone_oracle(golden_backbone, tag, dtype, tol):
     with torch.no_grad():
         _, dec = erfnet_oracle.erfnet_forward(x, P, training=False)
     assert relerr(dec, golden_backbone["bb_eval_dec_" + tag]) < max(tol, 1e-6 if tag == 'f32' else 0)
+
+
+def test_e2e_oracle_matches_reference_goldens(golden_e2e):
+    """oracle/e2e_oracle.py (the composition the full-size GPU tests and bench.py's parity leg use) against the real
+    reference's end-to-end runs at 4x3x256x512 (BEV) and 2x3x256x512 (BP), fp64 legs: lane coefficients, loss,
+    d loss / d logits, every parameter-gradient norm."""
+    from oracle import e2e_oracle, erfnet_oracle, inputs
+    import torch
+    N, R = 4, 256
+    x = torch.from_numpy(inputs.images(N, R, 2 * R, seed=61))
+    gt = inputs.bev_gt_params(N, seed=62)
+    o = e2e_oracle.bev_step(x, erfnet_oracle.make_params(seed=4, out_channels=2), gt, torch.float64, R)
+    assert relerr(o["beta"], golden_e2e["e2e_bev_beta_f64"]) < 1e-9
+    assert abs(o["loss"] - float(golden_e2e["e2e_bev_loss_f64"])) < 1e-10 * abs(o["loss"])
+    assert relerr(o["logits"][:, :, ::16, ::16], golden_e2e["e2e_bev_logits_sample_f64"]) < 1e-10
+    assert relerr(o["dlogits"][:, :, ::16, ::16], golden_e2e["e2e_bev_dlogits_sample_f64"]) < 1e-7
+    keys, n64 = list(golden_e2e["e2e_bev_grad_keys"]), golden_e2e["e2e_bev_grad_norms_f64"]
+    for k, ref in zip(keys, n64):
+        k = k[len("net."):] if k.startswith("net.") else k
+        got = o["grad_norms"][k]
+        if ref < 0:
+            assert got is None, k
+        else:
+            assert abs(got - ref) <= 1e-7 * max(ref, n64.max() * 1e-6), (k, got, ref)
+    # BP tree
+    N, K = 2, 4
+    x = torch.from_numpy(inputs.images(N, R, 2 * R, seed=71))
+    lanes, valid = inputs.bp_targets(N, K, R, seed=72)
+    o = e2e_oracle.bp_step(x, erfnet_oracle.make_params(seed=5, out_channels=K), lanes, valid, torch.float64, R, K)
+    assert np.abs(o["x_cal"] - golden_e2e["e2e_bp_xcal_f64"]).max() < 1e-6         # pixels
+    assert abs(o["loss"] - float(golden_e2e["e2e_bp_loss_f64"])) < 1e-8 * abs(o["loss"])
+    assert relerr(o["dlogits"][:, :, ::16, ::16], golden_e2e["e2e_bp_dlogits_sample_f64"]) < 1e-6

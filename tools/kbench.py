@@ -38,7 +38,7 @@ def timeit(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", type=int, nargs="+", default=[2])
+    ap.add_argument("--variants", type=int, nargs="+", default=[0, 2], help="0 = shipped selection (LDS-tiled kernel), 2 = streaming kernel")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--bf16", action="store_true", help="bf16 matrix-core kernel for fwd / dgrad; the torch check runs on "
@@ -112,13 +112,16 @@ if __name__ == "__main__" and "--phases" not in sys.argv:
     main()
 
 
-def phases(batch=32, split=0):
-    """Per-wave phase breakdown of the forward tap-GEMM (s_memtime stamps): prologue / main loop / epilogue."""
+def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16), (64, 64, 128, 1, 1))):
+    """Per-wave phase breakdown of the forward tap-GEMM (s_memrealtime stamps, 100 MHz): first operands resident /
+    main loop / epilogue + store drain, in microseconds from the first wave's start; launch time by HIP events."""
     import numpy as np
     lib = _lib.load()
     lib.lf_debug_set_ops_precision(split)
+    lib.lf_debug_set_tapgemm_variant(variant)
+    lib.lf_debug_set_lds_ablate(ablate)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for C, H, W, axis, d in [(128, 32, 64, 1, 16), (64, 64, 128, 1, 1)]:
+    for C, H, W, axis, d in shapes:
         N = batch
         x = torch.randn(N, H, W, C, device="cuda")
         w = torch.randn(C, C, 3, device="cuda") * 0.05
@@ -127,18 +130,26 @@ def phases(batch=32, split=0):
         scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C), device="cuda")
         nw = ((N * H * W + 255) // 256) * 4 * (C // 64)
         dbg = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
-        for _ in range(3):
-            _lib.check(lib.lf_debug_conv1d_fwd_phases(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, P(scratch), P(dbg), st), "phases")
+        f = lambda: _lib.check(lib.lf_debug_conv1d_fwd_phases(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, P(scratch), P(dbg), st), "phases")
+        us = timeit(f, 10) * 1e6
+        dbg.zero_()
+        f()
         torch.cuda.synchronize()
         t = dbg.view(nw, 8).cpu().numpy().astype(np.float64)
+        t = t[t[:, 0] > 0] * 0.01                      # waves that ran; ticks -> microseconds
         t0 = t[:, 0].min()
-        pro, main, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
-        print("split=%d C=%d N=%d waves=%d (s_memtime ticks): start spread %.0f | prologue %.0f | main loop %.0f (min %.0f max %.0f) | "
-              "epilogue %.0f | last end - first start %.0f" % (split, C, N, nw, (t[:, 0] - t0).max(), pro.mean(), main.mean(), main.min(),
-                                                               main.max(), epi.mean(), t[:, 3].max() - t0), flush=True)
+        print("var %d ablate %d C=%3d N=%3d waves %5d | launch+pack %6.1f us | start spread %5.2f | operands ready %5.2f (max %5.2f) | "
+              "main loop done %6.2f (min %6.2f max %6.2f) | stores retired %6.2f (max %6.2f)"
+              % (variant, ablate, C, N, len(t), us, (t[:, 0] - t0).max(), (t[:, 1] - t0).mean(), (t[:, 1] - t0).max(),
+                 (t[:, 2] - t0).mean(), (t[:, 2] - t0).min(), (t[:, 2] - t0).max(), (t[:, 3] - t0).mean(), (t[:, 3] - t0).max()),
+              flush=True)
+    lib.lf_debug_set_lds_ablate(0)
+    lib.lf_debug_set_tapgemm_variant(0)
 
 
 if __name__ == "__main__" and "--phases" in sys.argv:
     sp = int(sys.argv[sys.argv.index("--split") + 1]) if "--split" in sys.argv else 0
-    for nb in (16, 32, 64):
-        phases(nb, sp)
+    for nb in (32, 64):
+        phases(nb, sp, variant=2)
+        for ab in (0, 1, 4, 2, 6):
+            phases(nb, sp, variant=0, ablate=ab)
