@@ -37,6 +37,7 @@ struct LfTapArgs {
     const float* src;
     const float* wp;        // packed weights [tap][Cs/4][Cd][4]
     const float* wp32;      // the same weights as [tap][Cs/32][Cd][32] (LDS-tiled kernel, lf_convlds.hip); null = not available
+    const float* zeros;     // >= 32 zero floats (128-byte aligned): what the LDS-tiled kernel's DMA reads for padding pixels
     int s16;                // 1: src / dst / mask_src / add_src / aux hold bf16 elements (needs wp16)
     const void* wp16;       // non-null selects the bf16 matrix-core kernel: packed bf16 weights [tap][ceil(Cs/32)*4][Cd][8]
     int split;              // 9 or 6: fp32 on the bf16 matrix cores from 3-way split operands (tapgemm_split_kernel);
@@ -119,9 +120,11 @@ struct LfPackEntry {
 int lf_pack_weights_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena,
                            hipStream_t st);
 // wp32[((t*(Kc/32) + k/32)*Nc + n)*32 + k%32] for the entries the LDS-tiled kernel takes (same dst_off, separate arena)
+// (both also clear the 64-float zero page `zeros` that LfTapArgs::zeros points to)
 int lf_pack_weights_lds_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena32,
-                               hipStream_t st);
-int lf_pack_one_lds_launch(const float* w, float* dst, int Kc, int Nc, int ntaps, long sk, long sn, int flip, hipStream_t st);
+                               float* zeros, hipStream_t st);
+int lf_pack_one_lds_launch(const float* w, float* dst, int Kc, int Nc, int ntaps, long sk, long sn, int flip, float* zeros,
+                           hipStream_t st);
 long lf_pack_bf16_elems(int Kc, int Nc, int ntaps);
 // split weights: 3 bf16 pieces per element, entry e at 3 * e.dst16_off of arena48 (entries with Kc % 32 != 0 are skipped)
 int lf_pack_weights_split_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, void* arena48,

@@ -50,13 +50,15 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
 
 template <int TC>
 struct LdsCfg {
-    static constexpr int WN = TC / 64;            // wave blocks over output channels
-    static constexpr int WM = 4 / WN;             // wave blocks over pixels
-    static constexpr int TP = WM * 64;            // pixels per tile
-    static constexpr int XI = TP / 32;            // X DMA instructions per wave and chunk (8 rows each)
-    static constexpr int WI = TC / 32;            // W DMA instructions per wave and chunk
-    static constexpr int SUB = (TP + TC) * 32;    // floats per 32-channel sub-chunk: X rows, then W rows
-    static constexpr int STAGE = 2 * SUB;         // a stage = one tap x 64 source channels
+    static constexpr int WN = TC / 64;            // wave blocks over output channels (within a group)
+    static constexpr int WM = 4 / WN;             // wave blocks over pixels (within a group)
+    static constexpr int TPG = WM * 64;           // pixels per group tile; a workgroup's super-tile = 2 * TPG pixels
+    static constexpr int XI = TPG / 32;           // X DMA instructions per wave and chunk (8 rows each)
+    static constexpr int WI = TC / 32;            // W DMA instructions per group-A wave and chunk
+    static constexpr int XS = TPG * 32;           // floats of one X chunk (one group, 32 channels)
+    static constexpr int WS = TC * 32;            // floats of one W chunk
+    static constexpr int OFF_W = 4 * XS;          // [X_A 0][X_A 1][X_B 0][X_B 1][W 0][W 1][W 2]
+    static constexpr int TOTAL = 4 * XS + 3 * WS; // 112 KB (TC = 128) / 152 KB (TC = 64)
 };
 
 // tap offsets by a select chain: indexing the kernel-argument arrays with a run-time tap makes hipcc copy them to scratch
@@ -82,38 +84,58 @@ __device__ __forceinline__ void advance(PixCoord& c, int step, int Hl, int Wl) {
     if (c.x >= Wl) { c.x -= Wl; if (++c.y >= Hl) { c.y = 0; ++c.n; } }
 }
 
-// The LDS (2 stages = 128 / 160 KB: one workgroup per CU) is DYNAMIC so that hipcc budgets registers by the launch bounds
-// (256 per wave) alone: told the real LDS size it plans for one wave per SIMD, parks the accumulators in AGPRs and copies all
-// 64 of them to VGPRs and back around every chunk (measured: 79 instead of 54 us for the 128-channel launch).
-extern __shared__ __attribute__((aligned(16))) float lf_lds_dyn[];   // the ONLY LDS object (stages; statistics reduction at the end)
+// The LDS is DYNAMIC so that hipcc budgets registers by the launch bounds (256 per wave) alone: told the real size (one
+// workgroup per CU) it plans for the whole register file, parks the accumulators in AGPRs and copies all 64 of them to
+// VGPRs and back around every chunk (measured on an earlier form of this kernel: 79 instead of 54 us per launch).
+extern __shared__ __attribute__((aligned(16))) float lf_lds_dyn[];   // the ONLY LDS object
 
-template <int TC, int PROC, bool STATS>
-__global__ __launch_bounds__(256, 2) void tapgemm_lds_kernel(const LfTapGeom g, const LfTapArgs a, const int epi, const int ntiles) {
+// Workgroup = 512 threads = two 4-wave groups A (waves 0-3) and B (waves 4-7); waves w and w+4 share SIMD w.  Each group
+// owns one TPG-pixel tile of the workgroup's super-tile and walks the same (tap, 32-channel chunk) items, but B runs ONE
+// PHASE behind A, phase-locked by the workgroup barrier: while one group streams the 64 MFMAs of an item (its "compute"
+// phase, 4096 matrix cycles), the other is in its "service" phase -- epilogue of a finished tile, LDS-DMA requests for the
+// item after next, fragment reads for its next item -- so every SIMD's matrix pipe always has exactly one wave issuing
+// back-to-back MFMAs and nobody's stalls land in front of the pipe.  (Measured before this form: two independent 4-wave
+// workgroups per CU, or one with a lone wave per SIMD, keep the pipes only 65-80 % busy: every wait of a wave idles its SIMD
+// unless the partner happens to be ready, and the older workgroup wins every arbitration.)
+// Buffers: X chunks are private to a group and double-buffered (a group refills the buffer it has just finished reading,
+// during its service phase); the W chunk is shared (A loads it, both read it one phase apart) and needs three buffers.
+// Every DMA is waited for (vmcnt(0)) by its issuer at the end of the compute phase that follows -- a full phase of lead --
+// and published by that phase's barrier.
+// EPI: the epilogue flags as a compile-time constant for the combinations the network uses (straight-line epilogue: all of a
+// tile's operand loads in flight together), or -1 = read them from `epi_rt` (hipcc then branches around every load and
+// waits for each one separately).
+template <int TC, int PROC, int EPI>
+__global__ __launch_bounds__(512, 2) void tapgemm_lds_kernel(const LfTapGeom g, const LfTapArgs a, const int epi_rt, const int nsuper) {
     using C = LdsCfg<TC>;
+    const int epi = EPI >= 0 ? EPI : (epi_rt & 63);
+    constexpr bool STATS = EPI < 0 || (EPI & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0;
     float* const lds = lf_lds_dyn;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, gw = wave & 3;                    // group (0 = A, 1 = B), wave within the group
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wn = wave % C::WN, wm = wave / C::WN;
+    const int wn = gw % C::WN, wm = gw / C::WN;
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
-    const int nch = g.Cs >> 6;             // 64-channel chunks per tap
+    const int nch = g.Cs >> 5;                                   // 32-channel chunks per tap
     const int ntaps = g.ntaps;
     // tools/kbench.py --phases: per-wave wall-clock stamps (s_memrealtime, 100 MHz) and ablation switches in the high bits of
-    // `epi` (65536 = no stores, 131072 = no MFMAs, 262144 = only the first chunk is loaded); 0 in the product path
+    // `epi` (65536 = no stores, 131072 = no MFMAs, 262144 = no DMA after the first items); 0 in the product path
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
     if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memrealtime();
-    const bool ab_nostore = (epi & 65536) != 0, ab_nomma = (epi & 131072) != 0, ab_noload = (epi & 262144) != 0;
+    const bool ab_nostore = (epi_rt & 65536) != 0, ab_nomma = (epi_rt & 131072) != 0, ab_noload = (epi_rt & 262144) != 0;
 
-    // ---- tile schedule: workgroup b runs on XCD b % 8 (observed); every XCD gets a contiguous range of tiles so that the
-    // halo rows neighbouring tiles share meet in one L2
+    // ---- super-tile schedule: workgroup b runs on XCD b % 8 (observed); every XCD gets a contiguous range so that the halo
+    // rows neighbouring tiles share meet in one L2
     const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    int tile0, tstride, tend;
-    if ((G & 7) == 0 && (ntiles & 7) == 0) {
-        const int per = ntiles >> 3, gp = G >> 3, x = b & 7;
-        tile0 = x * per + (b >> 3); tstride = gp; tend = (x + 1) * per;
+    int st0, ststride, stend;
+    if ((G & 7) == 0 && (nsuper & 7) == 0) {
+        const int per = nsuper >> 3, gp = G >> 3, x = b & 7;
+        st0 = x * per + (b >> 3); ststride = gp; stend = (x + 1) * per;
     } else {
-        tile0 = b; tstride = G; tend = ntiles;
+        st0 = b; ststride = G; stend = nsuper;
     }
+    const int ntile = (stend - st0 + ststride - 1) / ststride;  // tiles of this group (>= 1)
+    const int nitems = ntile * ntaps * nch;
 
     // ---- per-lane constants
     const int swd = lane >> 4;                                   // DMA rows: (row >> 1) & 7 = ((i & 1) << 2) | (lane >> 4)
@@ -122,27 +144,38 @@ __global__ __launch_bounds__(256, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
     xslot[1] = ((lane & 7) ^ (swd | 4)) * 4;
     unsigned woff[C::WI];                                        // weights: float offset of this lane's 16 bytes inside a chunk
 #pragma unroll
-    for (int i = 0; i < C::WI; ++i) woff[i] = (unsigned)(((wave * C::WI + i) * 8 + (lane >> 3)) * 32 + xslot[i & 1]);
+    for (int i = 0; i < C::WI; ++i) woff[i] = (unsigned)(((gw * C::WI + i) * 8 + (lane >> 3)) * 32 + xslot[i & 1]);
     const int swl = (lane >> 1) & 7;                             // fragment rows: (row >> 1) & 7
     int fo[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) fo[q] = ((2 * q + lh) ^ swl) * 4;
-    const int aA = C::TP * 32 + (wn * 64 + l31) * 32;            // + i2 * 1024 + fo[q]
-    const int aB = (wm * 64 + l31) * 32;                         // + j2 * 1024 + fo[q]
+    const int aA = (wn * 64 + l31) * 32;                         // inside a W chunk: + i2 * 1024 + fo[q]
+    const int aB = (wm * 64 + l31) * 32;                         // inside an X chunk: + j2 * 1024 + fo[q]
+    float* const xbase = lds + grp * 2 * C::XS;                  // this group's two X buffers
+    float* const wbase = lds + C::OFF_W;
+
+    // ---- item cursors: (tile ordinal, tap, chunk); the load cursor runs one item ahead of the compute cursor
+    struct Cursor { int tile, t, ch, idx; };
+    auto step = [&](Cursor& c) {
+        ++c.idx;
+        if (++c.ch == nch) { c.ch = 0; if (++c.t == ntaps) { c.t = 0; ++c.tile; } }
+    };
 
     // ---- per-tile state
     PixCoord xr[C::XI];                 // pixels of this lane's DMA rows (tile being loaded)
     unsigned xoff[C::XI];               // their source offsets for the tap being loaded
+    unsigned xpad = 0;                  // bit i: row i of that tap is padding (PROC == 0: its DMA reads the zero page instead)
     struct TileInfo { unsigned vbits; unsigned dbase[2]; int pn[2]; bool pv[2]; };
     TileInfo cur, nxt;
     cur.vbits = 0; cur.dbase[0] = cur.dbase[1] = 0; cur.pn[0] = cur.pn[1] = 0; cur.pv[0] = cur.pv[1] = false;
     nxt = cur;
 
-    auto prepare = [&](int tile) {      // DMA rows + fragment / epilogue pixels of `tile`
-        PixCoord c = decompose((unsigned)tile * C::TP + (unsigned)(wave * C::XI * 8 + (lane >> 3)), npix, g.Hl, g.Wl);
+    auto prepare = [&](int tile_ord) {  // DMA rows + fragment / epilogue pixels of this group's tile number tile_ord
+        const unsigned pbase = ((unsigned)(st0 + tile_ord * ststride) * 2u + (unsigned)grp) * C::TPG;
+        PixCoord c = decompose(pbase + (unsigned)(gw * C::XI * 8 + (lane >> 3)), npix, g.Hl, g.Wl);
 #pragma unroll
         for (int i = 0; i < C::XI; ++i) { xr[i] = c; advance(c, 8, g.Hl, g.Wl); }
-        const unsigned p0 = (unsigned)tile * C::TP + (unsigned)(wm * 64 + l31);
+        const unsigned p0 = pbase + (unsigned)(wm * 64 + l31);
         PixCoord f = decompose(p0, npix, g.Hl, g.Wl);
         unsigned vb = 0;
 #pragma unroll
@@ -164,23 +197,34 @@ __global__ __launch_bounds__(256, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
     auto tap_offsets = [&](int t) {
         int dh, dw;
         tap_of(g, t, dh, dw);
+        xpad = 0;
 #pragma unroll
         for (int i = 0; i < C::XI; ++i) {
-            const int sy = min(max(xr[i].y * g.ssh + dh, 0), g.Hs - 1), sx = min(max(xr[i].x * g.ssw + dw, 0), g.Ws - 1);
+            const int syr = xr[i].y * g.ssh + dh, sxr = xr[i].x * g.ssw + dw;
+            const int sy = min(max(syr, 0), g.Hs - 1), sx = min(max(sxr, 0), g.Ws - 1);
             const int nn = min(xr[i].n, g.N - 1);                    // rows past the last pixel re-read image N-1 (never stored)
             xoff[i] = (unsigned)(((nn * g.Hs + sy) * g.Ws + sx) * g.s_pix + g.s_choff + xslot[i & 1]);
+            xpad |= ((sy != syr || sx != sxr) ? 1u : 0u) << i;
         }
     };
-    auto issue = [&](int t, int ch, int stage) {
-        if (ab_noload) return;
+    // requests of item c: this group's X chunk (buffer idx & 1) and, from group A, the shared W chunk (buffer idx % 3)
+    auto issue = [&](const Cursor& c) {
+        if (c.ch == 0) {
+            if (c.t == 0) prepare(c.tile);
+            tap_offsets(c.t);
+        }
+        float* xb = xbase + (c.idx & 1) * C::XS;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            float* sb = lds + stage * C::STAGE + sub * C::SUB;
+        for (int i = 0; i < C::XI; ++i) {
+            const float* src = a.src + xoff[i] + c.ch * 32;
+            if constexpr (PROC == LF_PRO_NONE) src = ((xpad >> i) & 1u) ? a.zeros + xslot[i & 1] : src;     // padding reads zeros
+            glds16(src, xb + (gw * C::XI + i) * 256);
+        }
+        if (grp == 0) {
+            float* wb = wbase + (c.idx % 3) * C::WS;
+            const float* wsrc = a.wp32 + (long)(c.t * nch + c.ch) * C::WS;
 #pragma unroll
-            for (int i = 0; i < C::XI; ++i) glds16(a.src + xoff[i] + ch * 64 + sub * 32, sb + (wave * C::XI + i) * 256);
-            const float* wsrc = a.wp32 + (long)((t * nch + ch) * 2 + sub) * (TC * 32);
-#pragma unroll
-            for (int i = 0; i < C::WI; ++i) glds16(wsrc + woff[i], sb + C::TP * 32 + (wave * C::WI + i) * 256);
+            for (int i = 0; i < C::WI; ++i) glds16(wsrc + woff[i], wb + (gw * C::WI + i) * 256);
         }
     };
 
@@ -190,7 +234,6 @@ __global__ __launch_bounds__(256, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
     for (int i2 = 0; i2 < (STATS ? 2 : 1); ++i2)
 #pragma unroll
         for (int gq = 0; gq < (STATS ? 4 : 1); ++gq) { s1[i2][gq] = zero4(); s2[i2][gq] = zero4(); }
-
     auto clear_acc = [&]() {
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
@@ -200,55 +243,74 @@ __global__ __launch_bounds__(256, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
                 for (int r = 0; r < 16; ++r) acc[i2][j2][r] = 0.f;
     };
 
-    auto compute = [&](int t, int ch, int stage) {
+    // fragments: two register sets; set 0 is filled in the service phase for group 0 of the coming item
+    f32x4 A0[2], A1[2], B0[2], B1[2];
+    auto frag = [&](int idx, int q, int s) {
+        const float* wb = wbase + (idx % 3) * C::WS;
+        const float* xb = xbase + (idx & 1) * C::XS;
+        A0[s] = *reinterpret_cast<const f32x4*>(wb + aA + fo[q]);
+        A1[s] = *reinterpret_cast<const f32x4*>(wb + aA + 1024 + fo[q]);
+        B0[s] = *reinterpret_cast<const f32x4*>(xb + aB + fo[q]);
+        B1[s] = *reinterpret_cast<const f32x4*>(xb + aB + 1024 + fo[q]);
+    };
+    // One item = 4 groups of 8 channels, 16 MFMAs each.  Order inside a group: 4 MFMAs, the 4 fragment requests of the NEXT group,
+    // 12 MFMAs.  PROC == 0 needs no VALU at all (padding arrives as zeros); with the BN+ReLU prologue the next group's pixel
+    // fragments are transformed between the last 8 MFMAs, four VALU per MFMA, so that no burst of vector work ever sits in front
+    // of the matrix pipe (tools/mfma_mix.hip: 8 v_cndmask in a row ahead of every 16 MFMAs cost 9 %).
+    auto transform = [&](const Cursor& c, int q, f32x4& b0, f32x4& b1, bool v0, bool v1) {
+        // per-channel scale / shift of channels ch*32 + 8q + 4*lh + {0..3}: uniform addresses -> scalar loads (lgkmcnt, not
+        // vmcnt: an ordinary vector load here would drain the DMA queue), selected by the lane's k-half
+        const float* psc = a.pro_sc + c.ch * 32 + q * 8;
+        const float* psh = a.pro_sh + c.ch * 32 + q * 8;
+        f32x4 sc, sh;
+        sc.x = lh ? psc[4] : psc[0]; sc.y = lh ? psc[5] : psc[1]; sc.z = lh ? psc[6] : psc[2]; sc.w = lh ? psc[7] : psc[3];
+        sh.x = lh ? psh[4] : psh[0]; sh.y = lh ? psh[5] : psh[1]; sh.z = lh ? psh[6] : psh[2]; sh.w = lh ? psh[7] : psh[3];
+        b0 = sel4(v0, max0(b0 * sc + sh)); b1 = sel4(v1, max0(b1 * sc + sh));
+    };
+    auto mma = [&](int cb, int s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[cb][s], B0[cb][s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[cb][s], B1[cb][s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[cb][s], B0[cb][s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[cb][s], B1[cb][s], acc[1][1], 0, 0, 0);
+    };
+    auto compute = [&](const Cursor& c) {
         if (ab_nomma) return;
-        const float* sb = lds + stage * C::STAGE;
-        const bool v0 = (cur.vbits >> (2 * t)) & 1u, v1 = (cur.vbits >> (2 * t + 1)) & 1u;
-        // 8 groups of 8 channels (two 32-channel sub-chunks); the fragments of group k+1 are requested before the 16 MFMAs of
-        // group k (two register sets)
-        f32x4 A0[2], A1[2], B0[2], B1[2];
-        auto frag = [&](int k, int s) {
-            const float* sq = sb + (k >> 2) * C::SUB;
-            const int q = k & 3;
-            A0[s] = *reinterpret_cast<const f32x4*>(sq + aA + fo[q]);
-            A1[s] = *reinterpret_cast<const f32x4*>(sq + aA + 1024 + fo[q]);
-            B0[s] = *reinterpret_cast<const f32x4*>(sq + aB + fo[q]);
-            B1[s] = *reinterpret_cast<const f32x4*>(sq + aB + 1024 + fo[q]);
-        };
-        frag(0, 0);
+        const bool v0 = (cur.vbits >> (2 * c.t)) & 1u, v1 = (cur.vbits >> (2 * c.t + 1)) & 1u;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int cb = k & 1;
-            if (k < 7) frag(k + 1, cb ^ 1);
-            __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this group's MFMAs (hipcc otherwise sinks them to their use)
-            f32x4 b0 = B0[cb], b1 = B1[cb];
+        for (int q = 0; q < 4; ++q) {
+            const int cb = q & 1;
+            mma(cb, 0);
+            if (q < 3) frag(c.idx, q + 1, cb ^ 1);
+            mma(cb, 1);
             if constexpr (PROC == LF_PRO_BNRELU) {
-                // per-channel scale / shift of channels ch*64 + 8k + 4*lh + {0..3}: uniform addresses -> scalar loads (lgkmcnt,
-                // not vmcnt: an ordinary vector load here would drain the DMA queue), selected by the lane's k-half
-                const float* psc = a.pro_sc + ch * 64 + k * 8;
-                const float* psh = a.pro_sh + ch * 64 + k * 8;
-                f32x4 sc, sh;
-                sc.x = lh ? psc[4] : psc[0]; sc.y = lh ? psc[5] : psc[1]; sc.z = lh ? psc[6] : psc[2]; sc.w = lh ? psc[7] : psc[3];
-                sh.x = lh ? psh[4] : psh[0]; sh.y = lh ? psh[5] : psh[1]; sh.z = lh ? psh[6] : psh[2]; sh.w = lh ? psh[7] : psh[3];
-                b0 = max0(b0 * sc + sh); b1 = max0(b1 * sc + sh);
+                if (q < 3) transform(c, q + 1, B0[cb ^ 1], B1[cb ^ 1], v0, v1);
             }
-            b0 = sel4(v0, b0); b1 = sel4(v1, b1);
+            mma(cb, 2);
+            mma(cb, 3);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);            // 4 MFMA
+            if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); // 4 DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);            // 4 MFMA
+            if constexpr (PROC == LF_PRO_BNRELU) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[cb][s], b0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[cb][s], b1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[cb][s], b0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[cb][s], b1[s], acc[1][1], 0, 0, 0);
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);    // <= 5 VALU behind it
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     auto epilogue = [&]() {            // tile `cur`: bias, residual / masks, ReLU, store, statistics
+        int opaque = 0;                 // keeps the per-channel vector loads INSIDE the epilogue: they are tile-invariant and
+        asm volatile("" : "+s"(opaque));   // hipcc otherwise hoists all 8 x 5 of them out of the item loop (128 registers, spills)
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int co = wn * 64 + i2 * 32 + gq * 8 + lh * 4;
+                const int co = wn * 64 + i2 * 32 + gq * 8 + lh * 4 + opaque;
                 const f32x4 bs = a.bias ? ldg4(a.bias + co) : zero4();
                 f32x4 msc, msh, asc, ash;
                 if (epi & LF_EPI_MASKBN) { msc = ldg4(a.msc + co); msh = ldg4(a.msh + co); }
@@ -275,97 +337,94 @@ __global__ __launch_bounds__(256, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
                         }
                     }
                 }
+                // operand loads are batched over two channel groups (<= 12 float4 in flight): hoisting all of a tile's loads
+                // to the top spills 100+ registers
+                if (gq & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
 
-    // ---- flat pipeline over (tile, tap, chunk) items
-    int tile = tile0;
-    if (tile < tend) {
-        prepare(tile);
-        cur = nxt;
-        tap_offsets(0);
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {     // the first chunk (always loaded, also under the no-load ablation)
-            float* sb = lds + sub * C::SUB;
-#pragma unroll
-            for (int i = 0; i < C::XI; ++i) glds16(a.src + xoff[i] + sub * 32, sb + (wave * C::XI + i) * 256);
-#pragma unroll
-            for (int i = 0; i < C::WI; ++i) glds16(a.wp32 + (long)sub * (TC * 32) + woff[i], sb + C::TP * 32 + (wave * C::WI + i) * 256);
+    // ---- prologue: items 0 of both groups
+    Cursor cc = {0, 0, 0, 0}, lc = {0, 0, 0, 0};            // compute cursor, load cursor
+    issue(lc);
+    cur = nxt;
+    step(lc);
+    clear_acc();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memrealtime();
+    if (grp == 1) __syncthreads();          // B runs one phase behind A (A is in its first service phase)
+
+    bool pending_epi = false;
+    for (int j = 0; j < nitems; ++j) {
+        // ---- service phase of item j (the partner group computes)
+        if (pending_epi) {                  // the tile that ended with item j-1
+            epilogue();
+            clear_acc();
+            cur = nxt;
+            pending_epi = false;
         }
-        clear_acc();
+        if (lc.idx < nitems && !(ab_noload && lc.idx > 0)) issue(lc);     // item j+1 (its tile's coordinates go to `nxt`)
+        if (lc.idx < nitems) step(lc);
+        frag(cc.idx, 0, 0);
+        if constexpr (PROC == LF_PRO_BNRELU)
+            transform(cc, 0, B0[0], B1[0], (cur.vbits >> (2 * cc.t)) & 1u, (cur.vbits >> (2 * cc.t + 1)) & 1u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute phase of item j
+        compute(cc);
+        if (cc.ch == nch - 1 && cc.t == ntaps - 1) pending_epi = true;
+        step(cc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my requests of the service phase above have landed ...
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                       // ... and are published
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (a.dbg) {
+        asm volatile("" ::"v"(acc[0][0][0]));
+        tstamp[2] = __builtin_amdgcn_s_memrealtime();
+    }
+    epilogue();                              // the last tile
+    if (grp == 0) __builtin_amdgcn_s_barrier();              // pairs B's extra first barrier (B's last compute phase)
+    if (a.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memrealtime();
-        int t = 0, ch = 0, stage = 0;
-        bool pending_epi = false;        // the previous tile's accumulators still await their epilogue
-        for (;;) {
-            // next item
-            int nt = t, nc = ch + 1, ntile = tile;
-            if (nc == nch) { nc = 0; if (++nt == ntaps) { nt = 0; ntile = tile + tstride; } }
-            const bool has_next = ntile < tend;
-            if (pending_epi) {           // first item of a tile: finish the previous one before touching the accumulators
-                epilogue();
-                clear_acc();
-                cur = nxt;
-                pending_epi = false;
-            }
-            if (has_next) {
-                if (nc == 0) {
-                    if (nt == 0) prepare(ntile);
-                    tap_offsets(nt);
-                }
-                issue(nt, nc, stage ^ 1);
-            }
-            compute(t, ch, stage);
-            if (nt == 0 && nc == 0) {    // that was the tile's last chunk
-                if (!has_next) break;
-                pending_epi = true;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            t = nt; ch = nc; tile = ntile; stage ^= 1;
-        }
-        if (a.dbg) {
-            asm volatile("" ::"v"(acc[0][0][0]));
-            tstamp[2] = __builtin_amdgcn_s_memrealtime();
-        }
-        epilogue();
-        if (a.dbg) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tstamp[3] = __builtin_amdgcn_s_memrealtime();
-            if (lane == 0) {
-                unsigned long long* d = a.dbg + ((unsigned long long)b * 4 + wave) * 8;
-                d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
-            }
+        tstamp[3] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* d = a.dbg + ((unsigned long long)b * 8 + wave) * 8;
+            d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
         }
     }
 
     if constexpr (STATS) {
-        // one partial row per workgroup: red[v][thread] through the (now idle) stage memory, summed in a fixed order
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        float* red = lds;
+        // one partial row per workgroup: red[v][thread] through the (now idle) LDS, sums then sums of squares (64 KB each),
+        // added in a fixed order
+        const int tid = threadIdx.x;
 #pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
+        for (int k = 0; k < 2; ++k) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            float* red = lds;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
+            for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    red[(i2 * 16 + gq * 4 + e) * 256 + threadIdx.x] = s1[i2][gq][e];
-                    red[(32 + i2 * 16 + gq * 4 + e) * 256 + threadIdx.x] = s2[i2][gq][e];
-                }
-        __syncthreads();
-        if ((int)threadIdx.x < 2 * TC) {
-            const int k = threadIdx.x / TC, c = threadIdx.x % TC;
-            const int cwn = c >> 6, i2 = (c >> 5) & 1, gq = (c >> 3) & 3, clh = (c >> 2) & 1, e = c & 3;
-            const float* row = red + (k * 32 + i2 * 16 + gq * 4 + e) * 256;
-            float sum = 0.f;
-            for (int w = 0; w < C::WM; ++w) {
-                const float* rw = row + (w * C::WN + cwn) * 64 + clh * 32;
-                for (int j = 0; j < 32; ++j) sum += rw[(j + threadIdx.x) & 31];      // rotated start: conflict-free, fixed order per thread
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) red[(i2 * 16 + gq * 4 + e) * 512 + tid] = k == 0 ? s1[i2][gq][e] : s2[i2][gq][e];
+            __syncthreads();
+            if (tid < TC) {
+                const int c = tid;
+                const int cwn = c >> 6, i2 = (c >> 5) & 1, gq = (c >> 3) & 3, clh = (c >> 2) & 1, e = c & 3;
+                const float* row = red + (i2 * 16 + gq * 4 + e) * 512;
+                float sum = 0.f;
+                for (int gr = 0; gr < 2; ++gr)
+                    for (int w = 0; w < C::WM; ++w) {
+                        const float* rw = row + (gr * 4 + w * C::WN + cwn) * 64 + clh * 32;
+                        for (int jj = 0; jj < 32; ++jj) sum += rw[(jj + tid) & 31];      // rotated start: conflict-free, fixed order per thread
+                    }
+                a.stats[((long)b * 2 + k) * g.Cd + c] = sum;
             }
-            a.stats[((long)b * 2 + k) * g.Cd + c] = sum;
         }
     }
 }
@@ -373,7 +432,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
 // weights in the order the kernel's DMA wants: wp32[((t*(Kc/32) + k/32)*Nc + n)*32 + k%32] = w[k*sk + n*sn + tapidx[t]]
 __global__ __launch_bounds__(256) void pack_weights_lds_kernel(const LfPackEntry* __restrict__ entries,
                                                               const float* const* __restrict__ params,
-                                                              float* __restrict__ arena) {
+                                                              float* __restrict__ arena, float* __restrict__ zeros) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zeros[threadIdx.x] = 0.f;
     const LfPackEntry e = entries[blockIdx.x];
     if (e.Kc % 32 != 0 || (e.Nc != 64 && e.Nc != 128)) return;
     const float* w = params[e.param];
@@ -391,7 +451,8 @@ __global__ __launch_bounds__(256) void pack_weights_lds_kernel(const LfPackEntry
 }
 
 __global__ __launch_bounds__(256) void pack_one_lds_kernel(const float* __restrict__ w, float* __restrict__ dst, int Kc, int Nc,
-                                                          int ntaps, long sk, long sn, int flip) {
+                                                          int ntaps, long sk, long sn, int flip, float* __restrict__ zeros) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) zeros[threadIdx.x] = 0.f;
     const long total = (long)ntaps * Kc * Nc;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int k32 = (int)(i & 31);
@@ -404,22 +465,22 @@ __global__ __launch_bounds__(256) void pack_one_lds_kernel(const float* __restri
     }
 }
 
-int lds_tiles(const LfTapGeom& g) {
+int lds_super_tiles(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;
-    const int tp = g.Cd == 128 ? LdsCfg<128>::TP : LdsCfg<64>::TP;
-    return lf_cdiv(npix, tp);
+    const int tpg = g.Cd == 128 ? LdsCfg<128>::TPG : LdsCfg<64>::TPG;
+    return lf_cdiv(npix, 2 * tpg);
 }
 
 }  // namespace
 
 bool lf_tapgemm_lds_ok(const LfTapGeom& g) {
-    return g.Cs % 64 == 0 && (g.Cd == 64 || g.Cd == 128) && g.s_pix % 4 == 0 && g.s_choff % 4 == 0 && g.d_pix % 4 == 0 &&
+    return g.Cs % 32 == 0 && (g.Cd == 64 || g.Cd == 128) && g.s_pix % 4 == 0 && g.s_choff % 4 == 0 && g.d_pix % 4 == 0 &&
            g.d_choff % 4 == 0 && g.Wl >= 32 && (long)g.N * g.Hd * g.Wd * g.d_pix < (1L << 31);
 }
 
-// workgroups (= statistics rows) of a launch: persistent, one per CU (its four waves have a SIMD each)
+// workgroups (= statistics rows) of a launch: persistent, one 8-wave workgroup per CU
 int lf_tapgemm_lds_grid(const LfTapGeom& g) {
-    const int nt = lds_tiles(g);
+    const int nt = lds_super_tiles(g);
     return nt < 256 ? nt : 256;
 }
 
@@ -429,23 +490,28 @@ void lf_tapgemm_lds_set_ablate(int mask) { g_lds_ablate = mask; }
 int lf_tapgemm_lds_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st) {
     LF_REQUIRE(lf_tapgemm_lds_ok(g) && a.wp32, "tapgemm_lds: unsupported launch");
     epi |= g_lds_ablate << 16;
-    const int nt = lds_tiles(g);
+    const int nt = lds_super_tiles(g);
     const dim3 grid(lf_tapgemm_lds_grid(g));
-    const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0;
-#define LF_TL1(TCV, PR, STV)                                                                                                \
+    LF_REQUIRE(a.zeros, "tapgemm_lds: zero page missing");
+#define LF_TL1(TCV, PR, EP)                                                                                                 \
     do {                                                                                                                    \
-        constexpr unsigned bytes = 2u * LdsCfg<TCV>::STAGE * sizeof(float);                                                 \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_lds_kernel<TCV, PR, STV>), \
+        constexpr unsigned bytes = (unsigned)LdsCfg<TCV>::TOTAL * sizeof(float);                                            \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapgemm_lds_kernel<TCV, PR, EP>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);         \
         LF_REQUIRE(attr == hipSuccess, "tapgemm_lds: cannot reserve %u bytes of LDS: %s", bytes, hipGetErrorString(attr));  \
-        hipLaunchKernelGGL((tapgemm_lds_kernel<TCV, PR, STV>), grid, dim3(256), bytes, st, g, a, epi, nt);                  \
+        hipLaunchKernelGGL((tapgemm_lds_kernel<TCV, PR, EP>), grid, dim3(512), bytes, st, g, a, epi, nt);                   \
     } while (0)
+    // the epilogue combinations of the network get a compiled-in epilogue; anything else takes the run-time form
 #define LF_TL(TCV)                                                                                                          \
     do {                                                                                                                    \
-        if (pro == LF_PRO_BNRELU && stats) LF_TL1(TCV, 1, true);                                                            \
-        else if (pro == LF_PRO_BNRELU) LF_TL1(TCV, 1, false);                                                               \
-        else if (stats) LF_TL1(TCV, 0, true);                                                                               \
-        else LF_TL1(TCV, 0, false);                                                                                         \
+        const int e = epi & 63;                                                                                             \
+        if (pro == LF_PRO_BNRELU) { if (e == LF_EPI_RELU) LF_TL1(TCV, 1, LF_EPI_RELU); else LF_TL1(TCV, 1, -1); }           \
+        else if (e == 0) LF_TL1(TCV, 0, 0);                                                                                 \
+        else if (e == LF_EPI_RELU) LF_TL1(TCV, 0, LF_EPI_RELU);                                                             \
+        else if (e == LF_EPI_STATS_SQ) LF_TL1(TCV, 0, LF_EPI_STATS_SQ);                                                     \
+        else if (e == LF_EPI_MASK) LF_TL1(TCV, 0, LF_EPI_MASK);                                                             \
+        else if (e == LF_EPI_ADD) LF_TL1(TCV, 0, LF_EPI_ADD);                                                               \
+        else LF_TL1(TCV, 0, -1);      /* the BatchNorm-backward sums (STATS_XHAT): compiled-in flags spill there */ \
     } while (0)
     if (g.Cd == 128) LF_TL(128);
     else LF_TL(64);
@@ -456,14 +522,15 @@ int lf_tapgemm_lds_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int e
 }
 
 int lf_pack_weights_lds_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena32,
-                               hipStream_t st) {
-    hipLaunchKernelGGL(pack_weights_lds_kernel, dim3(nentries, 16), dim3(256), 0, st, entries_dev, params_dev, arena32);
+                               float* zeros, hipStream_t st) {
+    hipLaunchKernelGGL(pack_weights_lds_kernel, dim3(nentries, 16), dim3(256), 0, st, entries_dev, params_dev, arena32, zeros);
     LF_CHECK_LAUNCH("pack_weights_lds");
     return 0;
 }
 
-int lf_pack_one_lds_launch(const float* w, float* dst, int Kc, int Nc, int ntaps, long sk, long sn, int flip, hipStream_t st) {
-    hipLaunchKernelGGL(pack_one_lds_kernel, dim3(64), dim3(256), 0, st, w, dst, Kc, Nc, ntaps, sk, sn, flip);
+int lf_pack_one_lds_launch(const float* w, float* dst, int Kc, int Nc, int ntaps, long sk, long sn, int flip, float* zeros,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(pack_one_lds_kernel, dim3(64), dim3(256), 0, st, w, dst, Kc, Nc, ntaps, sk, sn, flip, zeros);
     LF_CHECK_LAUNCH("pack_one_lds");
     return 0;
 }

@@ -57,6 +57,7 @@ struct lf_erfnet_plan {
     int p_head_w[2], p_head_b[2], n_heads;
     long off_entries, off_packed, packed_floats;
     long off_packed32;                          // the same weights in the LDS-tiled kernel's order (lf_convlds.hip), same dst_off
+    long off_zero;                              // 64 zero floats: the padding source of that kernel's DMA
     long off_packed16, packed16_elems;          // bf16 operand copies of the packed weights (precision modes 1, 2)
     long off_packed48;                          // 3-piece bf16 split of the packed weights (modes 3, 4): 3 * packed16_elems
     mutable int precision = 0;                  // lf_erfnet_set_precision
@@ -290,6 +291,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
     P->off_packed = ws.take(P->packed_floats);
     P->off_packed32 = ws.take(P->packed_floats);
+    P->off_zero = ws.take(64);
     P->off_packed16 = ws.take((P->packed16_elems + 1) / 2);
     P->off_packed48 = ws.take((3 * P->packed16_elems + 1) / 2);
     P->off_stat0 = ws.take(P->stat_floats);
@@ -394,7 +396,7 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
     extra.s16 = c.s16;
-    if (c.P->precision == 0) extra.wp32 = c.packed32(op.pack);
+    if (c.P->precision == 0) { extra.wp32 = c.packed32(op.pack); extra.zeros = c.at(c.P->off_zero); }
     if (c.P->precision == 1 || c.P->precision == 2)
         extra.wp16 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed16) + c.P->packs[op.pack].dst16_off;
     if (c.P->precision >= 3) {      // fp32 from split operands on the bf16 matrix cores (9 or 6 partial products)
@@ -679,7 +681,7 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
         return lf_fail("erfnet: upload of the pack table failed");
     LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
     if (P->precision == 0)
-        LF_TRY(lf_pack_weights_lds_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed32), c.st));
+        LF_TRY(lf_pack_weights_lds_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed32), c.at(P->off_zero), c.st));
     if (P->precision == 1 || P->precision == 2)
         LF_TRY(lf_pack_weights_bf16_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed16), c.st));
     if (P->precision >= 3)

@@ -78,8 +78,9 @@ void pack_conv1d(LfTapArgs& a, const float* w, float* scratch, int C, long sk, l
     } else {
         hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, sk, sn, flip);
         if (C % 32 == 0) {      // the LDS-tiled kernel's order (taken for C = 64 / 128)
-            (void)lf_pack_one_lds_launch(w, scratch + 3L * C * C, C, C, 3, sk, sn, flip, st);
+            (void)lf_pack_one_lds_launch(w, scratch + 3L * C * C, C, C, 3, sk, sn, flip, scratch + 6L * C * C, st);
             a.wp32 = scratch + 3L * C * C;
+            a.zeros = scratch + 6L * C * C;
         }
     }
     a.wp = scratch;

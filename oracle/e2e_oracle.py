@@ -10,9 +10,11 @@ Used by ``tests/test_baseline_configs_gpu.py`` (the BASELINE configs at their ow
 ``parity`` / ``cpu_baseline`` legs.  Reference call sites: BEV/main.py:213-223,264-265 (model -> Area_Loss per lane ->
 backward), BP/main.py:256-263 (early_return + CrossEntropy), :286-305 (backprojection_loss averaged over lanes).
 
-dtype is the BACKBONE dtype ("cpu32" / "cpu64" in the parity triples); the fit and the losses always run in fp64 on
-the logits that backbone produced, which makes |cpu32 - cpu64| the backbone's own fp32 noise -- a floor at or below the
-real reference's (whose fp32 fit adds ~2e-5 of its own).
+dtype is the BACKBONE dtype ("cpu32" / "cpu64" in the parity triples) and the dtype the projective grid is rounded to
+(the reference model cast with .double() builds its grid in fp64, its fp32 self in fp32; the HIP path uses the fp32 grid).
+The fit and the losses always run in fp64 on the logits that backbone produced, which makes |cpu32 - cpu64| the
+backbone's fp32 noise plus the grid rounding -- a floor at or below the real reference's (whose fp32 fit adds ~2e-5 of
+its own).
 """
 from collections import OrderedDict
 
@@ -52,7 +54,8 @@ def bev_step(x, P, gt, dtype=torch.float64, resize=256, mask_percentage=0.3, ord
     Pd = _trainable(P, dtype)
     _, dec = erfnet_oracle.erfnet_forward(x.to(dtype), Pd, training=training, keep_masks=keep_masks)
     M, _ = fit_oracle.bev_homography()
-    grid = fit_oracle.projective_grid(resize, 2 * resize, M.astype(np.float32), True, np.float32)
+    gdt = np.float64 if dtype == torch.float64 else np.float32
+    grid = fit_oracle.projective_grid(resize, 2 * resize, M.astype(np.float32), True, gdt)      # M is fp32 in both (BEV :30)
     zr = fit_oracle.zero_rows_of(resize, mask_percentage)
     c = fit_oracle.wls_forward(dec.detach().numpy(), grid, zr, order, 0.0, 1.0, "square")
     gb = np.zeros_like(c["beta"])
@@ -72,6 +75,8 @@ def bp_step(x, P, lanes, valid, dtype=torch.float64, resize=256, nclasses=4, mas
     Pd = _trainable(P, dtype)
     _, dec = erfnet_oracle.erfnet_forward(x.to(dtype), Pd, training=training)
     M, _ = fit_oracle.bp_homography(resize)
+    # the BP model computes its grid ONCE, in fp32, at construction (BP/Networks/LSQ_layer.py:219,231): an fp64 run of the
+    # reference uses that same fp32 grid widened
     grid = fit_oracle.projective_grid(resize, 2 * resize, M.astype(np.float32), False, np.float32).astype(np.float64)
     grid[~np.isfinite(grid)] = 0.0
     zr = fit_oracle.zero_rows_of(resize, mask_percentage)

@@ -131,7 +131,7 @@ def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16),
         nw = ((N * H * W + 255) // 256) * 4 * (C // 64)
         dbg = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
         f = lambda: _lib.check(lib.lf_debug_conv1d_fwd_phases(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, P(scratch), P(dbg), st), "phases")
-        us = timeit(f, 10) * 1e6
+        us = timeit(f, 300) * 1e6          # long enough for the clocks to settle (a cold 1 ms burst runs ~8 % slower)
         dbg.zero_()
         f()
         torch.cuda.synchronize()
@@ -149,7 +149,7 @@ def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16),
 
 if __name__ == "__main__" and "--phases" in sys.argv:
     sp = int(sys.argv[sys.argv.index("--split") + 1]) if "--split" in sys.argv else 0
-    for nb in (32, 64):
+    for nb in (32,):
         phases(nb, sp, variant=2)
         for ab in (0, 1, 4, 2, 6):
             phases(nb, sp, variant=0, ablate=ab)
