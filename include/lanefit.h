@@ -54,7 +54,9 @@ const char* lf_last_error(void);
  *   grid_xy  (H*W,2) fp32 (x', y') of every pixel; grid_batch_stride = 0 when shared by
  *            all images (always the case in the reference), else floats between images
  *   zero_rows  rows [0,zero_rows) of every map are masked to 0 (LSQ_layer.py:257-258,316)
- *   order 0..3, reg = --reg_ls, y_offset = 1 (BEV :109) or 255 (BP :94)
+ *   order 0..3, reg = --reg_ls added to the diagonal for BOTH solvers (BEV adds it before either factorisation,
+ *     LSQ_layer.py:120-126; BP's GELS has no regulariser, gels.py:10-15: its caller passes reg = 0),
+ *     y_offset = 1 (BEV :109) or 255 (BP :94)
  *   beta     out (N,K,order+1) fp64, coefficients highest power first
  *   zinv     out (N,K,(order+1)^2) fp64, (Y0^T Y0 + reg I)^-1 -- saved for backward
  *   masked   out (N,K,H,W) fp32 weight maps after activation+mask, or NULL to skip
@@ -103,7 +105,9 @@ int lf_backproj_loss(const double* beta, long beta_stride, const double* x_gt, c
 
 /* Class-weighted pixel cross entropy, weighted-mean reduction: BEV/Loss_crit.py:61-75,
  * BP/Loss_crit.py:64-65.  logits (N,C,H,W) fp32, target (N,H,W) int64, weights (C) fp32.
- * acc: 2 doubles of scratch.  loss out fp32 scalar. */
+ * acc: 3 doubles of scratch: weighted loss sum, weight sum, and the NUMBER OF TARGETS OUTSIDE [0, C) -- those pixels get
+ * weight 0 in loss and gradient, and the host raises when the count is non-zero (torch's NLLLoss asserts on them).
+ * loss out fp32 scalar. */
 int lf_ce2d_fwd(const float* logits, const int64_t* target, const float* weights,
                 int N, int C, int H, int W, double* acc, float* loss, void* stream);
 /* grad_logits (N,C,H,W) = upstream * d loss / d logits; `acc` as left by lf_ce2d_fwd. */
@@ -166,6 +170,14 @@ int lf_erfnet_backward(const lf_erfnet_plan* plan, const float* img, const float
                        const float* grad_encoder, const float* const* params_host, float* const* grads_host,
                        const float* dropmask, int training, int head, void* workspace, size_t workspace_bytes, void* stream);
 int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+/* encoder.output_conv = nn.Conv2d(128, num_classes, 1): the `predict=True` branch of Encoder.forward that
+ * Net.forward(input, flag, only_encode=True) returns (BEV/Networks/ERFNet.py:84,86-95,151-153).
+ * x (N,h,w,C) NHWC fp32 (the encoder output, read in place), w (K,C) = the weight (K,C,1,1), b (K) or NULL -> y (N,K,h,w) NCHW.
+ * Backward: gy (N,K,h,w) -> gx (N,h,w,C) NHWC (or NULL), gw (K,C) and gb (K) (or NULL); scratch >= lf_pointwise_scratch_floats(). */
+int lf_pointwise_fwd(const float* x, const float* w, const float* b, float* y, int N, int h, int w_, int C, int K, void* stream);
+long lf_pointwise_scratch_floats(int N, int h, int w_, int C, int K);
+int lf_pointwise_bwd(const float* x, const float* gy, const float* w, float* gx, float* gw, float* gb, int N, int h, int w_,
+                     int C, int K, float* scratch, void* stream);
 /* Roofline instrumentation (bench.py): HIP event pairs around every matrix-core launch of the engine.
  * out6 = {ms, algorithmic FLOPs, launches} for family 0 (tap-GEMM forward + data gradient) and
  * family 1 (weight gradient), accumulated since the last read. */
@@ -176,13 +188,23 @@ int lf_erfnet_profile_read(const lf_erfnet_plan* plan, double* out6_host, const 
 /* ------------------------------------------------------------------------------------
  * Fused Adam step over all parameter tensors in ONE launch ("next" row 8f-1).  Replaces optimizer.step() of the
  * torch.optim.Adam the reference builds (BEV/Networks/utils.py:411-420, BEV/main.py:266); same arithmetic.
- *   tensors_dev: n records {float* p; const float* g; float* m; float* v; long numel} on the device;
+ *   tensors_dev: n records {float* p; const float* g; float* m; float* v; long numel; long step[2]} on the device: the
+ *     step count is PER TENSOR like torch.optim.Adam's (a head that starts training late has its own bias correction) and
+ *     lives in the record, double-buffered;
  *   work_dev: nblocks int2 {tensor index, chunk index}, chunk = lf_adam_chunk() elements;
- *   step: 1-based count including this update; grad_scale: multiplies every gradient first (1/world size).
+ *   parity: the slot of step[] holding each tensor's count of updates so far; the launch writes count + 1 to the other slot
+ *     (alternate parity between calls); grad_scale: multiplies every gradient first (1/world size).
  * ---------------------------------------------------------------------------------- */
 int lf_adam_chunk(void);
 int lf_adam_step(const void* tensors_dev, const void* work_dev, int nblocks, float lr, float beta1, float beta2,
-                 float eps, float weight_decay, int step, float grad_scale, void* stream);
+                 float eps, float weight_decay, int parity, float grad_scale, void* stream);
+/* The other optimizers of define_optim (BEV/Networks/utils.py:414-417), same tables (record field m = momentum buffer,
+ * v = RMSprop's square average; the step slots are unused): torch.optim.SGD(momentum, dampening 0, no Nesterov) and
+ * torch.optim.RMSprop(alpha, eps, momentum, not centered), L2 weight decay folded into the gradient as torch does. */
+int lf_sgd_step(const void* tensors_dev, const void* work_dev, int nblocks, float lr, float momentum, float weight_decay,
+                float grad_scale, void* stream);
+int lf_rmsprop_step(const void* tensors_dev, const void* work_dev, int nblocks, float lr, float alpha, float eps,
+                    float momentum, float weight_decay, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * "Next" row 8f-3: the `--clas` heads and the inference-side post-processing of BP/test.py.

@@ -63,9 +63,15 @@ def _declare(lib):
         "lf_pipeline_image": (I, [P, P, I, P, P, P, P]),
         "lf_pipeline_label": (I, [P, P, I, P, P, I, P, P, P, P]),
         "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
+        "lf_pointwise_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+        "lf_pointwise_scratch_floats": (L, [I, I, I, I, I]),
+        "lf_pointwise_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P]),
         "lf_adam_chunk": (I, []),
         "lf_adam_step": (I, [P, P, I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                              I, ctypes.c_float, P]),
+        "lf_sgd_step": (I, [P, P, I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, P]),
+        "lf_rmsprop_step": (I, [P, P, I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                ctypes.c_float, P]),
         "lf_conv1d_scratch_floats": (L, [I, I, I, I]),
         "lf_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),

@@ -22,3 +22,4 @@ class Weighted_least_squares(WeightedLeastSquares):
     y_offset = 255.0
     max_order = 3
     out_dtype = torch.float64
+    cholesky_drops_reg = True    # the --use_cholesky branch is GELS.apply(Y0, W*x): no regulariser (BP/Networks/LSQ_layer.py:112-119, gels.py)

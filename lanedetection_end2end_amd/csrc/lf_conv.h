@@ -60,6 +60,7 @@ struct LfTapArgs {
 };
 
 void lf_tapgemm_set_split_any_size(int v);
+int lf_tapgemm_variant();
 void lf_tapgemm_set_variant(int v);   // kernel A/B switch for tools/kbench.py: 0 = default (LDS-tiled kernel where it applies), 2 = streaming kernel only
 int lf_tapgemm_stat_rows(const LfTapGeom& g);                          // upper bound over the kernels (buffer sizing)
 int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a);  // rows the launch with these arguments writes

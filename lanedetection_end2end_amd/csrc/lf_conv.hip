@@ -778,6 +778,7 @@ int pick_nt(int Cd) {
 }  // namespace
 
 void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
+int lf_tapgemm_variant() { return g_tapgemm_variant; }
 void lf_tapgemm_set_split_any_size(int v) { g_split_any_size = v; }
 
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel

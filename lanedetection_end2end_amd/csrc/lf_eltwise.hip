@@ -4,6 +4,7 @@
 // UpsamplerBlock :98-107, Decoder.output_conv :124), nn.BatchNorm2d(eps=1e-3), nn.Dropout2d.
 #include "lf_eltwise.h"
 #include "lf_types.h"
+#include "lf_plan.h"      // LF_TRY, lf_rows_reduce_launch (lf_conv.h)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -706,3 +707,121 @@ int lf_head_wgrad(const float* x, const float* gout, float* wrows, float* brows,
     LF_CHECK_LAUNCH("head_wgrad");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// encoder.output_conv: Conv2d(128, K, 1) on the encoder output -- the `predict=True` branch of Encoder.forward that
+// Net.forward(only_encode=True) returns (BEV/Networks/ERFNet.py:84,86-95,151-153).  NHWC (N,h,w,C) fp32 in, NCHW (N,K,h,w) out.
+// Bandwidth-bound (reads C floats, writes K <= 8 per pixel): one thread per pixel, weights broadcast from LDS.
+// ---------------------------------------------------------------------------------------
+namespace {
+constexpr int PW_MAXK = 8, PW_MAXC = 256;
+
+__global__ __launch_bounds__(256) void pointwise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ y, long npix,
+                                                           long pix_per_image, int C, int K) {
+    __shared__ float sw[PW_MAXK * PW_MAXC];
+    for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
+    __syncthreads();
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        float acc[PW_MAXK];
+        for (int k = 0; k < K; ++k) acc[k] = b ? b[k] : 0.f;
+        const float* xp = x + p * C;
+        for (int c = 0; c < C; c += 4) {
+            const lf_f32x4 v = *reinterpret_cast<const lf_f32x4*>(xp + c);
+            for (int k = 0; k < K; ++k) {
+                const float* wk = sw + k * C + c;
+                acc[k] = fmaf(v.x, wk[0], fmaf(v.y, wk[1], fmaf(v.z, wk[2], fmaf(v.w, wk[3], acc[k]))));
+            }
+        }
+        const long n = p / pix_per_image, q = p - n * pix_per_image;
+        for (int k = 0; k < K; ++k) y[(n * K + k) * pix_per_image + q] = acc[k];
+    }
+}
+
+// gx[p][c] = sum_k gy[n][k][q] * w[k][c]
+__global__ __launch_bounds__(256) void pointwise_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                float* __restrict__ gx, long npix, long pix_per_image, int C,
+                                                                int K) {
+    __shared__ float sw[PW_MAXK * PW_MAXC];
+    for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
+    __syncthreads();
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const long n = p / pix_per_image, q = p - n * pix_per_image;
+        float g[PW_MAXK];
+        for (int k = 0; k < K; ++k) g[k] = gy[(n * K + k) * pix_per_image + q];
+        float* gp = gx + p * C;
+        for (int c = 0; c < C; c += 4) {
+            lf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < K; ++k) {
+                const float* wk = sw + k * C + c;
+                v.x = fmaf(g[k], wk[0], v.x); v.y = fmaf(g[k], wk[1], v.y); v.z = fmaf(g[k], wk[2], v.z); v.w = fmaf(g[k], wk[3], v.w);
+            }
+            *reinterpret_cast<lf_f32x4*>(gp + c) = v;
+        }
+    }
+}
+
+// partial rows: wrows[block][k][c] = sum over the block's pixels of gy[k] * x[c]; brows[block][k] = sum gy[k].
+// thread = channel (C <= 256 threads active), pixels of the block in sequence: x loads coalesce over c, gy broadcasts.
+__global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                             float* __restrict__ wrows, float* __restrict__ brows, long npix,
+                                                             long pix_per_image, int C, int K, int pix_per_block) {
+    const int c = threadIdx.x;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    float acc[PW_MAXK], bs[PW_MAXK];
+    for (int k = 0; k < K; ++k) { acc[k] = 0.f; bs[k] = 0.f; }
+    for (int i = 0; i < pix_per_block; ++i) {
+        const long p = p0 + i;
+        if (p >= npix) break;
+        const long n = p / pix_per_image, q = p - n * pix_per_image;
+        const float xv = c < C ? x[p * C + c] : 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float g = gy[(n * K + k) * pix_per_image + q];
+            acc[k] = fmaf(g, xv, acc[k]);
+            bs[k] += g;
+        }
+    }
+    if (c < C)
+        for (int k = 0; k < K; ++k) wrows[((long)blockIdx.x * K + k) * C + c] = acc[k];
+    if (c == 0)
+        for (int k = 0; k < K; ++k) brows[(long)blockIdx.x * K + k] = bs[k];
+}
+}  // namespace
+
+extern "C" {
+// y (N,K,h,w) NCHW = Conv2d(C, K, 1)(x), x (N,h,w,C) NHWC fp32 (the encoder output in place), w (K,C) = the Conv2d weight
+// (K,C,1,1) flattened, b (K) or NULL.  C % 4 == 0, C <= 256, K <= 8.
+int lf_pointwise_fwd(const float* x, const float* w, const float* b, float* y, int N, int h, int w_, int C, int K, void* stream) {
+    LF_REQUIRE(x && w && y && C % 4 == 0 && C <= PW_MAXC && K >= 1 && K <= PW_MAXK, "lf_pointwise_fwd: bad arguments (C=%d K=%d)", C, K);
+    const long npix = (long)N * h * w_;
+    hipLaunchKernelGGL(pointwise_fwd_kernel, dim3(grid_for(npix, 4096)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, npix,
+                       (long)h * w_, C, K);
+    LF_CHECK_LAUNCH("pointwise_fwd");
+    return 0;
+}
+long lf_pointwise_scratch_floats(int N, int h, int w_, int C, int K) {
+    const long npix = (long)N * h * w_;
+    return (long)lf_cdiv(npix, 256) * (K * C + K);
+}
+// gx (N,h,w,C) NHWC or NULL; gw (K,C), gb (K) or NULL; scratch >= lf_pointwise_scratch_floats() floats
+int lf_pointwise_bwd(const float* x, const float* gy, const float* w, float* gx, float* gw, float* gb, int N, int h, int w_,
+                     int C, int K, float* scratch, void* stream) {
+    LF_REQUIRE(x && gy && w && C % 4 == 0 && C <= PW_MAXC && K >= 1 && K <= PW_MAXK, "lf_pointwise_bwd: bad arguments (C=%d K=%d)", C, K);
+    hipStream_t st = (hipStream_t)stream;
+    const long npix = (long)N * h * w_;
+    if (gx) {
+        hipLaunchKernelGGL(pointwise_bwd_data_kernel, dim3(grid_for(npix, 4096)), dim3(256), 0, st, gy, w, gx, npix, (long)h * w_, C, K);
+        LF_CHECK_LAUNCH("pointwise_bwd_data");
+    }
+    if (gw) {
+        LF_REQUIRE(scratch, "lf_pointwise_bwd: scratch missing");
+        const int rows = lf_cdiv(npix, 256);
+        float* brows = scratch + (long)rows * K * C;
+        hipLaunchKernelGGL(pointwise_wgrad_kernel, dim3(rows), dim3(256), 0, st, x, gy, scratch, brows, npix, (long)h * w_, C, K, 256);
+        LF_CHECK_LAUNCH("pointwise_wgrad");
+        LF_TRY(lf_rows_reduce_launch(scratch, rows, K * C, gw, 0, st));
+        if (gb) LF_TRY(lf_rows_reduce_launch(brows, rows, K, gb, 0, st));
+    }
+    return 0;
+}
+}  // extern "C"

@@ -396,7 +396,7 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
     extra.s16 = c.s16;
-    if (c.P->precision == 0) { extra.wp32 = c.packed32(op.pack); extra.zeros = c.at(c.P->off_zero); }
+    if (c.P->precision == 0 && lf_tapgemm_variant() == 0) { extra.wp32 = c.packed32(op.pack); extra.zeros = c.at(c.P->off_zero); }
     if (c.P->precision == 1 || c.P->precision == 2)
         extra.wp16 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed16) + c.P->packs[op.pack].dst16_off;
     if (c.P->precision >= 3) {      // fp32 from split operands on the bf16 matrix cores (9 or 6 partial products)
@@ -680,7 +680,7 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
     if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
         return lf_fail("erfnet: upload of the pack table failed");
     LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
-    if (P->precision == 0)
+    if (P->precision == 0 && lf_tapgemm_variant() == 0)      // only when the LDS-tiled kernel is selectable
         LF_TRY(lf_pack_weights_lds_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed32), c.at(P->off_zero), c.st));
     if (P->precision == 1 || P->precision == 2)
         LF_TRY(lf_pack_weights_bf16_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed16), c.st));

@@ -243,7 +243,7 @@ __global__ void wls_solve_kernel(const double* __restrict__ partials, int NK, do
 #pragma unroll
         for (int j = 0; j < M::N; ++j) mom[j] += partials[((long)nk * WLS_CHUNKS + c) * M::N + j];
     double Z[D][D], Zi[D][D], X[D];
-    const double r = (solver == LF_SOLVE_CHOLESKY) ? 0.0 : reg;   // gels.py ignores reg_ls
+    const double r = reg;     // both solvers (BEV/Networks/LSQ_layer.py:120-126); the GELS flavour's caller passes 0 (gels.py has none)
 #pragma unroll
     for (int i = 0; i < D; ++i) {
 #pragma unroll
@@ -674,7 +674,7 @@ constexpr int CE_MAXC = 8;
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ tgt,
                                                     const float* __restrict__ wts, int C, long HW, long total,
                                                     double* __restrict__ acc) {
-    double num = 0.0, den = 0.0;
+    double num = 0.0, den = 0.0, nbad = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long n = i / HW, p = i % HW;
         const float* zp = z + n * C * HW + p;
@@ -682,16 +682,23 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ z
         for (int c = 0; c < C; ++c) { v[c] = zp[(long)c * HW]; mx = fmaxf(mx, v[c]); }
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += expf(v[c] - mx);
-        const int t = (int)tgt[i];
+        const int64_t t64 = tgt[i];
+        const bool okt = t64 >= 0 && t64 < C;               // a label outside [0, C) is counted and ignored (weight 0)
+        const int t = okt ? (int)t64 : 0;
         float zt = 0.f;
         for (int c = 0; c < C; ++c) zt = (c == t) ? v[c] : zt;
-        const float w = wts[t];
+        const float w = okt ? wts[t] : 0.f;
         num += (double)(w * (mx + logf(se) - zt));
         den += (double)w;
+        nbad += okt ? 0.0 : 1.0;
     }
     num = lf_wave_sum(num);
     den = lf_wave_sum(den);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(acc, num); atomicAdd(acc + 1, den); }
+    nbad = lf_wave_sum(nbad);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(acc, num); atomicAdd(acc + 1, den);
+        if (nbad != 0.0) atomicAdd(acc + 2, nbad);
+    }
 }
 __global__ void ce_finish_kernel(const double* acc, float* loss) { loss[0] = (float)(acc[0] / acc[1]); }
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ tgt,
@@ -707,8 +714,10 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z
         for (int c = 0; c < C; ++c) { v[c] = zp[(long)c * HW]; mx = fmaxf(mx, v[c]); }
         float se = 0.f;
         for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); se += v[c]; }
-        const int t = (int)tgt[i];
-        const float w = wts[t] * scale, ise = 1.f / se;
+        const int64_t t64 = tgt[i];
+        const bool okt = t64 >= 0 && t64 < C;
+        const int t = okt ? (int)t64 : 0;
+        const float w = okt ? wts[t] * scale : 0.f, ise = 1.f / se;
         for (int c = 0; c < C; ++c) gp[(long)c * HW] = w * (v[c] * ise - (c == t ? 1.f : 0.f));
     }
 }
@@ -751,7 +760,7 @@ extern "C" int lf_ce2d_fwd(const float* logits, const int64_t* target, const flo
     LF_REQUIRE(C >= 1 && C <= CE_MAXC, "lf_ce2d_fwd: C=%d not in 1..%d", C, CE_MAXC);
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W, total = (long)N * HW;
-    if (hipMemsetAsync(acc, 0, 2 * sizeof(double), st) != hipSuccess) return lf_fail("lf_ce2d_fwd: memset failed");
+    if (hipMemsetAsync(acc, 0, 3 * sizeof(double), st) != hipSuccess) return lf_fail("lf_ce2d_fwd: memset failed");
     int grid = lf_cdiv(total, 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, st, logits, target, weights, C, HW, total, acc);

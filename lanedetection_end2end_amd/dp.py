@@ -28,9 +28,11 @@ class FlatGradAllReduce:
     """Average ``p.grad`` over the ranks in ONE all-reduce.
 
     Parameters whose grad is None on this rank (``encoder.output_conv`` never gets one, ERFNet.py:84,92-93;
-    the unused head when ``pretrained``) are skipped; they must be None on every rank, which holds because
-    all ranks run the same graph.  The list of participating parameters is fixed at the first call and
-    checked afterwards.
+    the unused head when ``pretrained``) are skipped.  The set of participating parameters may CHANGE between steps -- the
+    reference's pretrained schedule flips ``end_to_end`` mid-run (BEV/main.py get_flags): ``decoder.output_conv2`` stops
+    and ``decoder.output_conv`` starts receiving gradients -- but it must change identically on every rank (all ranks run
+    the same schedule).  That is verified, not assumed: each call first all-reduces (MAX) a two-word signature of the local
+    set; ranks that disagree all raise instead of hanging in a size-mismatched collective.
     """
 
     def __init__(self, params, group=None, flat_provider=None):
@@ -41,6 +43,18 @@ class FlatGradAllReduce:
         self.group = group
         self.active = None
         self.flat_provider = flat_provider
+
+    def _agree(self, active):
+        """All ranks must hold gradients for the same parameters: MAX over ranks of (h, -h) is (h, -h) only if every h is equal."""
+        h = 0
+        for i in active:
+            h = (h * 1000003 + i + 1) % 2147483629
+        h = h * 4096 + (len(active) % 4096)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        sig = torch.tensor([h, -h], dtype=torch.int64, device=dev)
+        dist.all_reduce(sig, op=dist.ReduceOp.MAX, group=self.group)
+        if int(sig[0]) != -int(sig[1]):
+            raise RuntimeError("data-parallel ranks disagree on the set of parameters with gradients (%d tensors here)" % len(active))
 
     def _in_place_flat(self, grads):
         flat = self.flat_provider() if self.flat_provider is not None else None
@@ -56,12 +70,11 @@ class FlatGradAllReduce:
     def __call__(self):
         world = dist.get_world_size(self.group)
         active = [i for i, p in enumerate(self.params) if p.grad is not None]
-        if self.active is None:
-            self.active = active
-        elif active != self.active:
-            raise RuntimeError("set of parameters with gradients changed between steps: %d vs %d tensors"
-                               % (len(active), len(self.active)))
-        if world == 1 or not active:
+        self.active = active
+        if world == 1:
+            return 0
+        self._agree(active)
+        if not active:
             return 0
         grads = [self.params[i].grad for i in active]
         flat = self._in_place_flat(grads)

@@ -118,6 +118,23 @@ def _ptr_array(tensors):
     return arr
 
 
+class _PtrCache:
+    """ctypes pointer arrays of tensor lists that rarely move (parameters, BatchNorm buffers, the gradient views of the flat
+    buffer the caching allocator hands back at the same address every step): rebuilt only when an address changed."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, tag, tensors):
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
+        hit = self._store.get(tag)
+        if hit is None or hit[0] != key:
+            arr = (ctypes.c_void_p * len(key))(*[k or None for k in key])
+            hit = (key, arr)
+            self._store[tag] = hit
+        return hit[1]
+
+
 # lf_erfnet_set_precision modes (include/lanefit.h)
 _PRECISIONS = {"fp32": 0, "bf16_mfma": 1, "bf16": 2, "fp32x9": 3, "fp32x6": 4}
 
@@ -133,11 +150,11 @@ class _BackboneFn(torch.autograd.Function):
         params = [p.detach() for p in params]
         for p in params:
             assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
-        host = _ptr_array(params)
+        host = net._ptrs.get("params", params)
         devarr = net._device_ptr_table(params)
         ctx.precision = _PRECISIONS[net.precision]
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
-        running = _ptr_array(net._running_buffers())
+        running = net._ptrs.get("running", net._running_buffers())
         _lib.check(lib.lf_erfnet_forward(plan.handle, _lib.ptr(x), host, _lib.ptr(devarr), running,
                                          _lib.ptr(dropmask), int(training), head, _lib.ptr(logits), _lib.ptr(ws),
                                          plan.ws_bytes, _lib.stream()), "lf_erfnet_forward")
@@ -186,21 +203,59 @@ class _BackboneFn(torch.autograd.Function):
         glogits = glogits.contiguous()
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _lib.ptr(genc),
-                                          _ptr_array(params), _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.training,
+                                          ctx.net._ptrs.get("params", params), ctx.net._ptrs.get("grads", grads), _lib.ptr(ctx.dropmask), ctx.training,
                                           ctx.head, _lib.ptr(ctx.ws), plan.ws_bytes, _lib.stream()), "lf_erfnet_backward")
         ctx.ws = None
         return (None, None, None, None, None, None) + tuple(grads)
+
+
+class _PointwiseFn(torch.autograd.Function):
+    """``encoder.output_conv`` (Conv2d(128, K, 1)) on the NHWC encoder output -> NCHW (lf_pointwise_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, enc_nhwc, weight, bias):
+        lib = _lib.load()
+        N, h, w, C = enc_nhwc.shape
+        K = weight.shape[0]
+        x = enc_nhwc.contiguous()
+        wt = weight.detach().reshape(K, C).contiguous()
+        y = torch.empty(N, K, h, w, dtype=torch.float32, device=x.device)
+        _lib.check(lib.lf_pointwise_fwd(_lib.ptr(x), _lib.ptr(wt), _lib.ptr(bias.detach().contiguous()), _lib.ptr(y), N, h, w, C, K,
+                                        _lib.stream()), "lf_pointwise_fwd")
+        ctx.save_for_backward(x, wt)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, wt = ctx.saved_tensors
+        N, h, w, C = x.shape
+        K = wt.shape[0]
+        gy = gy.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(wt) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(K, dtype=torch.float32, device=x.device) if (gw is not None and ctx.needs_input_grad[2]) else None
+        scratch = torch.empty(lib.lf_pointwise_scratch_floats(N, h, w, C, K), dtype=torch.float32, device=x.device)
+        _lib.check(lib.lf_pointwise_bwd(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(wt), _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), N, h, w,
+                                        C, K, _lib.ptr(scratch), _lib.stream()), "lf_pointwise_bwd")
+        return gx, (None if gw is None else gw.view(ctx.wshape)), gb
 
 
 class Net(nn.Module):
     """``Net(layers=18, in_channels=1, out_channels=1, pretrained=False, pool=False)`` and
     ``forward(input, flag, only_encode=False) -> (encoder_output, decoder_output)``
     exactly as BEV/Networks/ERFNet.py:145-157.  ``three_outputs=True`` gives the BP variant's
-    ``(encoder_output, decoder_output, output_seg=None)`` (BP/Networks/ERFNet.py:170-176).
+    ``(encoder_output, decoder_output, output_seg)`` (BP/Networks/ERFNet.py:170-176), where ``output_seg`` is the encoder
+    output itself (the decoder's second head is never built, :128-163).
 
-    Deviations: ``only_encode=True`` is not implemented; ``encoder_output`` is a channels-last view of the
-    engine's workspace (logical shape (N,128,H/8,W/8) as in the reference, differentiable: the ``--clas`` heads
-    train through it); no gradient is produced for the input image.
+    ``only_encode=True`` returns ``encoder.forward(input, predict=True)`` = ``output_conv`` (1x1, 128 -> num_classes) of the
+    encoder output, (N, num_classes, H/8, W/8) (ERFNet.py:86-95,151-153); the engine still runs its whole plan (the decoder's
+    work is discarded: the reference's training loops never take this branch), and the result is differentiable through the
+    encoder like the ``--clas`` heads' input.
+
+    Deviations: ``encoder_output`` is a channels-last view of the engine's workspace (logical shape (N,128,H/8,W/8) as in
+    the reference, differentiable: the ``--clas`` heads train through it); no gradient is produced for the input image.
     """
     three_outputs = False
 
@@ -211,6 +266,7 @@ class Net(nn.Module):
         self.in_channels, self.out_channels, self.pretrained = in_channels, out_channels, bool(pretrained)
         self._plans = {}
         self._ptr_cache = (None, None)
+        self._ptrs = _PtrCache()
         self._flat_grad = None
         # precision mode: "fp32" (default, the parity path); "bf16_mfma" (conv operands rounded to bf16 in registers,
         # fp32 accumulation, fp32 tensors); "bf16" (bf16 matrix cores AND bf16 activation / gradient tensors in HBM;
@@ -225,17 +281,24 @@ class Net(nn.Module):
 
     # ---- bookkeeping -------------------------------------------------------------------
     def _ordered_params(self):
-        return [p for _, p in self.named_parameters()]
+        ps = self.__dict__.get("_param_list")        # built once: nn.Parameter objects keep their identity through
+        if ps is None:                                # .cuda() / .to() / load_state_dict (data is swapped in place)
+            ps = [p for _, p in self.named_parameters()]
+            self.__dict__["_param_list"] = ps
+        return ps
 
     def _running_buffers(self):
         out = []
-        for m in self.modules():
-            if isinstance(m, nn.BatchNorm2d):
-                out += [m.running_mean, m.running_var]
+        for m in self._batchnorms():
+            out += [m.running_mean, m.running_var]
         return out
 
     def _batchnorms(self):
-        return [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        bns = self.__dict__.get("_bn_list")          # the module tree is fixed after construction
+        if bns is None:
+            bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+            self.__dict__["_bn_list"] = bns
+        return bns
 
     def _dropouts(self):
         return [m.dropout for m in self.modules() if isinstance(m, non_bottleneck_1d) and m.dropout.p != 0]
@@ -283,9 +346,6 @@ class Net(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------
     def forward(self, input, flag, only_encode=False):
-        if only_encode:
-            raise NotImplementedError("lanefit ERFNet: only_encode=True (encoder.output_conv) is outside the "
-                                      "accelerated hot path")
         if not input.is_cuda:
             raise _lib.LaneFitLibraryError("lanefit ERFNet needs its input on the MI355X; there is no CPU path")
         x = input.contiguous().float()
@@ -297,12 +357,26 @@ class Net(nn.Module):
             head = 1                                  # Decoder.forward: flag selects output_conv (ERFNet.py:134-141)
         dropmask = self._make_dropmask(plan, x.device) if self.training else None
         params = self._ordered_params()
-        logits, enc = _BackboneFn.apply(self, plan, x, head, self.training, dropmask, *params)
+        export = self.export_encoder_output
+        if only_encode:
+            if self.precision == "bf16":
+                raise NotImplementedError("only_encode reads an fp32 encoder output: use precision 'fp32' or 'bf16_mfma'")
+            self.export_encoder_output = True
+        try:
+            logits, enc = _BackboneFn.apply(self, plan, x, head, self.training, dropmask, *params)
+        finally:
+            self.export_encoder_output = export
+        if only_encode:
+            if self.training:
+                torch._foreach_add_([m.num_batches_tracked for m in self._batchnorms()], 1)
+            return _PointwiseFn.apply(enc, self.encoder.output_conv.weight, self.encoder.output_conv.bias)
         if self.training:
             torch._foreach_add_([m.num_batches_tracked for m in self._batchnorms()], 1)
         if enc.dim() == 4:
             enc = enc.permute(0, 3, 1, 2)             # logical NCHW, channels-last memory
         if self.three_outputs:
-            return enc, logits, None
+            # BP/Networks/ERFNet.py:143-163: the decoder returns (output, output_seg) with output_seg = its INPUT (the encoder
+            # output) unchanged, because do_segmentation is never set
+            return enc, logits, (enc if enc.dim() == 4 else None)
         return enc, logits
 

@@ -31,6 +31,7 @@ class WeightedLeastSquares(nn.Module):
     y_offset = 1.0          # BEV: y = 1 - grid_y (LSQ_layer.py:109)
     max_order = 2           # BEV implements orders 0..2 (:110-118)
     out_dtype = torch.float32
+    cholesky_drops_reg = False   # BEV regularises before either factorisation (LSQ_layer.py:120-126)
 
     def __init__(self, size, nclasses, order, no_cuda=False, reg_ls=0, use_cholesky=False):
         super().__init__()
@@ -47,7 +48,8 @@ class WeightedLeastSquares(nn.Module):
     def forward(self, W, grid):
         P = grid.size(1)
         Wm = W.reshape(-1, self.nclasses, 1, P)
-        beta, _, _ = fit_lanes(Wm, grid[: Wm.size(0)], 0, self.order, self.reg_ls_value, self.y_offset, "none",
+        reg = 0.0 if (self.use_cholesky and self.cholesky_drops_reg) else self.reg_ls_value
+        beta, _, _ = fit_lanes(Wm, grid[: Wm.size(0)], 0, self.order, reg, self.y_offset, "none",
                                self.use_cholesky, return_masked=False, check_singular=self.check_singular)
         return split_lanes(beta, self.nclasses, self.out_dtype)
 

@@ -80,11 +80,12 @@ class CrossEntropyLoss2d(nn.Module):
         super().__init__()
         w = [1.0] + [float(weight)] * nclasses if seg else [1.0] * (nclasses + 1)
         self.register_buffer("weights", torch.tensor(w, dtype=torch.float32), persistent=False)
+        self.check_targets = True       # raise on a label outside [0, C) like nn.NLLLoss (one D2H sync per call)
 
     def forward(self, inputs, targets):
         if targets.dim() == 4:
             targets = targets[:, 0, :, :]
-        return ops.CrossEntropy2dFn.apply(inputs, targets.long(), self.weights)
+        return ops.CrossEntropy2dFn.apply(inputs, targets.long(), self.weights, self.check_targets)
 
 
 class backprojection_loss(nn.Module):

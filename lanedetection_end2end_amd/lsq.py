@@ -23,21 +23,12 @@ def activation_layer(activation='square', no_cuda=False):
     return table[activation]
 
 
-def define_model(mod, **kwargs):
-    """Backbone registry (BEV/Networks/__init__.py:9-20)."""
-    if mod not in model_dict:
-        raise KeyError("The requested model: {} is not implemented".format(mod))
-    return model_dict[mod](**kwargs)
-
-
-model_dict = {'erfnet': erfnet.Net}
-
-
 class _LaneFitNet(nn.Module):
     normalised = True
     y_offset = 1.0
     beta_dtype = torch.float32
     max_order = 2
+    cholesky_drops_reg = False       # BP only: its --use_cholesky branch is GELS, which has no regulariser
 
     def _common_init(self, args, M, backbone_cls):
         self.nclasses = args.nclasses
@@ -95,8 +86,9 @@ class _LaneFitNet(nn.Module):
 
     def _fit(self, output, end_to_end, gt_line=None):
         grid = self.grid_on(output.device)
+        reg = 0.0 if (self.use_cholesky and self.cholesky_drops_reg) else self.reg_ls
         if end_to_end:
-            beta, masked, status = fit.fit_lanes(output, grid, self.zero_rows, self.order, self.reg_ls, self.y_offset,
+            beta, masked, status = fit.fit_lanes(output, grid, self.zero_rows, self.order, reg, self.y_offset,
                                                  self.activation_name, self.use_cholesky, self.return_masked,
                                                  self.check_singular)
         else:
@@ -105,8 +97,8 @@ class _LaneFitNet(nn.Module):
             if gt_line is not None and gt_line.sum() != 0:
                 # "Prevent singular matrix" (BP/Networks/LSQ_layer.py:308-311): absent lanes borrow map [0,0]
                 sel = gt_line.bool()
-                maps[sel] = maps[0, 0]
-            beta, _, status = fit.fit_lanes(maps, grid, 0, self.order, self.reg_ls, self.y_offset, "none",
+                maps[sel] = maps[0, 0].clone()
+            beta, _, status = fit.fit_lanes(maps, grid, 0, self.order, reg, self.y_offset, "none",
                                             self.use_cholesky, False, self.check_singular)
             masked = maps
         self.last_status = status
@@ -142,11 +134,13 @@ class BPNet(_LaneFitNet):
     y_offset = 255.0
     beta_dtype = torch.float64
     max_order = 3
+    cholesky_drops_reg = True
 
     def __init__(self, args):
         super().__init__()
         M, _ = geometry.get_homography(args.resize, getattr(args, "no_mapping", False))
         self._common_init(args, M, _BPBackbone)
+        self.net.export_encoder_output = True        # output_seg IS the encoder output in this tree (BP/Networks/ERFNet.py:143-163)
 
     def forward(self, input, gt_line, end_to_end, early_return=False, gt=None):
         shared_encoder, output, output_seg = self.net(input, end_to_end * self.pretrained)

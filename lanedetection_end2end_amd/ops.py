@@ -129,8 +129,12 @@ class BackprojLossFn(torch.autograd.Function):
 
 
 class CrossEntropy2dFn(torch.autograd.Function):
+    """``check_targets``: read back the kernel's count of labels outside [0, C) (one D2H sync) and raise like torch's
+    NLLLoss does; with False the count stays in ``CrossEntropy2dFn.last_acc[2]`` for the caller to inspect."""
+    last_acc = None
+
     @staticmethod
-    def forward(ctx, logits, target, weights):
+    def forward(ctx, logits, target, weights, check_targets=True):
         lib = _lib.load()
         logits = logits.contiguous()
         target = target.contiguous()
@@ -138,10 +142,13 @@ class CrossEntropy2dFn(torch.autograd.Function):
         assert logits.dtype == torch.float32 and target.dtype == torch.int64
         N, C, H, W = logits.shape
         assert target.shape == (N, H, W), (target.shape, logits.shape)
-        acc = torch.empty(2, dtype=torch.float64, device=logits.device)
+        acc = torch.empty(3, dtype=torch.float64, device=logits.device)
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         _lib.check(lib.lf_ce2d_fwd(_lib.ptr(logits), _lib.ptr(target), _lib.ptr(weights), N, C, H, W,
                                    _lib.ptr(acc), _lib.ptr(loss), _lib.stream()), "lf_ce2d_fwd")
+        CrossEntropy2dFn.last_acc = acc
+        if check_targets and float(acc[2]) != 0.0:
+            raise RuntimeError("cross entropy: %d target value(s) outside [0, %d)" % (int(acc[2]), C))
         ctx.save_for_backward(logits, target, weights, acc)
         return loss
 
@@ -154,4 +161,4 @@ class CrossEntropy2dFn(torch.autograd.Function):
         g = torch.empty_like(logits)
         _lib.check(lib.lf_ce2d_bwd(_lib.ptr(logits), _lib.ptr(target), _lib.ptr(weights), N, C, H, W,
                                    _lib.ptr(acc), _lib.ptr(up), _lib.ptr(g), _lib.stream()), "lf_ce2d_bwd")
-        return g, None, None
+        return g, None, None, None

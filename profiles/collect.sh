@@ -1,0 +1,36 @@
+#!/bin/bash
+# Regenerates the round's profile evidence from HEAD on a 1-GPU MI355X box (run through gpurun from the repo root):
+#
+#     gpurun --timeout 1500 -- 'bash profiles/collect.sh r2'
+#
+# 1. rocprofv3 --kernel-trace --stats of the exact bench command       -> profiles/<tag>_kernel_stats.txt
+# 2. two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain other than --kernel-trace) over one
+#    128-channel 3-tap conv at batch 32 (forward, data gradient, weight gradient)
+#                                                                        -> profiles/<tag>_pmc_hbm_conv128.txt
+# 3. profiles/traffic.json: HBM-side bytes per launch of the two dominant kernels (FETCH_SIZE doubled for 16 B/lane streaming
+#    reads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE) with the commit they were measured at; bench.py reports it as
+#    roofline.traffic
+# 4. a matrix-pipe pass (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) over the bench -> profiles/<tag>_pmc_bench.txt
+# Everything is written under gpurun_out/ first (scratch) and the summaries are copied to profiles/ by this script; commit them.
+set -u
+TAG=${1:-r2}
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+COMMIT=$(cat .git_head 2>/dev/null || echo unknown)
+
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 16 --warmup 4 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+DB=$(find $OUT/trace -name '*_results.db' | head -1)
+python profiles/summarize_rocpd.py "$DB" > profiles/${TAG}_kernel_stats.txt
+
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --variants 2 --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1
+done
+python profiles/summarize_traffic.py $OUT $TAG "$COMMIT"
+
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
+DB=$(find $OUT/pmc_mfma -name '*_results.db' | head -1)
+python profiles/summarize_pmc.py "$DB" 3 > profiles/${TAG}_pmc_bench.txt
+cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/traffic.json gpurun_out/ 2>/dev/null
+tail -3 profiles/${TAG}_kernel_stats.txt; cat profiles/traffic.json

@@ -174,6 +174,116 @@ def test_eval_mode_and_no_grad(golden_backbone):
     assert float(net.state_dict()["encoder.initial_block.bn.running_mean"].abs().max()) == 0.0   # untouched in eval
 
 
+class _FixedLogits(torch.nn.Module):
+    """Stands in for the backbone: returns fixed logits (the paths under test start at the logits)."""
+    precision = "fp32"
+    export_encoder_output = False
+
+    def __init__(self, logits, three):
+        super().__init__()
+        self.logits, self.three = logits, three
+
+    def forward(self, x, flag):
+        return (None, self.logits, None) if self.three else (None, self.logits)
+
+
+def test_segmentation_mode_fit_vs_reference_goldens():
+    """end_to_end=False forward of both Net classes, VALUES against the real reference (tests/golden/segmode.npz, made by
+    oracle/gen_golden_segmode.py with the backbone stubbed to fixed logits): arg-max -> per-lane maps valued k -> row mask
+    -> (BP) "prevent singular matrix" overwrite of the lanes flagged in gt_line with map [0,0] -> WLS under detach.
+    BEV/Networks/LSQ_layer.py:302-308,316,324-325; BP/Networks/LSQ_layer.py:279-293,298,308-314."""
+    import os
+    from conftest import GOLDEN
+    from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Net as BEVNet
+    from lanedetection_end2end_amd.bp.Networks.LSQ_layer import Net as BPNet
+    G = np.load(os.path.join(GOLDEN, "segmode.npz"))
+    N, R = 2, 64
+    x = torch.zeros(N, 3, R, 2 * R).cuda()
+    a = _bp_args(N, R, 2, mask=0.3, end_to_end=False)
+    model = BEVNet(a).cuda()
+    model.net = _FixedLogits(torch.from_numpy(G["bev_logits"]).cuda(), False)
+    b0, b1, b2, b3, masked, M, output, line, horizon = model(x, False)
+    assert b2 is None and b3 is None and line is None and not b0.requires_grad
+    beta = torch.stack([b0, b1], 1)[..., 0].cpu().numpy()
+    assert np.array_equal(masked.cpu().numpy(), G["bev_masked"])                     # maps are exact (integers 0 / k)
+    assert relerr(beta, G["bev_beta"]) < 1e-4        # the golden is the reference's fp32 fit (2-5e-5 from its own fp64 run, SURVEY 8c)
+    # BP, 4 lanes, two lanes flagged absent
+    a = _bp_args(N, R, 4, mask=0.2, end_to_end=False)
+    model = BPNet(a).cuda()
+    model.net = _FixedLogits(torch.from_numpy(G["bp_logits"]).cuda(), True)
+    for key, gt_line in (("bp_beta", torch.from_numpy(G["bp_gt_line"]).float()), ("bp_beta_noflag", torch.zeros(N, 4))):
+        out = model(x, gt_line, False)
+        beta = torch.stack(out[:4], 1)[..., 0].cpu().numpy()
+        ys = np.linspace(5, 50, 6)
+        Yv = np.stack([ys ** (2 - j) for j in range(3)], 1)
+        # pixel coordinates (cond(Z) ~ 1e8): compare the fitted curves x(y), not the raw coefficients
+        fa, fb = beta @ Yv.T, G[key].astype(np.float64) @ Yv.T
+        assert np.abs(fa - fb).max() < 2e-3 * max(np.abs(fb).max(), 1.0), key
+        if key == "bp_beta":
+            assert np.array_equal(out[4].cpu().numpy(), G["bp_masked"])
+            m = out[4]
+            assert torch.equal(m[0, 2], m[0, 0]) and torch.equal(m[1, 3], m[0, 0])   # the overwrite
+
+
+def test_only_encode_predict_branch():
+    """Net.forward(x, flag, only_encode=True) = encoder.forward(x, predict=True): the 1x1 encoder.output_conv on the encoder
+    output (BEV/Networks/ERFNet.py:86-95,151-153), value and gradients (output_conv weight / bias, and through the encoder)."""
+    N, H, W = 2, 64, 128
+    net, P = build()
+    net.eval()
+    x = torch.from_numpy(inputs.images(N, H, W, seed=52))
+    y = net(x.cuda(), True, only_encode=True)
+    assert y.shape == (N, 2, H // 8, W // 8)
+    gy = torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * gy.cuda()).sum().backward()
+    Pd = erfnet_oracle.cast_params(P, torch.float64)
+    for k, v in Pd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    enc, _ = erfnet_oracle.erfnet_forward(x.double(), Pd, training=False)
+    yo = torch.nn.functional.conv2d(enc, Pd["encoder.output_conv.weight"], Pd["encoder.output_conv.bias"])
+    (yo * gy.double()).sum().backward()
+    assert relerr(y.detach().cpu(), yo.detach()) < 2e-5
+    g = dict(net.named_parameters())
+    for k in ("encoder.output_conv.weight", "encoder.output_conv.bias", "encoder.layers.13.conv1x3_2.weight",
+              "encoder.layers.2.bn1.weight", "encoder.initial_block.conv.weight"):
+        assert relerr(g[k].grad.cpu(), Pd[k].grad) < 2e-4, k
+    assert g["decoder.output_conv.weight"].grad is None or float(g["decoder.output_conv.weight"].grad.abs().max()) == 0.0
+
+
+def test_eval_mode_backward_is_the_affine_batchnorm():
+    """net.eval() WITH gradients (fine-tuning on frozen statistics): BatchNorm normalises with the running statistics, so its
+    backward is the per-channel affine map's (dx = gamma * rstd * dy, no mean terms).  Logits, input-side gradients of every
+    parameter vs the fp64 oracle run in the same mode (autograd of torch's eval-mode batch_norm formula)."""
+    N, H, W = 2, 64, 128
+    net, P = build()
+    # non-trivial running statistics: one training step of the oracle's statistics, loaded into both
+    x0 = torch.from_numpy(inputs.images(N, H, W, seed=77))
+    _, _, _, stats, _ = run_oracle(x0, P, torch.float64)
+    P2 = dict(P)
+    for k, v in stats.items():
+        P2[k] = v.float()
+    net.load_state_dict(P2)
+    net.eval()
+    x = torch.from_numpy(inputs.images(N, H, W, seed=51))
+    gy = torch.from_numpy(np.random.default_rng(9).standard_normal((N, 2, H, W)).astype(np.float32))
+    enc, dec = net(x.cuda(), True)
+    (dec * gy.cuda()).sum().backward()
+    _, dec64, _, _, Pd = run_oracle(x, P2, torch.float64, gy=gy, training=False)
+    assert relerr(dec.detach().cpu(), dec64.detach()) < 2e-5
+    worst = 0.0
+    for k, p in net.named_parameters():
+        ref = Pd[k].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        e = relerr(p.grad.cpu(), ref)
+        worst = max(worst, e)
+        assert e < 2e-4, (k, e)          # no batch statistics: not chaotic, only fp32 roundoff through 70 layers
+    print("eval-mode backward: worst parameter-gradient error vs fp64 %.2e" % worst)
+    assert float((net.state_dict()["encoder.initial_block.bn.running_mean"].cpu() - P2["encoder.initial_block.bn.running_mean"]).abs().max()) == 0.0
+
+
 def test_dropout_masks_and_pretrained_head():
     """Train mode with Dropout2d keep-masks: replay the masks the module drew through the oracle."""
     N, H, W = 2, 64, 128
@@ -314,7 +424,9 @@ def test_e2e_bp_vs_golden(golden_e2e):
     crit = backprojection_loss(args)
     out = model(x, torch.zeros(N, K), True)
     betas, masked, output, output_seg = out[:4], out[4], out[5], out[8]
-    assert len(out) == 9 and output_seg is None and all(b.dtype == torch.float64 and b.shape == (N, 3, 1) for b in betas)
+    assert len(out) == 9 and all(b.dtype == torch.float64 and b.shape == (N, 3, 1) for b in betas)
+    # output_seg = the decoder's untouched input, i.e. the encoder output (BP/Networks/ERFNet.py:143-163)
+    assert output_seg.shape == (N, 128, R // 8, 2 * R // 8) and float(output_seg.abs().max()) > 0
     output.retain_grad()
     loss, xcals = 0, []
     for k in range(K):

@@ -41,6 +41,12 @@ def _worker(rank, world, port, out):
         else:
             ok &= bool(torch.allclose(p.grad, torch.full_like(p, 1.5 * (1 + i % 3))))     # mean of 1 and 2
     n2 = reducer()                                      # second step: same active set
+    # the active set may change between steps when it changes on EVERY rank (the pretrained schedule's head switch)
+    saved = net.decoder.output_conv.weight.grad
+    net.decoder.output_conv.weight.grad = None
+    n3 = reducer()
+    ok &= n3 == n - net.decoder.output_conv.weight.numel()
+    net.decoder.output_conv.weight.grad = saved
     # in-place path: gradients that are views of one flat buffer are reduced without copies
     act = [p for nme, p in net.named_parameters() if not nme.startswith("encoder.output_conv")]
     flat = torch.full((sum(p.numel() for p in act),), float(rank + 1))
@@ -52,14 +58,14 @@ def _worker(rank, world, port, out):
     assert red2._in_place_flat([p.grad for p in act]) is flat
     red2()
     ok &= bool(torch.allclose(flat, torch.full_like(flat, 1.5))) and act[3].grad.data_ptr() >= flat.data_ptr()
-    # a rank-dependent active set must be detected
+    # a rank-dependent active set is detected on EVERY rank (signature all-reduce), nobody hangs in a mismatched collective
     failed = False
     if rank == 0:
         net.encoder.output_conv.weight.grad = torch.zeros_like(net.encoder.output_conv.weight)
-        try:
-            reducer()
-        except RuntimeError:
-            failed = True
+    try:
+        reducer()
+    except RuntimeError:
+        failed = True
     out.put((rank, same_params, ok, n, n2, failed, len(names)))
     dist.barrier() if False else None
     dist.destroy_process_group()
@@ -80,7 +86,7 @@ def test_flat_grad_allreduce_gloo_world2():
         assert same_params and ok
         assert n == n2 == 2063344 - (128 * 2 + 2)        # all parameters but encoder.output_conv
         assert nnames == 228
-    assert res[0][5] is True                             # rank 0 detected the changed active set
+    assert res[0][5] is True and res[1][5] is True       # both ranks saw the disagreement
 
 
 def test_epoch_batches_config4_sharding():

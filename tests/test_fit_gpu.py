@@ -212,6 +212,18 @@ def test_cross_entropy(lf, golden_fit):
     L2.backward()
     Lo, go = fit_oracle.cross_entropy_2d(zz, tt, [1, 30, 30])
     assert abs(float(L2) - Lo) < 1e-5 * Lo and relerr(z2.grad.cpu(), go) < 1e-5
+    # a label outside [0, C) raises like nn.NLLLoss does (instead of reading the weight table out of bounds) ...
+    bad = tt.copy()
+    bad[0, 3, 5] = 255
+    with pytest.raises(RuntimeError):
+        crit(dev(zz), dev(bad))
+    # ... and with the check deferred it is counted and carries weight 0 in loss and gradient
+    crit.check_targets = False
+    z3 = dev(zz).requires_grad_(True)
+    L3 = crit(z3, dev(bad))
+    L3.backward()
+    assert int(lf.ops.CrossEntropy2dFn.last_acc[2]) == 1
+    assert float(z3.grad[0, :, 3, 5].abs().max()) == 0.0 and torch.isfinite(L3)
 
 
 def test_trapezoid_metric(lf, golden_fit):
@@ -264,3 +276,56 @@ def test_fused_adam_matches_torch():
         assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
     assert torch.equal(unused_a, unused_b)
     assert oa.state[pa[0]]["step"] == 5
+    # per-parameter step counts (the reference's pretrained schedule switches heads under one optimizer): the unused
+    # parameter starts receiving gradients at step 6 and one of the others stops -- torch.optim.Adam restarts the bias
+    # correction for the newcomer at 1, so must the fused step
+    for it in range(4):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = torch.randn_like(a)
+            a.grad, b.grad = (None, None) if i == 1 else (g.clone(), g.clone())
+        g = torch.randn_like(unused_a)
+        unused_a.grad, unused_b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa + [unused_a], pb + [unused_b]):
+        assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
+    assert oa.state[unused_a]["step"] == 4 and oa.state[pa[1]]["step"] == 5 and oa.state[pa[0]]["step"] == 9
+    # a torch.optim.Adam state_dict (tensor-valued steps) loads and continues identically
+    oc = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in pb] + [torch.nn.Parameter(unused_b.detach().clone())],
+                   lr=1e-2, weight_decay=1e-3)
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))      # (load_state_dict keeps same-device tensors by reference)
+    pc = oc.param_groups[0]["params"]
+    for a, b in zip(pc, pb + [unused_b]):
+        g = torch.randn_like(a)
+        a.grad, b.grad = g.clone(), g.clone()
+    oc.step()
+    ob.step()
+    for a, b in zip(pc, pb + [unused_b]):
+        assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("kind", ["sgd", "rmsprop"])
+def test_fused_sgd_rmsprop_match_torch(kind):
+    """optim.define_optim('sgd' | 'rmsprop') == the torch optimizers the reference's define_optim builds
+    (BEV/Networks/utils.py:414-417: momentum 0.9, weight decay), a parameter without a gradient included."""
+    from lanedetection_end2end_amd.optim import define_optim
+    torch.manual_seed(1)
+    shapes = [(64, 64, 3, 1), (128,), (13, 3, 3, 3), (5000,), (1,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ua, ub = torch.nn.Parameter(torch.ones(4, device="cuda")), torch.nn.Parameter(torch.ones(4, device="cuda"))
+    oa = define_optim(kind, pa + [ua], 1e-2, 1e-3)
+    ob = (torch.optim.SGD(pb + [ub], lr=1e-2, momentum=0.9, weight_decay=1e-3) if kind == "sgd" else
+          torch.optim.RMSprop(pb + [ub], lr=1e-2, momentum=0.9, weight_decay=1e-3))
+    for it in range(6):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) < 3e-6 * float(b.abs().max())
+    assert torch.equal(ua, ub)
+    with pytest.raises(KeyError):
+        define_optim("lbfgs", pa, 1e-2, 0.0)
