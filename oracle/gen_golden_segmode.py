@@ -4,7 +4,10 @@ singular matrix" overwrite of absent lanes with map [0,0] -> weighted least squa
 BEV/Networks/LSQ_layer.py:302-308,316,324-325; BP/Networks/LSQ_layer.py:279-293,298,308-314.
 
 The backbone is replaced by a stub returning FIXED logits (the paths under test start at the logits; the backbone has its own
-goldens), so the vectors are independent of fp32 noise in the network.  Writes tests/golden/segmode.npz.
+goldens), so the vectors are independent of fp32 noise in the network.  The fit runs in fp64 (the reference modules cast with
+the same handful of ``.to(float64)`` calls gen_golden.py uses): in fp32 the reference's own bmm / inverse chain returns
+coefficients that are rounding noise for these 0/k-valued maps in pixel coordinates (b = -1.5625 exactly, c off by 7 %:
+cond(Z) ~ 1e9), which would pin nothing.  Writes tests/golden/segmode.npz.
 
     python -m oracle.gen_golden_segmode
 """
@@ -49,7 +52,11 @@ def main():
     ref = ref_shims.load("bev")
     model = ref.LSQ_layer.Net(ref_shims.default_args("bev", batch_size=N, resize=R, end_to_end=False))
     z = torch.from_numpy(seg_logits(N, 3, R, 2 * R, seed=21))
-    model.net = _Stub(z, False)
+    model.net = _Stub(z.double(), False)
+    model.M = model.M.double()
+    model.project_layer.base_grid = model.project_layer.base_grid.double()
+    model.ls_layer.tensor_ones = model.ls_layer.tensor_ones.double()
+    model.ls_layer.reg_ls = model.ls_layer.reg_ls.double()
     b0, b1, b2, b3, masked, M, output, line, horizon = model(x, False)
     assert b2 is None and b3 is None
     out["bev_logits"] = z.numpy()
@@ -59,7 +66,10 @@ def main():
     ref = ref_shims.load("bp")
     model = ref.LSQ_layer.Net(ref_shims.default_args("bp", batch_size=N, resize=R, nclasses=4, end_to_end=False, mask_percentage=0.2))
     z = torch.from_numpy(seg_logits(N, 5, R, 2 * R, seed=22))
-    model.net = _Stub(z, True)
+    model.net = _Stub(z.double(), True)
+    model.grid = model.grid.double()
+    model.ls_layer.tensor_ones = model.ls_layer.tensor_ones.double()
+    model.ls_layer.reg_ls = model.ls_layer.reg_ls.double()
     # (an integer gt_line: with torch >= 2 `repeat(gt_line.sum().item(), 1, 1)` rejects the float count a float tensor yields)
     gt_line = torch.zeros(N, 4, dtype=torch.long)
     gt_line[0, 2] = 1

@@ -32,5 +32,9 @@ python profiles/summarize_traffic.py $OUT $TAG "$COMMIT"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
 DB=$(find $OUT/pmc_mfma -name '*_results.db' | head -1)
 python profiles/summarize_pmc.py "$DB" 3 > profiles/${TAG}_pmc_bench.txt
-cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/traffic.json gpurun_out/ 2>/dev/null
-tail -3 profiles/${TAG}_kernel_stats.txt; cat profiles/traffic.json
+# only gpurun_out/ travels back (<= 64 MiB): keep the summaries and logs, drop the databases
+mkdir -p gpurun_out/profiles_$TAG
+cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/traffic.json gpurun_out/profiles_$TAG/ 2>/dev/null
+cp $OUT/*.log $OUT/*.err $OUT/*.json gpurun_out/profiles_$TAG/ 2>/dev/null
+rm -rf $OUT
+head -12 profiles/${TAG}_kernel_stats.txt; cat profiles/traffic.json; tail -3 gpurun_out/profiles_$TAG/*.err gpurun_out/profiles_$TAG/pmc_*.log 2>/dev/null | tail -30

@@ -46,15 +46,15 @@ def main(out_dir, tag, commit):
     open(os.path.join(root, "profiles", "%s_pmc_hbm_conv128.txt" % tag), "w").write("\n".join(lines) + "\n")
 
     def bytes_of(prefix):
-        f = [v for (k, c), v in tot.items() if k.startswith(prefix) and c == "FETCH_SIZE"]
-        w = [v for (k, c), v in tot.items() if k.startswith(prefix) and c == "WRITE_SIZE"]
+        f = [v for (k, c), v in tot.items() if prefix in k and c == "FETCH_SIZE"]
+        w = [v for (k, c), v in tot.items() if prefix in k and c == "WRITE_SIZE"]
         if not f or not w:
             return None
         return {"bytes_per_launch": 2 * max(f) * 1e3 + max(w) * 1e3, "fetch_kb_reported": max(f), "write_kb_reported": max(w)}
     out = {"commit": commit, "source": "profiles/%s_pmc_hbm_conv128.txt" % tag,
            "launch": "128-channel 3-tap conv, 32x64, batch 32 (tools/kbench.py --one 128 32 64 1 16)",
            "algorithmic_bytes_per_launch": 2 * 32 * 32 * 64 * 128 * 4,
-           "tapgemm": bytes_of("tapgemm_kernel"), "tapwgrad": bytes_of("tapwgrad")}
+           "tapgemm": bytes_of("tapgemm_kernel<"), "tapwgrad": bytes_of("tapwgrad_kernel<")}
     json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 
 

@@ -206,7 +206,7 @@ def test_segmentation_mode_fit_vs_reference_goldens():
     assert b2 is None and b3 is None and line is None and not b0.requires_grad
     beta = torch.stack([b0, b1], 1)[..., 0].cpu().numpy()
     assert np.array_equal(masked.cpu().numpy(), G["bev_masked"])                     # maps are exact (integers 0 / k)
-    assert relerr(beta, G["bev_beta"]) < 1e-4        # the golden is the reference's fp32 fit (2-5e-5 from its own fp64 run)
+    assert relerr(beta, G["bev_beta"]) < 1e-5        # golden = the reference's fit in fp64 (fp64 grid; ours is the fp32 grid)
     # BP, 4 lanes, two lanes flagged absent
     a = _bp_args(N, R, 4, mask=0.2, end_to_end=False)
     model = BPNet(a).cuda()
@@ -214,11 +214,11 @@ def test_segmentation_mode_fit_vs_reference_goldens():
     for key, gt_line in (("bp_beta", torch.from_numpy(G["bp_gt_line"]).float()), ("bp_beta_noflag", torch.zeros(N, 4))):
         out = model(x, gt_line, False)
         beta = torch.stack(out[:4], 1)[..., 0].cpu().numpy()
-        ys = np.linspace(5, 50, 6)
+        ys = np.linspace(195, 245, 6)                   # y = 255 - grid_y over the unmasked rows at resize 64
         Yv = np.stack([ys ** (2 - j) for j in range(3)], 1)
-        # pixel coordinates (cond(Z) ~ 1e8): compare the fitted curves x(y), not the raw coefficients
+        # pixel coordinates (cond(Z) ~ 1e9): compare the fitted curves x(y) inside the data range, in pixels
         fa, fb = beta @ Yv.T, G[key].astype(np.float64) @ Yv.T
-        assert np.abs(fa - fb).max() < 2e-3 * max(np.abs(fb).max(), 1.0), key
+        assert np.abs(fa - fb).max() < 1e-3, (key, np.abs(fa - fb).max())
         if key == "bp_beta":
             assert np.array_equal(out[4].cpu().numpy(), G["bp_masked"])
             m = out[4]
