@@ -355,6 +355,9 @@ __global__ __launch_bounds__(512, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
     if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memrealtime();
     if (grp == 1) __syncthreads();          // B runs one phase behind A (A is in its first service phase)
 
+    // tools/kbench.py --phases: waves of the first 4 workgroups also log the time of every barrier (64 stamps per wave,
+    // behind the 2048 x 8 summary words)
+    unsigned long long* const trace = (a.dbg && b < 4 && lane == 0) ? a.dbg + 2048 * 8 + (b * 8 + wave) * 64 : nullptr;
     bool pending_epi = false;
     for (int j = 0; j < nitems; ++j) {
         // ---- service phase of item j (the partner group computes)
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (trace && j < 31) trace[2 * j] = __builtin_amdgcn_s_memrealtime();
         // ---- compute phase of item j
         compute(cc);
         if (cc.ch == nch - 1 && cc.t == ntaps - 1) pending_epi = true;
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_lds_kernel(const LfTapGeom g, 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                       // ... and are published
         __builtin_amdgcn_sched_barrier(0);
+        if (trace && j < 31) trace[2 * j + 1] = __builtin_amdgcn_s_memrealtime();
     }
     if (a.dbg) {
         asm volatile("" ::"v"(acc[0][0][0]));

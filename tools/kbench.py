@@ -129,13 +129,15 @@ def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16),
         y = torch.empty_like(x)
         scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C), device="cuda")
         nw = ((N * H * W + 255) // 256) * 4 * (C // 64)
-        dbg = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
+        dbg = torch.zeros(max(nw, 2048) * 8 + 4 * 8 * 64, dtype=torch.int64, device="cuda")
         f = lambda: _lib.check(lib.lf_debug_conv1d_fwd_phases(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, P(scratch), P(dbg), st), "phases")
         us = timeit(f, 300) * 1e6          # long enough for the clocks to settle (a cold 1 ms burst runs ~8 % slower)
         dbg.zero_()
         f()
         torch.cuda.synchronize()
-        t = dbg.view(nw, 8).cpu().numpy().astype(np.float64)
+        full = dbg.cpu().numpy().astype(np.float64)
+        t = full[: nw * 8].reshape(nw, 8)
+        tr = full[2048 * 8: 2048 * 8 + 2048].reshape(32, 64) * 0.01 if variant == 0 else np.zeros((32, 64))
         t = t[t[:, 0] > 0] * 0.01                      # waves that ran; ticks -> microseconds
         t0 = t[:, 0].min()
         print("var %d ablate %d C=%3d N=%3d waves %5d | launch+pack %6.1f us | start spread %5.2f | operands ready %5.2f (max %5.2f) | "
@@ -143,13 +145,19 @@ def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16),
               % (variant, ablate, C, N, len(t), us, (t[:, 0] - t0).max(), (t[:, 1] - t0).mean(), (t[:, 1] - t0).max(),
                  (t[:, 2] - t0).mean(), (t[:, 2] - t0).min(), (t[:, 2] - t0).max(), (t[:, 3] - t0).mean(), (t[:, 3] - t0).max()),
               flush=True)
+        if variant == 0 and tr.max() > 0:           # per-phase trace of workgroup 0: wave 0 (group A) and wave 4 (group B)
+            for wv in (0, 4):
+                r = tr[wv]
+                r = r[r > 0]
+                d = np.diff(r)
+                print("     wg 0 wave %d: barrier-to-barrier us: %s" % (wv, " ".join("%.2f" % v for v in d)), flush=True)
     lib.lf_debug_set_lds_ablate(0)
-    lib.lf_debug_set_tapgemm_variant(0)
+    lib.lf_debug_set_tapgemm_variant(2)
 
 
 if __name__ == "__main__" and "--phases" in sys.argv:
     sp = int(sys.argv[sys.argv.index("--split") + 1]) if "--split" in sys.argv else 0
     for nb in (32,):
         phases(nb, sp, variant=2)
-        for ab in (0, 1, 4, 2, 6):
+        for ab in (0, 4):
             phases(nb, sp, variant=0, ablate=ab)
