@@ -35,6 +35,17 @@ constexpr int WG_WAVES = 4;
 constexpr int PIX_PER_WG = WG_WAVES * MT * 16;
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Buffer-addressed 16-byte load: SGPR resource + 32-bit VGPR byte offset + scalar byte offset.  Beside a dense MFMA stream a
+// global_load whose 64-bit VGPR address was just computed costs the SIMD ~200 ns of matrix issue, this form ~6 ns
+// (tools/vmem_cost.hip, profiles/r2_vmem_cost.txt); an offset >= num_records reads as 0.0f (the conv's zero padding).
+typedef unsigned u32x4v __attribute__((vector_size(16)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ldb4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+constexpr unsigned LF_OOB = 0xffff0000u;      // byte offset beyond every tensor the launcher admits (< 4 GiB - 64 KiB)
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f32x4 max0(f32x4 v) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -192,6 +203,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
         __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
         __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
+        // PROC == 0: a padding position holds the out-of-range offset LF_OOB, the buffer load returns the zero itself;
+        // with the BN+ReLU prologue (transform(0) != 0) the offsets are clamped and the mask is applied after the transform.
         for (int t = 0; t < g.ntaps; ++t) {
             const int dh = g.tdh[t], dw = g.tdw[t];
             unsigned o[MT], okb = 0;
@@ -200,31 +213,38 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
                 const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
                 const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
                 const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-                o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4);
+                o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4) * 4u;
+                if (PROC == 0 && !in) o[m] = LF_OOB;
                 okb |= (in ? 1u : 0u) << m;
             }
             tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
             tab_ok[wave][t][lane] = okb;
         }
         // (each lane reads back only what it wrote: no barrier needed)
-        const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;
-        const int wstep = g.Cd * 16;                       // floats per 16-channel step
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 4, (long)LF_OOB));
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp, 0xffffffffu);
+        const unsigned wlane = (unsigned)(kq * g.Cd + cob + pl) * 16u;      // bytes
+        const int wstep = g.Cd * 64;                       // bytes per 16-channel step
         const int ntaps = g.ntaps;
         const int wlast = (nsteps - 1) * wstep;
         int t_ld = 0, cg_ld = 0, wofs = 0;
         auto issue = [&](Step& S) {
             const bool live = t_ld < ntaps;
             const int tc = live ? t_ld : ntaps - 1;
-            const uint4 o = tab_off[wave][tc][lane];
+            uint4 o = tab_off[wave][tc][lane];
             const unsigned okb = tab_ok[wave][tc][lane];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) S.w[n] = ldg4(wp + wofs + n * 64);
-            const int c16 = cg_ld * 16;
-            S.x[0] = ldg4(a.src + o.x + c16);
-            S.x[1] = ldg4(a.src + o.y + c16);
-            S.x[2] = ldg4(a.src + o.z + c16);
-            S.x[3] = ldg4(a.src + o.w + c16);
-            if constexpr (PROC == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + c16 + kq * 4); S.sh = ldg4(a.pro_sh + c16 + kq * 4); }
+            for (int n = 0; n < NT; ++n) S.w[n] = ldb4(rw, wlane + n * 256, (unsigned)wofs);
+            const unsigned c16 = (unsigned)cg_ld * 64u;    // bytes
+            if constexpr (PROC == 0) {                     // a dead step (odd step count) reads zeros
+                const unsigned dead = live ? 0u : LF_OOB;
+                o.x |= dead; o.y |= dead; o.z |= dead; o.w |= dead;
+            }
+            S.x[0] = ldb4(rx, o.x, c16);
+            S.x[1] = ldb4(rx, o.y, c16);
+            S.x[2] = ldb4(rx, o.z, c16);
+            S.x[3] = ldb4(rx, o.w, c16);
+            if constexpr (PROC == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + cg_ld * 16 + kq * 4); S.sh = ldg4(a.pro_sh + cg_ld * 16 + kq * 4); }
             S.ok = live ? okb : 0u;
             // advance (scalar selects, no branches); a dead step re-reads the last live operands
             const int cgn = cg_ld + 1;
@@ -234,13 +254,14 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
             t_ld = (live && wrap) ? t_ld + 1 : t_ld;
         };
         auto finish = [&](Step& S) {
+            if constexpr (PROC == LF_PRO_BNRELU) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x4 v = S.x[m];
-                if constexpr (PROC == LF_PRO_BNRELU) v = max0(v * S.sc + S.sh);
-                const bool in = (S.ok >> m) & 1u;
-                v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
-                S.x[m] = v;
+                for (int m = 0; m < MT; ++m) {
+                    f32x4 v = max0(S.x[m] * S.sc + S.sh);
+                    const bool in = (S.ok >> m) & 1u;
+                    v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+                    S.x[m] = v;
+                }
             }
         };
         auto mma = [&](const Step& S, int s) {
@@ -817,7 +838,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     LF_REQUIRE(npix < (1L << 30), "tapgemm: too many pixels (%ld)", npix);
     const int nt = pick_nt(g.Cd);
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
-    LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31), "tapgemm: source tensor too large for 32-bit offsets");
+    LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix * 4 < (long)LF_OOB, "tapgemm: source tensor too large for 32-bit byte offsets");
     if (use_lds_kernel(g, a)) return lf_tapgemm_lds_launch(g, a, pro, epi, st);
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
