@@ -56,15 +56,26 @@ __device__ __forceinline__ f32x4 keep_pos(f32x4 v, f32x4 m) {
     return v;
 }
 // storage-typed access of the epilogue operands / result (S16: the tensors hold bf16 elements, see lf_types.h)
+// (buffer-addressed like the operand loads: the epilogue of one wave runs beside its partner's MFMA stream, where 64-bit
+// address arithmetic and VGPR-pair addressed memory instructions are what made it take 9 us instead of 4)
+typedef unsigned u32x2v __attribute__((vector_size(8)));
 template <bool S16>
-__device__ __forceinline__ f32x4 epi_ld(const float* base, long off) {
-    if constexpr (S16) return lf_ldv(reinterpret_cast<const lf_bf16*>(base) + off);
-    else return ldg4(base + off);
+__device__ __forceinline__ f32x4 epi_ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    if constexpr (S16) {
+        const u32x2v q = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(off * 2u), 0, 0);
+        f32x4 v;
+        v.x = __uint_as_float(q[0] << 16); v.y = __uint_as_float(q[0] & 0xffff0000u);
+        v.z = __uint_as_float(q[1] << 16); v.w = __uint_as_float(q[1] & 0xffff0000u);
+        return v;
+    } else return ldb4(r, off * 4u, 0u);
 }
 template <bool S16>
-__device__ __forceinline__ void epi_st(float* base, long off, f32x4 v) {
-    if constexpr (S16) lf_stv(reinterpret_cast<lf_bf16*>(base) + off, v);
-    else *reinterpret_cast<f32x4*>(base + off) = v;
+__device__ __forceinline__ void epi_st(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    if constexpr (S16) {
+        lf_bf16x4 b;
+        b[0] = (lf_bf16)v.x; b[1] = (lf_bf16)v.y; b[2] = (lf_bf16)v.z; b[3] = (lf_bf16)v.w;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, b), r, (int)(off * 2u), 0, 0);
+    } else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, (int)(off * 4u), 0, 0);
 }
 __device__ __forceinline__ f32x4 round_bf16(f32x4 v) {
     v.x = (float)(lf_bf16)v.x; v.y = (float)(lf_bf16)v.y; v.z = (float)(lf_bf16)v.z; v.w = (float)(lf_bf16)v.w;
@@ -91,27 +102,33 @@ __device__ __forceinline__ float sum16(float v) {
      * contiguous NT*16-channel run, so every cache line is touched once while it is hot (the channel-tile-outer order \
      * revisited each line NT times with the whole grid's working set in between: 4x the HBM reads with bf16 tensors). */ \
     const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0; \
+    __builtin_amdgcn_s_setprio(3);   /* ahead of the partner wave's MFMA stream: the sooner this wave retires, the sooner its slot refills */ \
+    const __amdgpu_buffer_rsrc_t r_dst = make_rsrc(a.dst, 0xffffffffu), r_add = make_rsrc(a.add_src, 0xffffffffu), \
+                                 r_msk = make_rsrc(a.mask_src, 0xffffffffu), r_aux = make_rsrc(a.aux, 0xffffffffu), \
+                                 r_bias = make_rsrc(a.bias, 0xffffffffu), r_msc = make_rsrc(a.msc, 0xffffffffu), \
+                                 r_msh = make_rsrc(a.msh, 0xffffffffu), r_asc = make_rsrc(a.asc, 0xffffffffu), \
+                                 r_ash = make_rsrc(a.ash, 0xffffffffu), r_dm = make_rsrc(a.dm, 0xffffffffu); \
     f32x4 s1[NT], s2[NT], bs[NT], hv[HOISTV ? NT : 1][4]; \
 _Pragma("unroll") \
     for (int n = 0; n < NT; ++n) { \
         const int co = cob + n * 16 + kq * 4; \
         s1[n] = zero4(); s2[n] = zero4(); \
-        bs[n] = a.bias ? ldg4(a.bias + co) : zero4(); \
+        bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4(); \
         if (HOISTV) { \
-            if (epi & LF_EPI_MASKBN) { hv[n][0] = ldg4(a.msc + co); hv[n][1] = ldg4(a.msh + co); } \
-            if (epi & LF_EPI_STATS_XHAT) { hv[n][2] = ldg4(a.asc + co); hv[n][3] = ldg4(a.ash + co); } \
+            if (epi & LF_EPI_MASKBN) { hv[n][0] = ldb4(r_msc, co * 4u, 0u); hv[n][1] = ldb4(r_msh, co * 4u, 0u); } \
+            if (epi & LF_EPI_STATS_XHAT) { hv[n][2] = ldb4(r_asc, co * 4u, 0u); hv[n][3] = ldb4(r_ash, co * 4u, 0u); } \
         } \
     } \
 _Pragma("unroll") \
     for (int m = 0; m < MT; ++m) { \
-        const long dbase = ((long)(pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + g.d_choff + cob + kq * 4; \
+        const unsigned dbase = (unsigned)(((pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + g.d_choff + cob + kq * 4); \
         f32x4 la[NT], lm[NT], lx[NT], ld[NT]; \
 _Pragma("unroll") \
         for (int n = 0; n < NT; ++n) { \
-            if (epi & LF_EPI_ADD) la[n] = epi_ld<S16>(a.add_src, dbase + n * 16); \
-            if (epi & LF_EPI_MASK) lm[n] = epi_ld<S16>(a.mask_src, dbase + n * 16); \
-            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[n] = epi_ld<S16>(a.aux, dbase + n * 16); \
-            if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[n] = ldg4(a.dm + (long)pn[m] * g.Cd + cob + n * 16 + kq * 4); \
+            if (epi & LF_EPI_ADD) la[n] = epi_ld<S16>(r_add, dbase + n * 16); \
+            if (epi & LF_EPI_MASK) lm[n] = epi_ld<S16>(r_msk, dbase + n * 16); \
+            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[n] = epi_ld<S16>(r_aux, dbase + n * 16); \
+            if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[n] = ldb4(r_dm, (unsigned)(pn[m] * g.Cd + cob + n * 16 + kq * 4) * 4u, 0u); \
         } \
 _Pragma("unroll") \
         for (int n = 0; n < NT; ++n) { \
@@ -119,15 +136,15 @@ _Pragma("unroll") \
             if (epi & LF_EPI_ADD) v += la[n]; \
             if (epi & LF_EPI_MASK) v = keep_pos(v, lm[n]); \
             const int co = cob + n * 16 + kq * 4;   /* per-channel vectors: L1-resident, re-read instead of held in registers */ \
-            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[n] * (HOISTV ? hv[HOISTV ? n : 0][0] : ldg4(a.msc + co)) + (HOISTV ? hv[HOISTV ? n : 0][1] : ldg4(a.msh + co))); \
+            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[n] * (HOISTV ? hv[HOISTV ? n : 0][0] : ldb4(r_msc, co * 4u, 0u)) + (HOISTV ? hv[HOISTV ? n : 0][1] : ldb4(r_msh, co * 4u, 0u))); \
             if (epi & LF_EPI_RELU) v = max0(v); \
             if (S16) v = round_bf16(v);   /* statistics are taken from the values as stored */ \
-            if (pv[m]) epi_st<S16>(a.dst, dbase + n * 16, v); \
+            if (pv[m]) epi_st<S16>(r_dst, dbase + n * 16, v); \
             if (!pv[m]) v = zero4(); \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
                 const f32x4 gm = a.dm ? v * ld[n] : v; \
-                s1[n] += gm; s2[n] += gm * (lx[n] * (HOISTV ? hv[HOISTV ? n : 0][2] : ldg4(a.asc + co)) + (HOISTV ? hv[HOISTV ? n : 0][3] : ldg4(a.ash + co))); \
+                s1[n] += gm; s2[n] += gm * (lx[n] * (HOISTV ? hv[HOISTV ? n : 0][2] : ldb4(r_asc, co * 4u, 0u)) + (HOISTV ? hv[HOISTV ? n : 0][3] : ldb4(r_ash, co * 4u, 0u))); \
             } \
         } \
     } \
@@ -155,9 +172,13 @@ _Pragma("unroll") \
         } \
     } \
 
-template <int NT, int PROC>
-__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
-    constexpr bool S16 = false, HOISTV = false;      // the fp32 loop leaves no registers to hold the per-channel vectors
+// EPIC >= 0: the epilogue flags are compiled in (the combinations the network uses at 64 output channels per workgroup); the
+// epilogue of one wave runs beside its partner's MFMA stream at ~14 cycles per VALU instruction, so the ~1500 instructions of
+// the runtime-flag form (EPIC = -1) cost 9 us of a 30 us workgroup life -- and the slot it occupies cannot be refilled.
+template <int NT, int PROC, int EPIC = -1>
+__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
+    const int epi = EPIC >= 0 ? EPIC : epi_rt;
+    constexpr bool S16 = false, HOISTV = EPIC >= 0;  // compiled-in flags: the per-channel vectors are loaded once, after the loop
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
@@ -299,6 +320,10 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         if (lane == 0) {
             unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WG_WAVES + wave) * 8;
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
+            unsigned hwid, xcc;                   // which SIMD the wave ran on (tools/kbench.py --phases pairs the waves up)
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
         }
     }
 }
@@ -839,12 +864,14 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     const int nt = pick_nt(g.Cd);
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix * 4 < (long)LF_OOB, "tapgemm: source tensor too large for 32-bit byte offsets");
+    LF_REQUIRE((long)g.N * g.Hd * g.Wd * g.d_pix * 4 < (long)LF_OOB, "tapgemm: destination tensor too large for 32-bit byte offsets");
     if (use_lds_kernel(g, a)) return lf_tapgemm_lds_launch(g, a, pro, epi, st);
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
         if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), 0, st, g, a, pro, epi);  \
         else hipLaunchKernelGGL((tapgemm_kernel<NTV, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                       \
     } while (0)
+#define LF_TG4(PROV, EPIV) hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi)
     LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
     if (a.split && a.wp48 && !a.wp16 && lf_tapgemm_split_ok(g)) {
         LF_REQUIRE(a.split == 9 || a.split == 6, "tapgemm: split must be 9 or 6 (got %d)", a.split);
@@ -882,7 +909,21 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         return 0;
     }
     switch (nt) {
-        case 4: LF_TG(4); break;
+        case 4:
+            if (pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) LF_TG4(1, LF_EPI_RELU);
+            else if (pro == LF_PRO_BNRELU) LF_TG4(1, -1);
+            else switch (epi) {
+                case 0: LF_TG4(0, 0); break;
+                case LF_EPI_RELU: LF_TG4(0, LF_EPI_RELU); break;
+                case LF_EPI_MASK: LF_TG4(0, LF_EPI_MASK); break;
+                case LF_EPI_ADD: LF_TG4(0, LF_EPI_ADD); break;
+                case LF_EPI_STATS_SQ: LF_TG4(0, LF_EPI_STATS_SQ); break;
+                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TG4(0, LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TG4(0, LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TG4(0, LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                default: LF_TG4(0, -1); break;
+            }
+            break;
         case 3: LF_TG(3); break;
         case 2: LF_TG(2); break;
         default:
@@ -891,6 +932,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
             break;
     }
 #undef LF_TG
+#undef LF_TG4
     LF_CHECK_LAUNCH("tapgemm");
     return 0;
 }

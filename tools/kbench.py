@@ -145,6 +145,22 @@ def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16),
               % (variant, ablate, C, N, len(t), us, (t[:, 0] - t0).max(), (t[:, 1] - t0).mean(), (t[:, 1] - t0).max(),
                  (t[:, 2] - t0).mean(), (t[:, 2] - t0).min(), (t[:, 2] - t0).max(), (t[:, 3] - t0).mean(), (t[:, 3] - t0).max()),
               flush=True)
+        if variant == 2:                            # pair the waves up by the SIMD they ran on
+            hw = full[: nw * 8].reshape(nw, 8)[:, 4].astype(np.int64)
+            hw = hw[full[: nw * 8].reshape(nw, 8)[:, 0] > 0]
+            key = ((hw >> 32) & 15) * 65536 + ((hw >> 4) & 3) + ((hw >> 8) & 15) * 4 + ((hw >> 12) & 0xf) * 64
+            simds = {}
+            for i, k in enumerate(key):
+                simds.setdefault(int(k), []).append(t[i] - t0)
+            cnt = np.bincount([len(v) for v in simds.values()])
+            print("     SIMDs used %d; waves per SIMD histogram %s" % (len(simds), dict((i, int(c)) for i, c in enumerate(cnt) if c)))
+            ends = np.array([max(w[3] for w in v) for v in simds.values()])
+            loops = np.array([max(w[2] for w in v) for v in simds.values()])
+            first = np.array([min(w[2] for w in v) for v in simds.values()])
+            print("     per SIMD: first wave's loop done %.2f (%.2f..%.2f) | last wave's loop done %.2f (%.2f..%.2f) | last store %.2f (%.2f..%.2f)"
+                  % (first.mean(), first.min(), first.max(), loops.mean(), loops.min(), loops.max(), ends.mean(), ends.min(), ends.max()))
+            for k in sorted(simds)[:3] + sorted(simds)[len(simds) // 2: len(simds) // 2 + 3]:
+                print("     simd %06x: %s" % (k, "  ".join("[start %.2f ready %.2f loop %.2f end %.2f]" % tuple(w[:4]) for w in sorted(simds[k], key=lambda w: w[0]))))
         if variant == 0 and tr.max() > 0:           # per-phase trace of workgroup 0: wave 0 (group A) and wave 4 (group B)
             for wv in (0, 4):
                 r = tr[wv]
@@ -159,5 +175,9 @@ if __name__ == "__main__" and "--phases" in sys.argv:
     sp = int(sys.argv[sys.argv.index("--split") + 1]) if "--split" in sys.argv else 0
     for nb in (32,):
         phases(nb, sp, variant=2)
-        for ab in (0, 4):
-            phases(nb, sp, variant=0, ablate=ab)
+        if "--store-ablate" in sys.argv:
+            phases(nb, sp, variant=2, ablate=1)
+            phases(nb, sp, variant=2, ablate=2)
+        if "--lds" in sys.argv:
+            for ab in (0, 4):
+                phases(nb, sp, variant=0, ablate=ab)
