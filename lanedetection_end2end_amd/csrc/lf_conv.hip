@@ -946,15 +946,16 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
 namespace {
 
 // storage-typed loads of the weight-gradient kernels (S16: x and g hold bf16 elements, widened exactly to fp32)
+// (buffer-addressed, element offsets: see ldb4)
 template <bool S16>
-__device__ __forceinline__ f32x4 wg_ld4(const float* base, unsigned off) {
-    if constexpr (S16) return lf_ldv(reinterpret_cast<const lf_bf16*>(base) + off);
-    else return ldg4(base + off);
+__device__ __forceinline__ f32x4 wg_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) { return epi_ld<S16>(r, off); }
+template <bool S16>
+__device__ __forceinline__ float wg_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    if constexpr (S16) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, (int)(off * 2u), 0, 0) << 16);
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(off * 4u), 0, 0));
 }
-template <bool S16>
-__device__ __forceinline__ float wg_ld1(const float* base, unsigned off) {
-    if constexpr (S16) return (float)reinterpret_cast<const lf_bf16*>(base)[off];
-    else return base[off];
+__device__ __forceinline__ uint2 wg_ldraw(__amdgpu_buffer_rsrc_t r, unsigned off) {      // 4 bf16 elements, raw
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(off * 2u), 0, 0));
 }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1010,6 +1011,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     const int dh = g.tdh[t], dw = g.tdw[t];
     const int xch = g.s_choff + cib * XB + (XV ? 4 * pl : pl);
     const int gch = g.d_choff + cob * GB + (GV ? 4 * pl : pl);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, 0xffffffffu), rg = make_rsrc(a.g, 0xffffffffu);
     f32x4 psc, psh;
     float psc1[XTiles], psh1[XTiles];
     if (pro == LF_PRO_BNRELU) {
@@ -1047,21 +1049,21 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
             const bool v = rowv && (p + 4 * u) < p_end;
             vm |= (v ? 1u : 0u) << u;
             const unsigned go = v ? gofs + u * gstep : gofs;
-            if constexpr (BFM) S.gr[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const lf_bf16*>(a.g) + go);
-            else if constexpr (GV) S.g4[u] = wg_ld4<S16>(a.g, go);
+            if constexpr (BFM) S.gr[u] = wg_ldraw(rg, go);
+            else if constexpr (GV) S.g4[u] = wg_ld4<S16>(rg, go);
             else {
 #pragma unroll
-                for (int q = 0; q < GTiles; ++q) S.gs[u][q] = wg_ld1<S16>(a.g, go + q * 16);
+                for (int q = 0; q < GTiles; ++q) S.gs[u][q] = wg_ld1<S16>(rg, go + q * 16);
             }
             const int sx = (jj + 4 * u) * g.ssw + dw;
             const bool xin = v && yin && sx >= 0 && sx < g.Ws;
             xm |= (xin ? 1u : 0u) << u;
             const unsigned xo = xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix);
-            if constexpr (BFM) S.xr[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const lf_bf16*>(a.x) + xo);
-            else if constexpr (XV) S.x4[u] = wg_ld4<S16>(a.x, xo);
+            if constexpr (BFM) S.xr[u] = wg_ldraw(rx, xo);
+            else if constexpr (XV) S.x4[u] = wg_ld4<S16>(rx, xo);
             else {
 #pragma unroll
-                for (int r = 0; r < XTiles; ++r) S.xs[u][r] = wg_ld1<S16>(a.x, xo + r * 16);
+                for (int r = 0; r < XTiles; ++r) S.xs[u][r] = wg_ld1<S16>(rx, xo + r * 16);
             }
         }
         S.vmask = vm; S.xmask = xm;
@@ -1169,6 +1171,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     }
 
     // ---- reduce the 4 waves of the workgroup through LDS, wave 0 writes one partial row
+    __builtin_amdgcn_s_setprio(3);
     __shared__ float red[WG_WAVES - 1][XTiles * GTiles * 4][64];
     __shared__ float bred[WG_WAVES][GTiles][64];
     if (wave > 0) {
@@ -1183,21 +1186,30 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     for (int q = 0; q < GTiles; ++q) bred[wave][q][lane] = bsum[q];
     __syncthreads();
     if (wave == 0) {
-        float* out = a.partial + ((long)bxs * g.ntaps + t) * g.Cs * g.Cd;
+        // this workgroup's slab of the partial tensor: < 2^32 bytes (Cs * Cd <= 128 x 128), buffer-addressed
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.partial + ((long)bxs * g.ntaps + t) * g.Cs * g.Cd, 0xffffffffu);
 #pragma unroll
         for (int r = 0; r < XTiles; ++r)
 #pragma unroll
-            for (int q = 0; q < GTiles; ++q)
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * kq + e;                                  // row of tile (r,q)
+                const int ci = cib * XB + (XV ? 4 * i + r : r * 16 + i);
+                float v[GTiles];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[r][q][e];
+                for (int q = 0; q < GTiles; ++q) {
+                    v[q] = acc[r][q][e];
 #pragma unroll
-                    for (int w = 0; w < WG_WAVES - 1; ++w) v += red[w][(r * GTiles + q) * 4 + e][lane];
-                    const int i = 4 * kq + e;                                  // row of tile (r,q)
-                    const int ci = cib * XB + (XV ? 4 * i + r : r * 16 + i);
-                    const int co = cob * GB + (GV ? 4 * pl + q : q * 16 + pl);
-                    out[(long)ci * g.Cd + co] = v;
+                    for (int w = 0; w < WG_WAVES - 1; ++w) v[q] += red[w][(r * GTiles + q) * 4 + e][lane];
                 }
+                if constexpr (GV) {          // columns 4*pl .. 4*pl+3 of row ci: one 16-byte store
+                    f32x4 v4 = {v[0], v[1], v[2], v[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v4), ro, (ci * g.Cd + cob * GB + 4 * pl) * 4, 0, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < GTiles; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), ro, (ci * g.Cd + cob * GB + q * 16 + pl) * 4, 0, 0);
+                }
+            }
         if (write_bias && a.bias_partial && t == 0 && cib == 0) {
             // column sums of G over this workgroup's pixels: lanes with equal pl (4 k-slots) x 4 waves
 #pragma unroll
@@ -1437,13 +1449,14 @@ __global__ __launch_bounds__(256) void tapwgrad16_kernel(const LfTapGeom g, cons
         pi = (int)(r - (unsigned)pn * (unsigned)g.Hl);
     }
     const unsigned gstep = (unsigned)(4 * g.dsw * g.d_pix);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, 0xffffffffu), rg = make_rsrc(a.g, 0xffffffffu);
     while (p - kq < p_end) {                        // wave-uniform; 16 pixels of one row per iteration
         const unsigned gofs = (unsigned)(((pn * g.Hd + pi * g.dsh + g.dah) * g.Wd + pj * g.dsw + g.daw) * g.d_pix + g.d_choff + pl);
         float gv[U], xv[NTAPS][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool v = (p + 4 * u) < p_end;
-            const float t0 = wg_ld1<S16>(a.g, v ? gofs + u * gstep : gofs);
+            const float t0 = wg_ld1<S16>(rg, v ? gofs + u * gstep : gofs);
             gv[u] = v ? t0 : 0.f;
         }
 #pragma unroll
@@ -1455,7 +1468,7 @@ __global__ __launch_bounds__(256) void tapwgrad16_kernel(const LfTapGeom g, cons
             for (int u = 0; u < U; ++u) {
                 const int sx = (pj + 4 * u) * g.ssw + tdw[t];
                 const bool in = yin && sx >= 0 && sx < g.Ws && (p + 4 * u) < p_end;
-                float x0 = wg_ld1<S16>(a.x, xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix));
+                float x0 = wg_ld1<S16>(rx, xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix));
                 if (pro == LF_PRO_BNRELU) x0 = fmaxf(x0 * psc + psh, 0.f);
                 xv[t][u] = in ? x0 : 0.f;
             }
@@ -1568,8 +1581,8 @@ int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro) {
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st) {
     LF_REQUIRE(g.Cs % 16 == 0 && g.Cd % 16 == 0, "tapwgrad: channels must be multiples of 16");
     LF_REQUIRE(g.Wl % 4 == 0, "tapwgrad: logical width %d must be a multiple of 4", g.Wl);
-    LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 31) && (long)g.N * g.Hd * g.Wd * g.d_pix < (1L << 31),
-               "tapwgrad: tensor too large for 32-bit offsets");
+    LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 30) && (long)g.N * g.Hd * g.Wd * g.d_pix < (1L << 30),
+               "tapwgrad: tensor too large for 32-bit byte offsets");
     const int wb = a.bias_partial != nullptr;
     if (wgrad_split_ok(g, &a, pro)) {
         LF_REQUIRE(a.split == 9 || a.split == 6, "tapwgrad: split must be 9 or 6 (got %d)", a.split);
