@@ -81,6 +81,7 @@ struct LfWgradArgs {
     int split;              // 9 or 6: fp32 from 3-way split operands on the bf16 matrix cores (fp32 tensors, 64-channel blocks)
     float* partial;         // [splits][ntaps][Cs][Cd]
     float* bias_partial;    // [bias_rows][Cd] or null
+    unsigned long long* dbg = nullptr;   // tools/kbench.py --phases: 8 words per wave (start, first operands, loop done, end, HW id)
 };
 // number of k-split rows the kernel will write for this geometry
 int lf_tapwgrad_splits(const LfTapGeom& g);

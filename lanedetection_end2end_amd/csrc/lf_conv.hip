@@ -60,14 +60,14 @@ __device__ __forceinline__ f32x4 keep_pos(f32x4 v, f32x4 m) {
 // address arithmetic and VGPR-pair addressed memory instructions are what made it take 9 us instead of 4)
 typedef unsigned u32x2v __attribute__((vector_size(8)));
 template <bool S16>
-__device__ __forceinline__ f32x4 epi_ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
+__device__ __forceinline__ f32x4 epi_ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff = 0u) {   // element offsets
     if constexpr (S16) {
-        const u32x2v q = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(off * 2u), 0, 0);
+        const u32x2v q = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(off * 2u), (int)(soff * 2u), 0);
         f32x4 v;
         v.x = __uint_as_float(q[0] << 16); v.y = __uint_as_float(q[0] & 0xffff0000u);
         v.z = __uint_as_float(q[1] << 16); v.w = __uint_as_float(q[1] & 0xffff0000u);
         return v;
-    } else return ldb4(r, off * 4u, 0u);
+    } else return ldb4(r, off * 4u, soff * 4u);
 }
 template <bool S16>
 __device__ __forceinline__ void epi_st(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
@@ -950,9 +950,9 @@ namespace {
 template <bool S16>
 __device__ __forceinline__ f32x4 wg_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) { return epi_ld<S16>(r, off); }
 template <bool S16>
-__device__ __forceinline__ float wg_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    if constexpr (S16) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, (int)(off * 2u), 0, 0) << 16);
-    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(off * 4u), 0, 0));
+__device__ __forceinline__ float wg_ld1(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff = 0u) {
+    if constexpr (S16) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, (int)(off * 2u), (int)(soff * 2u), 0) << 16);
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(off * 4u), (int)(soff * 4u), 0));
 }
 __device__ __forceinline__ uint2 wg_ldraw(__amdgpu_buffer_rsrc_t r, unsigned off) {      // 4 bf16 elements, raw
     return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(off * 2u), 0, 0));
@@ -970,6 +970,8 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     constexpr int XB = XTiles * 16, GB = GTiles * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
+    unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
+    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memrealtime();
     // 1-D grid of gx * ntaps * (channel-block pairs) workgroups.  Workgroup L runs on XCD L % 8 (observed): each
     // XCD gets a contiguous run of the (pixel-split, channel-block, tap) order with the tap fastest, so all jobs of
     // one pixel range -- which read the same G rows and overlapping X rows -- follow each other through ONE L2
@@ -983,11 +985,17 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     const unsigned bxs = ord / ((unsigned)g.ntaps * nz);                  // pixel-split index: slowest
     (void)gxs;
     const int cib = bz / ncob, cob = bz % ncob;
+    // Loop state is WAVE-UNIFORM (scalar registers): a wave walks its pixel range in groups of 4U consecutive pixels of one
+    // image row; lane (pl, kq) takes pixel kq + 4u of the group.  A VALU instruction issued beside the partner wave's MFMA
+    // stream costs ~13 cycles, so the per-lane address / mask arithmetic of the first version (~150 instructions per 64 MFMAs)
+    // was as long as the matrix work itself.
     const long npix = (long)g.N * g.Hl * g.Wl;
-    const long sub = (long)bxs * WG_WAVES + wave;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const long sub = (long)bxs * WG_WAVES + wave_u;
     const long p_begin = sub * pps;
     long p_end = p_begin + pps;
     if (p_end > npix) p_end = npix;
+    const int niter = p_end > p_begin ? (int)((p_end - p_begin) / (4 * U)) : 0;     // pps and npix are multiples of 4U
 
     f32x4 acc[XTiles][GTiles];
 #pragma unroll
@@ -998,20 +1006,23 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
 #pragma unroll
     for (int q = 0; q < GTiles; ++q) bsum[q] = 0.f;
 
-    // this lane's pixel: p = p_begin + kq + 4*iter  (Wl % 4 == 0, so j += 4 never skips a row end)
-    long p = p_begin + kq;
-    int pj, pi, pn;
+    int pj, pi, pn;                       // (column, row, image) of the current group's first pixel
     {
-        const unsigned q = p < npix ? (unsigned)p : 0u;
+        const unsigned q = niter ? (unsigned)p_begin : 0u;
         const unsigned r = q / (unsigned)g.Wl;
         pj = (int)(q - r * (unsigned)g.Wl);
         pn = (int)(r / (unsigned)g.Hl);
         pi = (int)(r - (unsigned)pn * (unsigned)g.Hl);
+        // (the divisions run on the vector ALU: pin the uniform results to scalar registers)
+        pj = __builtin_amdgcn_readfirstlane(pj); pi = __builtin_amdgcn_readfirstlane(pi); pn = __builtin_amdgcn_readfirstlane(pn);
     }
     const int dh = g.tdh[t], dw = g.tdw[t];
     const int xch = g.s_choff + cib * XB + (XV ? 4 * pl : pl);
     const int gch = g.d_choff + cob * GB + (GV ? 4 * pl : pl);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, 0xffffffffu), rg = make_rsrc(a.g, 0xffffffffu);
+    // x: num_records = the tensor, so that the out-of-range offset LF_OOB reads as zero (the conv's padding); the launcher
+    // keeps tensors below LF_OOB bytes
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)((long)g.N * g.Hs * g.Ws * g.s_pix << (S16 ? 1 : 2))),
+                                 rg = make_rsrc(a.g, 0xffffffffu);
     f32x4 psc, psh;
     float psc1[XTiles], psh1[XTiles];
     if (pro == LF_PRO_BNRELU) {
@@ -1022,66 +1033,87 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
         }
     }
 
-    // One iteration = U k-steps = 4*U consecutive pixels of ONE image row (the launcher guarantees
-    // Wl % (4U) == 0 and pps % (4U) == 0), so a single (n,i,j) -> address computation serves U loads per
-    // operand.  Loads are unconditional (clamped address, masked at use) and double-buffered in two named
-    // register sets: the next iteration's 2U loads are in flight during the current 16*U MFMAs.
+    // per-lane constants (element offsets inside a group) and the group strides
+    const unsigned gvoff = (unsigned)(kq * g.dsw * g.d_pix + gch), gstep = (unsigned)(4 * g.dsw * g.d_pix);
+    const unsigned xvoff = (unsigned)(kq * g.ssw * g.s_pix + xch), xstep = (unsigned)(4 * g.ssw * g.s_pix);
+    constexpr unsigned ESH = S16 ? 1 : 2;          // element -> byte shift
+    // One iteration = U k-steps = one group (the launcher guarantees Wl % (4U) == 0 and pps % (4U) == 0).  INTERIOR groups
+    // (every tap position inside the image -- decided on scalars) load from a scalar base + per-lane constant; the others
+    // compute per-lane offsets, and a tap position outside the image gets the out-of-range offset LF_OOB, which the buffer load
+    // returns as 0.0f: no masks on the values.  Only with the BN+ReLU prologue (transform(0) != 0) the offsets are clamped
+    // and the mask bits applied after the transform.
+    // Loads are double-buffered in two named register sets: the next group's 2U loads are in flight during 16*U MFMAs.
     static_assert(!BFM || (S16 && XV && GV && U == 4), "BFM needs bf16 tensors, vector mode, U = 4");
     struct WStep {
         uint2 xr[BFM ? U : 1], gr[BFM ? U : 1];             // BFM: raw bf16 quads
         f32x4 x4[XV ? U : 1], g4[GV ? U : 1];
         float xs[XV ? 1 : U][XTiles], gs[GV ? 1 : U][GTiles];
-        unsigned vmask, xmask;
+        unsigned xmask;                                     // used with the prologue only
     };
-    auto wload = [&](WStep& S) {
-        unsigned vm = 0, xm = 0;
-        const bool rowv = (p - kq) < p_end;                  // whole group valid or not (p_end is a multiple of 4U or npix)
-        const int nn = rowv ? pn : 0, ii = rowv ? pi : 0, jj = rowv ? pj : 0;
-        // 32-bit element offsets from the (uniform) base pointers: one VGPR per address
-        const unsigned gofs = (unsigned)(((nn * g.Hd + ii * g.dsh + g.dah) * g.Wd + jj * g.dsw + g.daw) * g.d_pix + gch);
-        const unsigned gstep = (unsigned)(4 * g.dsw * g.d_pix);
-        const int sy = ii * g.ssh + dh;
-        const bool yin = sy >= 0 && sy < g.Hs;
-        const int syc = min(max(sy, 0), g.Hs - 1);
-        const unsigned xrow = (unsigned)((nn * g.Hs + syc) * g.Ws * g.s_pix + xch);
+    constexpr unsigned OOBE = LF_OOB >> ESH;                // in elements
+    auto ldx = [&](WStep& S, int u, unsigned voff, unsigned soff) __attribute__((always_inline)) {      // element offsets
+        if constexpr (BFM) S.xr[u] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, (int)(voff << 1), (int)(soff << 1), 0));
+        else if constexpr (XV) {
+            if constexpr (S16) S.x4[u] = epi_ld<true>(rx, voff, soff);
+            else S.x4[u] = ldb4(rx, voff << 2, soff << 2);
+        } else {
+#pragma unroll
+            for (int r = 0; r < XTiles; ++r) S.xs[u][r] = wg_ld1<S16>(rx, voff + r * 16, soff);
+        }
+    };
+    auto wload = [&](WStep& S) __attribute__((always_inline)) {
+        const unsigned gso = (unsigned)(((pn * g.Hd + pi * g.dsh + g.dah) * g.Wd + pj * g.dsw + g.daw) * g.d_pix);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool v = rowv && (p + 4 * u) < p_end;
-            vm |= (v ? 1u : 0u) << u;
-            const unsigned go = v ? gofs + u * gstep : gofs;
-            if constexpr (BFM) S.gr[u] = wg_ldraw(rg, go);
-            else if constexpr (GV) S.g4[u] = wg_ld4<S16>(rg, go);
-            else {
+            const unsigned so = gso + u * gstep;
+            if constexpr (BFM) S.gr[u] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, (int)(gvoff << 1), (int)(so << 1), 0));
+            else if constexpr (GV) {
+                if constexpr (S16) S.g4[u] = epi_ld<true>(rg, gvoff, so);
+                else S.g4[u] = ldb4(rg, gvoff << 2, so << 2);
+            } else {
 #pragma unroll
-                for (int q = 0; q < GTiles; ++q) S.gs[u][q] = wg_ld1<S16>(rg, go + q * 16);
-            }
-            const int sx = (jj + 4 * u) * g.ssw + dw;
-            const bool xin = v && yin && sx >= 0 && sx < g.Ws;
-            xm |= (xin ? 1u : 0u) << u;
-            const unsigned xo = xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix);
-            if constexpr (BFM) S.xr[u] = wg_ldraw(rx, xo);
-            else if constexpr (XV) S.x4[u] = wg_ld4<S16>(rx, xo);
-            else {
-#pragma unroll
-                for (int r = 0; r < XTiles; ++r) S.xs[u][r] = wg_ld1<S16>(rx, xo + r * 16);
+                for (int q = 0; q < GTiles; ++q) S.gs[u][q] = wg_ld1<S16>(rg, gvoff + q * 16, so);
             }
         }
-        S.vmask = vm; S.xmask = xm;
+        const int sy = pi * g.ssh + dh;
+        const bool yin = sy >= 0 && sy < g.Hs;
+        const int sx0 = pj * g.ssw + dw, sxl = sx0 + (4 * U - 1) * g.ssw;
+        if (yin && sx0 >= 0 && sxl < g.Ws) {
+            const unsigned xso = (unsigned)(((pn * g.Hs + sy) * g.Ws + sx0) * g.s_pix);
+#pragma unroll
+            for (int u = 0; u < U; ++u) ldx(S, u, xvoff, xso + u * xstep);
+            S.xmask = 0xfu;
+        } else {
+            const int syc = min(max(sy, 0), g.Hs - 1);
+            const unsigned xso = (unsigned)((pn * g.Hs + syc) * g.Ws * g.s_pix);
+            unsigned xm = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sx = sx0 + (kq + 4 * u) * g.ssw;
+                const bool in = yin && sx >= 0 && sx < g.Ws;
+                xm |= (in ? 1u : 0u) << u;
+                const unsigned oc = (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix + xch);
+                ldx(S, u, (in || pro == LF_PRO_BNRELU) ? oc : OOBE, xso);
+            }
+            S.xmask = xm;
+        }
     };
-    auto advance = [&]() {
-        p += 4 * U;
+    auto advance = [&]() __attribute__((always_inline)) {
         pj += 4 * U;
         if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
     };
     const bool need_bias = write_bias && a.bias_partial && t == 0 && cib == 0;      // workgroup-uniform
-    auto compute = [&](const WStep& S) {
+    // BIAS / PRO are compile-time in the loop body: left as scalar conditions the compiler if-converts them into v_cndmask
+    // selects over BOTH sides -- the VALU work the scalar loop state was meant to remove.
+    auto compute = [&](const WStep& S, auto BIAS_c, auto PRO_c) __attribute__((always_inline)) {
+        constexpr bool BIAS = decltype(BIAS_c)::value, PRO = decltype(PRO_c)::value;
         if constexpr (BFM) {
             uint2 xq[U], gq[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool v = (S.vmask >> u) & 1u, xin = (S.xmask >> u) & 1u;
+                const bool xin = !PRO || ((S.xmask >> u) & 1u);
                 uint2 xx = S.xr[u], gg = S.gr[u];
-                if (pro == LF_PRO_BNRELU) {          // relu(bn(x)) in fp32 on the widened quad, rounded back
+                if constexpr (PRO) {          // relu(bn(x)) in fp32 on the widened quad, rounded back
                     f32x4 t4;
                     t4.x = __uint_as_float(xx.x << 16); t4.y = __uint_as_float(xx.x & 0xffff0000u);
                     t4.z = __uint_as_float(xx.y << 16); t4.w = __uint_as_float(xx.y & 0xffff0000u);
@@ -1091,7 +1123,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
                     xx = __builtin_bit_cast(uint2, b);
                 }
                 xq[u].x = xin ? xx.x : 0u; xq[u].y = xin ? xx.y : 0u;
-                gq[u].x = v ? gg.x : 0u; gq[u].y = v ? gg.y : 0u;
+                gq[u] = gg;
             }
             // tile e of the x side = channels {4*row + e}: element e of every pixel's quad -> k = 4*kq + u
             s16x4 xa[4], gb[4];
@@ -1114,7 +1146,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa[r], gb[q], acc[r][q], 0, 0, 0);
-            if (need_bias) {
+            if constexpr (BIAS) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     bsum[0] += __uint_as_float(gq[u].x << 16); bsum[1] += __uint_as_float(gq[u].x & 0xffff0000u);
@@ -1126,50 +1158,61 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float xv[XTiles], gv[GTiles];
-            const bool v = (S.vmask >> u) & 1u, xin = (S.xmask >> u) & 1u;
             if constexpr (GV) { gv[0] = S.g4[u].x; gv[1] = S.g4[u].y; gv[2] = S.g4[u].z; gv[3] = S.g4[u].w; }
             else {
 #pragma unroll
                 for (int q = 0; q < GTiles; ++q) gv[q] = S.gs[u][q];
             }
-#pragma unroll
-            for (int q = 0; q < GTiles; ++q) gv[q] = v ? gv[q] : 0.f;
             if constexpr (XV) {
                 f32x4 t4 = S.x4[u];
-                if (pro == LF_PRO_BNRELU) t4 = max0(t4 * psc + psh);
+                if constexpr (PRO) t4 = max0(t4 * psc + psh);
                 xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
             } else {
 #pragma unroll
                 for (int r = 0; r < XTiles; ++r) {
                     float t1 = S.xs[u][r];
-                    if (pro == LF_PRO_BNRELU) t1 = fmaxf(t1 * psc1[r] + psh1[r], 0.f);
+                    if constexpr (PRO) t1 = fmaxf(t1 * psc1[r] + psh1[r], 0.f);
                     xv[r] = t1;
                 }
             }
+            if constexpr (PRO) {
+                const bool xin = (S.xmask >> u) & 1u;
 #pragma unroll
-            for (int r = 0; r < XTiles; ++r) xv[r] = xin ? xv[r] : 0.f;
+                for (int r = 0; r < XTiles; ++r) xv[r] = xin ? xv[r] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < XTiles; ++r)
 #pragma unroll
                 for (int q = 0; q < GTiles; ++q)
                     acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r], gv[q], acc[r][q], 0, 0, 0);
+            if constexpr (BIAS) {
 #pragma unroll
-            for (int q = 0; q < GTiles; ++q) bsum[q] += gv[q];
+                for (int q = 0; q < GTiles; ++q) bsum[q] += gv[q];
+            }
         }
     };
 
     WStep A, B;
-    wload(A);
-    while (p - kq < p_end) {           // wave-uniform: p - kq is the same in every lane
-        advance();
-        wload(B);                      // past the end: clamped, fully masked loads
-        compute(A);
-        if (!(p - kq < p_end)) break;
-        advance();
+    auto run = [&](auto BIAS_c, auto PRO_c) __attribute__((always_inline)) {
+        auto step = [&](const WStep& S) __attribute__((always_inline)) { compute(S, BIAS_c, PRO_c); };
         wload(A);
-        compute(B);
+        advance();
+        if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tstamp[1] = __builtin_amdgcn_s_memrealtime(); }
+        for (int it = 0;;) {
+            if (it + 1 < niter) { wload(B); advance(); }
+            step(A);
+            if (++it >= niter) break;
+            if (it + 1 < niter) { wload(A); advance(); }
+            step(B);
+            if (++it >= niter) break;
+        }
+    };
+    if (niter > 0) {
+        const bool prologue = pro == LF_PRO_BNRELU;
+        if (need_bias) { if (prologue) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+        else { if (prologue) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
     }
-
+    if (a.dbg) { asm volatile("" ::"v"(acc[0][0][0])); tstamp[2] = __builtin_amdgcn_s_memrealtime(); }
     // ---- reduce the 4 waves of the workgroup through LDS, wave 0 writes one partial row
     __builtin_amdgcn_s_setprio(3);
     __shared__ float red[WG_WAVES - 1][XTiles * GTiles * 4][64];
@@ -1224,6 +1267,18 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
                     a.bias_partial[(long)bxs * g.Cd + co] = v;
                 }
             }
+        }
+    }
+    if (a.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp[3] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* d = a.dbg + ((unsigned long long)blockIdx.x * WG_WAVES + wave) * 8;
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
+            d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
         }
     }
 }
@@ -1581,7 +1636,7 @@ int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro) {
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st) {
     LF_REQUIRE(g.Cs % 16 == 0 && g.Cd % 16 == 0, "tapwgrad: channels must be multiples of 16");
     LF_REQUIRE(g.Wl % 4 == 0, "tapwgrad: logical width %d must be a multiple of 4", g.Wl);
-    LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (1L << 30) && (long)g.N * g.Hd * g.Wd * g.d_pix < (1L << 30),
+    LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (long)(LF_OOB >> 2) && (long)g.N * g.Hd * g.Wd * g.d_pix < (long)(LF_OOB >> 2),
                "tapwgrad: tensor too large for 32-bit byte offsets");
     const int wb = a.bias_partial != nullptr;
     if (wgrad_split_ok(g, &a, pro)) {

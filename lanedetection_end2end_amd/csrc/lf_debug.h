@@ -18,6 +18,10 @@ void lf_debug_set_ops_precision(int mode);
  * retired; 8 words per wave) */
 int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C,
                                int axis, int dilation, float* scratch, unsigned long long* dbg, void* stream);
+/* the weight-gradient launch of lf_conv1d_bwd_weight with the same stamps (start, first operands, main loop done, partials
+ * stored, HW id); returns the number of waves launched, -1 on error */
+int lf_debug_conv1d_wgrad_phases(const float* x, const float* gy, int N, int H, int W, int C, int axis, int dilation,
+                                 float* scratch, unsigned long long* dbg, void* stream);
 #ifdef __cplusplus
 }
 #endif

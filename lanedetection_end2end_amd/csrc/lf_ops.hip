@@ -119,6 +119,17 @@ int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias
     return lf_tapgemm_launch(g, a, LF_PRO_NONE, 0, st);
 }
 
+// the weight gradient of lf_conv1d_bwd_weight (no reduction) with per-wave phase timestamps; returns the number of waves
+int lf_debug_conv1d_wgrad_phases(const float* x, const float* gy, int N, int H, int W, int C, int axis, int dilation,
+                                 float* scratch, unsigned long long* dbg, void* stream) {
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    LfWgradArgs a;
+    a.x = x; a.g = gy; a.pro_sc = nullptr; a.pro_sh = nullptr; a.s16 = 0; a.split = 0;
+    a.partial = scratch; a.bias_partial = nullptr; a.dbg = dbg;
+    const int rc = lf_tapwgrad_launch(g, a, LF_PRO_NONE, (hipStream_t)stream);
+    return rc ? -1 : lf_tapwgrad_splits_for(g, a, LF_PRO_NONE) * 3 * (C / 64) * (C / 64) * 4;
+}
+
 // scratch floats needed by the three calls below (packed weights / split-K partials)
 long lf_conv1d_scratch_floats(int N, int H, int W, int C) {
     const LfTapGeom g = conv1d_geom(N, H, W, C, 0, 1);

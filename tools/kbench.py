@@ -171,13 +171,59 @@ def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16),
     lib.lf_debug_set_tapgemm_variant(2)
 
 
+def _simd_report(t, hw, t0):
+    import numpy as np
+    key = ((hw >> 32) & 15) * 65536 + ((hw >> 4) & 3) + ((hw >> 8) & 15) * 4 + ((hw >> 12) & 0xf) * 64
+    simds = {}
+    for i, k in enumerate(key):
+        simds.setdefault(int(k), []).append(t[i] - t0)
+    cnt = np.bincount([len(v) for v in simds.values()])
+    print("     SIMDs used %d; waves per SIMD histogram %s" % (len(simds), dict((i, int(c)) for i, c in enumerate(cnt) if c)))
+    ends = np.array([max(w[3] for w in v) for v in simds.values()])
+    loops = np.array([max(w[2] for w in v) for v in simds.values()])
+    first = np.array([min(w[2] for w in v) for v in simds.values()])
+    print("     per SIMD: first wave's loop done %.2f (%.2f..%.2f) | last wave's loop done %.2f (%.2f..%.2f) | last store %.2f (%.2f..%.2f)"
+          % (first.mean(), first.min(), first.max(), loops.mean(), loops.min(), loops.max(), ends.mean(), ends.min(), ends.max()))
+    for k in sorted(simds)[:3] + sorted(simds)[len(simds) // 2: len(simds) // 2 + 3]:
+        print("     simd %06x: %s" % (k, "  ".join("[start %.2f ready %.2f loop %.2f end %.2f]" % tuple(w[:4]) for w in sorted(simds[k], key=lambda w: w[0]))))
+
+
+def wgrad_phases(batch=32, shapes=((128, 32, 64, 1, 16), (64, 64, 128, 1, 1))):
+    """Per-wave phases of the weight-gradient kernel (same stamps as phases())."""
+    import numpy as np
+    lib = _lib.load()
+    lib.lf_debug_set_ops_precision(0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for C, H, W, axis, d in shapes:
+        N = batch
+        x = torch.randn(N, H, W, C, device="cuda")
+        gy = torch.randn(N, H, W, C, device="cuda")
+        scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C), device="cuda")
+        dbg = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda")
+        f = lambda: lib.lf_debug_conv1d_wgrad_phases(P(x), P(gy), N, H, W, C, axis, d, P(scratch), P(dbg), st)
+        us = timeit(f, 300) * 1e6
+        dbg.zero_()
+        nw = f()
+        torch.cuda.synchronize()
+        full = dbg.cpu().numpy()
+        t = full[: nw * 8].reshape(nw, 8)
+        ok = t[:, 0] > 0
+        hw = t[ok, 4]
+        t = t[ok].astype(np.float64) * 0.01
+        t0 = t[:, 0].min()
+        print("wgrad C=%3d N=%3d waves %5d | launch %6.1f us | start spread %5.2f | first operands %5.2f | main loop done %6.2f (min %6.2f max %6.2f) | "
+              "partials stored %6.2f (max %6.2f)" % (C, N, len(t), us, (t[:, 0] - t0).max(), (t[:, 1] - t0).mean(), (t[:, 2] - t0).mean(),
+                                                     (t[:, 2] - t0).min(), (t[:, 2] - t0).max(), (t[:, 3] - t0).mean(), (t[:, 3] - t0).max()), flush=True)
+        _simd_report(t, hw, t0)
+
+
 if __name__ == "__main__" and "--phases" in sys.argv:
     sp = int(sys.argv[sys.argv.index("--split") + 1]) if "--split" in sys.argv else 0
     for nb in (32,):
+        if "--wgrad" in sys.argv:
+            wgrad_phases(nb)
+            continue
         phases(nb, sp, variant=2)
-        if "--store-ablate" in sys.argv:
-            phases(nb, sp, variant=2, ablate=1)
-            phases(nb, sp, variant=2, ablate=2)
         if "--lds" in sys.argv:
             for ab in (0, 4):
                 phases(nb, sp, variant=0, ablate=ab)
