@@ -172,9 +172,14 @@ _Pragma("unroll") \
         } \
     } \
 
+extern __shared__ __attribute__((aligned(16))) unsigned char lf_tap_lds[];      // tap tables of tapgemm_kernel
+constexpr size_t LF_TAP_LDS_PER_TAP = (size_t)WG_WAVES * 64 * (sizeof(uint4) + sizeof(unsigned));
+
 // EPIC >= 0: the epilogue flags are compiled in (the combinations the network uses at 64 output channels per workgroup); the
 // epilogue of one wave runs beside its partner's MFMA stream at ~14 cycles per VALU instruction, so the ~1500 instructions of
 // the runtime-flag form (EPIC = -1) cost 9 us of a 30 us workgroup life -- and the slot it occupies cannot be refilled.
+// (A one-operand-set form at <= 128 registers, four workgroups per CU so that the 4096 waves of a 64-channel launch run as ONE
+// round, was measured and dropped: 72 vs 68 us -- three waves per SIMD of this form already overlap rounds.)
 template <int NT, int PROC, int EPIC = -1>
 __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
@@ -222,8 +227,9 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         // accumulators stay in place and the scheduler is free to sink loads between MFMAs.  Steps past the
         // end (odd step counts) are issued with clamped addresses and a zero mask.
         struct Step { f32x4 w[NT]; f32x4 x[MT]; f32x4 sc, sh; unsigned ok; };
-        __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
-        __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
+        // (dynamic LDS, 5 KB per tap: the static 9-tap table was 46 KB and capped the CU at 3 workgroups)
+        uint4 (*tab_off)[64] = reinterpret_cast<uint4 (*)[64]>(lf_tap_lds) + wave * g.ntaps;
+        unsigned (*tab_ok)[64] = reinterpret_cast<unsigned (*)[64]>(lf_tap_lds + (size_t)WG_WAVES * g.ntaps * 64 * sizeof(uint4)) + wave * g.ntaps;
         // PROC == 0: a padding position holds the out-of-range offset LF_OOB, the buffer load returns the zero itself;
         // with the BN+ReLU prologue (transform(0) != 0) the offsets are clamped and the mask is applied after the transform.
         for (int t = 0; t < g.ntaps; ++t) {
@@ -238,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
                 if (PROC == 0 && !in) o[m] = LF_OOB;
                 okb |= (in ? 1u : 0u) << m;
             }
-            tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
-            tab_ok[wave][t][lane] = okb;
+            tab_off[t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+            tab_ok[t][lane] = okb;
         }
         // (each lane reads back only what it wrote: no barrier needed)
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 4, (long)LF_OOB));
@@ -252,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         auto issue = [&](Step& S) {
             const bool live = t_ld < ntaps;
             const int tc = live ? t_ld : ntaps - 1;
-            uint4 o = tab_off[wave][tc][lane];
-            const unsigned okb = tab_ok[wave][tc][lane];
+            uint4 o = tab_off[tc][lane];
+            const unsigned okb = tab_ok[tc][lane];
 #pragma unroll
             for (int n = 0; n < NT; ++n) S.w[n] = ldb4(rw, wlane + n * 256, (unsigned)wofs);
             const unsigned c16 = (unsigned)cg_ld * 64u;    // bytes
@@ -297,6 +303,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         Step A, B;
         issue(A);
         const int npairs = (nsteps + 1) >> 1;
+        // (Priority falling with progress makes the two waves of a SIMD finish together instead of ~12 us apart -- measured
+        // neutral at 128 channels and 15 % SLOWER at 64, where a third / fourth wave waits for the slot of the first finisher.)
         for (int pr = 0; pr < npairs; ++pr) {
             finish(A);
             mma(A, 0);
@@ -868,10 +876,11 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     if (use_lds_kernel(g, a)) return lf_tapgemm_lds_launch(g, a, pro, epi, st);
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
-        if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), 0, st, g, a, pro, epi);  \
-        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                       \
+        if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), tap_lds, st, g, a, pro, epi);  \
+        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 0>), grid, dim3(256), tap_lds, st, g, a, pro, epi);                       \
     } while (0)
-#define LF_TG4(PROV, EPIV) hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi)
+#define LF_TG4(PROV, EPIV) hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV>), grid, dim3(256), tap_lds, st, g, a, pro, epi)
+    const size_t tap_lds = LF_TAP_LDS_PER_TAP * g.ntaps;
     LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
     if (a.split && a.wp48 && !a.wp16 && lf_tapgemm_split_ok(g)) {
         LF_REQUIRE(a.split == 9 || a.split == 6, "tapgemm: split must be 9 or 6 (got %d)", a.split);
@@ -1198,7 +1207,12 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
         wload(A);
         advance();
         if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tstamp[1] = __builtin_amdgcn_s_memrealtime(); }
+        __builtin_amdgcn_s_setprio(3);              // priority falls with progress (see tapgemm_kernel): the waves of a SIMD finish together
+        const int q1 = niter >> 2, q2 = niter >> 1, q3 = q1 + q2;
         for (int it = 0;;) {
+            if (it == q1) __builtin_amdgcn_s_setprio(2);
+            if (it == q2) __builtin_amdgcn_s_setprio(1);
+            if (it == q3) __builtin_amdgcn_s_setprio(0);
             if (it + 1 < niter) { wload(B); advance(); }
             step(A);
             if (++it >= niter) break;
