@@ -36,8 +36,6 @@ enum {
 struct LfTapArgs {
     const float* src;
     const float* wp;        // packed weights [tap][Cs/4][Cd][4]
-    const float* wp32;      // the same weights as [tap][Cs/32][Cd][32] (LDS-tiled kernel, lf_convlds.hip); null = not available
-    const float* zeros;     // >= 32 zero floats (128-byte aligned): what the LDS-tiled kernel's DMA reads for padding pixels
     int s16;                // 1: src / dst / mask_src / add_src / aux hold bf16 elements (needs wp16)
     const void* wp16;       // non-null selects the bf16 matrix-core kernel: packed bf16 weights [tap][ceil(Cs/32)*4][Cd][8]
     int split;              // 9 or 6: fp32 on the bf16 matrix cores from 3-way split operands (tapgemm_split_kernel);
@@ -60,17 +58,9 @@ struct LfTapArgs {
 };
 
 void lf_tapgemm_set_split_any_size(int v);
-int lf_tapgemm_variant();
-void lf_tapgemm_set_variant(int v);   // kernel A/B switch for tools/kbench.py: 0 = default (LDS-tiled kernel where it applies), 2 = streaming kernel only
 int lf_tapgemm_stat_rows(const LfTapGeom& g);                          // upper bound over the kernels (buffer sizing)
 int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a);  // rows the launch with these arguments writes
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);
-
-// LDS-tiled kernel (lf_convlds.hip): Cs % 32 == 0, Cd == 64 or 128, fp32 tensors
-bool lf_tapgemm_lds_ok(const LfTapGeom& g);
-int lf_tapgemm_lds_grid(const LfTapGeom& g);
-void lf_tapgemm_lds_set_ablate(int mask);   // tools/kbench.py --phases only
-int lf_tapgemm_lds_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);
 
 struct LfWgradArgs {
     const float* x;         // source-side tensor (gathered by taps), geometry = source fields of LfTapGeom
@@ -120,12 +110,6 @@ struct LfPackEntry {
     long dst16_off; // bf16-element offset into the bf16 packed arena (precision mode "bf16")
 };
 int lf_pack_weights_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena,
-                           hipStream_t st);
-// wp32[((t*(Kc/32) + k/32)*Nc + n)*32 + k%32] for the entries the LDS-tiled kernel takes (same dst_off, separate arena)
-// (both also clear the 64-float zero page `zeros` that LfTapArgs::zeros points to)
-int lf_pack_weights_lds_launch(const LfPackEntry* entries_dev, int nentries, const float* const* params_dev, float* arena32,
-                               float* zeros, hipStream_t st);
-int lf_pack_one_lds_launch(const float* w, float* dst, int Kc, int Nc, int ntaps, long sk, long sn, int flip, float* zeros,
                            hipStream_t st);
 long lf_pack_bf16_elems(int Kc, int Nc, int ntaps);
 // split weights: 3 bf16 pieces per element, entry e at 3 * e.dst16_off of arena48 (entries with Kc % 32 != 0 are skipped)

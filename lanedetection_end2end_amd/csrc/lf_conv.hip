@@ -818,7 +818,6 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
     LF_TAPGEMM_EPILOGUE
 }
 
-int g_tapgemm_variant = 2;     // 2 = streaming kernels (shipped), 0 = LDS-tiled kernel where it applies (lf_convlds.hip; tools/kbench.py A/B)
 int g_split_any_size = 0;      // kernel-level tests only: let the split kernel take launches below its shipped size rule
 
 int pick_nt(int Cd) {
@@ -831,8 +830,6 @@ int pick_nt(int Cd) {
 
 }  // namespace
 
-void lf_tapgemm_set_variant(int v) { g_tapgemm_variant = v; }
-int lf_tapgemm_variant() { return g_tapgemm_variant; }
 void lf_tapgemm_set_split_any_size(int v) { g_split_any_size = v; }
 
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
@@ -846,20 +843,12 @@ bool lf_tapgemm_split_ok(const LfTapGeom& g) {
            (wgs >= 192 || g_split_any_size);
 }
 
-namespace {
-bool use_lds_kernel(const LfTapGeom& g, const LfTapArgs& a) {
-    return g_tapgemm_variant == 0 && a.wp32 && !a.wp16 && !a.split && !a.s16 && lf_tapgemm_lds_ok(g);
-}
-}  // namespace
-
 int lf_tapgemm_stat_rows(const LfTapGeom& g) {
     const long npix = (long)g.N * g.Hl * g.Wl;
-    const int rows = lf_cdiv(npix, PIX_PER_WG);
-    const int lds = lf_tapgemm_lds_ok(g) ? lf_tapgemm_lds_grid(g) : 0;
-    return rows > lds ? rows : lds;
+    return lf_cdiv(npix, PIX_PER_WG);
 }
 int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a) {
-    if (use_lds_kernel(g, a)) return lf_tapgemm_lds_grid(g);
+    (void)a;
     return lf_cdiv((long)g.N * g.Hl * g.Wl, PIX_PER_WG);
 }
 
@@ -873,7 +862,6 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     dim3 grid(lf_cdiv(npix, PIX_PER_WG), g.Cd / (16 * nt));
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix * 4 < (long)LF_OOB, "tapgemm: source tensor too large for 32-bit byte offsets");
     LF_REQUIRE((long)g.N * g.Hd * g.Wd * g.d_pix * 4 < (long)LF_OOB, "tapgemm: destination tensor too large for 32-bit byte offsets");
-    if (use_lds_kernel(g, a)) return lf_tapgemm_lds_launch(g, a, pro, epi, st);
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
         if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), tap_lds, st, g, a, pro, epi);  \

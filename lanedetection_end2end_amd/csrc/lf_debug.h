@@ -1,16 +1,12 @@
-// Test / tooling hooks of liblanefit_hip.so (NOT part of the public C ABI in include/lanefit.h): kernel A/B switches for
+// Test / tooling hooks of liblanefit_hip.so (NOT part of the public C ABI in include/lanefit.h): the phase-stamp entries of
 // tools/kbench.py and the precision selector of the kernel-level lf_conv1d_* parity tests.  Exported with C linkage so
 // that ctypes can reach them; process-global state, never touched by the product path.
 #pragma once
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* 0 = default kernel selection (LDS-tiled kernel for the 64- / 128-channel launches), 2 = streaming kernels only */
-void lf_debug_set_tapgemm_variant(int v);
 /* 1: the split kernels also take launches below their shipped size rule (kernel-level tests at small shapes) */
 void lf_debug_set_split_any_size(int v);
-/* LDS-tiled kernel ablations for tools/kbench.py --phases: 1 = no stores, 2 = no MFMAs, 4 = only the first chunk loaded */
-void lf_debug_set_lds_ablate(int mask);
 /* precision mode of the lf_conv1d_* calls: 0 fp32, 1 bf16 matrix cores on fp32 tensors, 2 bf16 matrix cores on bf16
  * tensors (x, y, gx, gy, mask_src hold bf16; w, bias, gw, gb stay fp32), 9 / 6 fp32 from 3-way split operands */
 void lf_debug_set_ops_precision(int mode);

@@ -56,8 +56,6 @@ struct lf_erfnet_plan {
     int n_params, n_bn, n_drop;
     int p_head_w[2], p_head_b[2], n_heads;
     long off_entries, off_packed, packed_floats;
-    long off_packed32;                          // the same weights in the LDS-tiled kernel's order (lf_convlds.hip), same dst_off
-    long off_zero;                              // 64 zero floats: the padding source of that kernel's DMA
     long off_packed16, packed16_elems;          // bf16 operand copies of the packed weights (precision modes 1, 2)
     long off_packed48;                          // 3-piece bf16 split of the packed weights (modes 3, 4): 3 * packed16_elems
     mutable int precision = 0;                  // lf_erfnet_set_precision
@@ -290,8 +288,6 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
 
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
     P->off_packed = ws.take(P->packed_floats);
-    P->off_packed32 = ws.take(P->packed_floats);
-    P->off_zero = ws.take(64);
     P->off_packed16 = ws.take((P->packed16_elems + 1) / 2);
     P->off_packed48 = ws.take((3 * P->packed16_elems + 1) / 2);
     P->off_stat0 = ws.take(P->stat_floats);
@@ -371,7 +367,6 @@ struct Ctx {
     mutable int last_rows = 0;           // BatchNorm partial rows the last run_gemm wrote (depends on the kernel it selected)
     float* at(long off) const { return ws + off; }
     const float* packed(int pack) const { return ws + P->off_packed + P->packs[pack].dst_off; }
-    const float* packed32(int pack) const { return ws + P->off_packed32 + P->packs[pack].dst_off; }
 };
 
 double gemm_flops(const LfTapGeom& g) { return 2.0 * (double)g.N * g.Hl * g.Wl * g.Cs * g.Cd * g.ntaps; }
@@ -396,7 +391,6 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
              LfTapArgs extra) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
     extra.s16 = c.s16;
-    if (c.P->precision == 0 && lf_tapgemm_variant() == 0) { extra.wp32 = c.packed32(op.pack); extra.zeros = c.at(c.P->off_zero); }
     if (c.P->precision == 1 || c.P->precision == 2)
         extra.wp16 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed16) + c.P->packs[op.pack].dst16_off;
     if (c.P->precision >= 3) {      // fp32 from split operands on the bf16 matrix cores (9 or 6 partial products)
@@ -680,8 +674,6 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
     if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
         return lf_fail("erfnet: upload of the pack table failed");
     LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
-    if (P->precision == 0 && lf_tapgemm_variant() == 0)      // only when the LDS-tiled kernel is selectable
-        LF_TRY(lf_pack_weights_lds_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed32), c.at(P->off_zero), c.st));
     if (P->precision == 1 || P->precision == 2)
         LF_TRY(lf_pack_weights_bf16_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed16), c.st));
     if (P->precision >= 3)

@@ -77,11 +77,6 @@ void pack_conv1d(LfTapArgs& a, const float* w, float* scratch, int C, long sk, l
         a.s16 = g_ops_bf16 == 2;
     } else {
         hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, sk, sn, flip);
-        if (C % 32 == 0) {      // the LDS-tiled kernel's order (taken for C = 64 / 128)
-            (void)lf_pack_one_lds_launch(w, scratch + 3L * C * C, C, C, 3, sk, sn, flip, scratch + 6L * C * C, st);
-            a.wp32 = scratch + 3L * C * C;
-            a.zeros = scratch + 6L * C * C;
-        }
     }
     a.wp = scratch;
 }
@@ -99,9 +94,7 @@ LfTapGeom conv1d_geom(int N, int H, int W, int C, int axis, int d) {
 
 extern "C" {
 
-void lf_debug_set_tapgemm_variant(int v) { lf_tapgemm_set_variant(v); }
 void lf_debug_set_split_any_size(int v) { lf_tapgemm_set_split_any_size(v); }
-void lf_debug_set_lds_ablate(int mask) { lf_tapgemm_lds_set_ablate(mask); }
 // precision mode of the kernel-level conv1d calls below (tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32 tensors,
 // 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src then hold bf16 elements; w, bias, gw, gb stay fp32)
 void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = mode; }

@@ -25,7 +25,7 @@ DB=$(find $OUT/trace -name '*_results.db' | head -1)
 python profiles/summarize_rocpd.py "$DB" > profiles/${TAG}_kernel_stats.txt
 
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --variants 2 --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1
 done
 python profiles/summarize_traffic.py $OUT $TAG "$COMMIT"
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # after a kernel change: kernel-level timings + conv parity tests + the headline bench
 mkdir -p gpurun_out
-python tools/kbench.py --variants 2 --iters 300 > gpurun_out/r2_kbench6.txt 2>&1
+python tools/kbench.py --iters 300 > gpurun_out/r2_kbench6.txt 2>&1
 tail -12 gpurun_out/r2_kbench6.txt
 timeout 900 python -m pytest tests/test_backbone_gpu.py -m gpu -x -q > gpurun_out/r2_pytest6.txt 2>&1
 tail -3 gpurun_out/r2_pytest6.txt

@@ -1,3 +1,8 @@
+// EXPERIMENT, NOT BUILT: the LDS-tiled, phase-locked 8-wave form of the tap-GEMM measured in round 2 (profiles/
+// r2_kbench_lds_vs_streaming.txt, r2_lds_kernel_phases.txt).  It ties the shipped streaming kernel at 128 channels (60.1 vs
+// 60.7 us warm) and loses at 64 (73.7 vs 66.7 us), so it was taken out of the library; commit 8c5b696 has it wired in
+// (LfTapArgs::wp32 / zeros, lf_pack_weights_lds_launch, tools/kbench.py --variants 0).  Kept as the starting point for a
+// 3-buffer / staggered-epilogue follow-up.
 // LDS-tiled tap-GEMM for the 64- / 128-channel layers (94 % of the network's MACs), fp32 matrix cores.
 //
 // Same contract as tapgemm_kernel (lf_conv.h): dst[dpix(p)][co] = epi(bias + sum_t sum_ci pro(src[spix(p,t)][ci]) * W[t][ci][co]),

@@ -3,7 +3,8 @@
 HIP-event timed, as TFLOP/s against the fp32 MFMA peak.  Also checks each result against torch (on the
 GPU, fp32) so that a faster variant that is wrong is caught immediately.
 
-    python tools/kbench.py [--variants 0 1] [--iters 30]
+    python tools/kbench.py [--iters 300] [--bf16 | --split 9] [--one C H W AXIS DIL]
+    python tools/kbench.py --phases [--wgrad]      per-wave phase stamps, waves paired up by the SIMD they ran on
 """
 import argparse
 import ctypes
@@ -38,7 +39,6 @@ def timeit(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", type=int, nargs="+", default=[0, 2], help="0 = shipped selection (LDS-tiled kernel), 2 = streaming kernel")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--bf16", action="store_true", help="bf16 matrix-core kernel for fwd / dgrad; the torch check runs on "
@@ -84,8 +84,7 @@ def main():
                 yr = F.conv2d(rb(xn), rb(w4), b, padding=pad, dilation=dil)
                 gx_ref = torch.nn.grad.conv2d_input(xn.shape, rb(w4), rb(gy.permute(0, 3, 1, 2).contiguous()), padding=pad,
                                                     dilation=dil)
-        for v in a.variants:
-            lib.lf_debug_set_tapgemm_variant(v)
+        for v in (2,):
             f = lambda: _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 0, P(scratch), st), "fwd")
             tf = timeit(f, a.iters)
             e1 = float((y.permute(0, 3, 1, 2) - yr).abs().max() / yr.abs().max())
@@ -112,14 +111,12 @@ if __name__ == "__main__" and "--phases" not in sys.argv:
     main()
 
 
-def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16), (64, 64, 128, 1, 1))):
+def phases(batch=32, split=0, variant=2, ablate=0, shapes=((128, 32, 64, 1, 16), (64, 64, 128, 1, 1))):
     """Per-wave phase breakdown of the forward tap-GEMM (s_memrealtime stamps, 100 MHz): first operands resident /
     main loop / epilogue + store drain, in microseconds from the first wave's start; launch time by HIP events."""
     import numpy as np
     lib = _lib.load()
     lib.lf_debug_set_ops_precision(split)
-    lib.lf_debug_set_tapgemm_variant(variant)
-    lib.lf_debug_set_lds_ablate(ablate)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for C, H, W, axis, d in shapes:
         N = batch
@@ -137,38 +134,15 @@ def phases(batch=32, split=0, variant=0, ablate=0, shapes=((128, 32, 64, 1, 16),
         torch.cuda.synchronize()
         full = dbg.cpu().numpy().astype(np.float64)
         t = full[: nw * 8].reshape(nw, 8)
-        tr = full[2048 * 8: 2048 * 8 + 2048].reshape(32, 64) * 0.01 if variant == 0 else np.zeros((32, 64))
         t = t[t[:, 0] > 0] * 0.01                      # waves that ran; ticks -> microseconds
         t0 = t[:, 0].min()
-        print("var %d ablate %d C=%3d N=%3d waves %5d | launch+pack %6.1f us | start spread %5.2f | operands ready %5.2f (max %5.2f) | "
+        print("fwd C=%3d N=%3d waves %5d | launch+pack %6.1f us | start spread %5.2f | operands ready %5.2f (max %5.2f) | "
               "main loop done %6.2f (min %6.2f max %6.2f) | stores retired %6.2f (max %6.2f)"
-              % (variant, ablate, C, N, len(t), us, (t[:, 0] - t0).max(), (t[:, 1] - t0).mean(), (t[:, 1] - t0).max(),
+              % (C, N, len(t), us, (t[:, 0] - t0).max(), (t[:, 1] - t0).mean(), (t[:, 1] - t0).max(),
                  (t[:, 2] - t0).mean(), (t[:, 2] - t0).min(), (t[:, 2] - t0).max(), (t[:, 3] - t0).mean(), (t[:, 3] - t0).max()),
               flush=True)
-        if variant == 2:                            # pair the waves up by the SIMD they ran on
-            hw = full[: nw * 8].reshape(nw, 8)[:, 4].astype(np.int64)
-            hw = hw[full[: nw * 8].reshape(nw, 8)[:, 0] > 0]
-            key = ((hw >> 32) & 15) * 65536 + ((hw >> 4) & 3) + ((hw >> 8) & 15) * 4 + ((hw >> 12) & 0xf) * 64
-            simds = {}
-            for i, k in enumerate(key):
-                simds.setdefault(int(k), []).append(t[i] - t0)
-            cnt = np.bincount([len(v) for v in simds.values()])
-            print("     SIMDs used %d; waves per SIMD histogram %s" % (len(simds), dict((i, int(c)) for i, c in enumerate(cnt) if c)))
-            ends = np.array([max(w[3] for w in v) for v in simds.values()])
-            loops = np.array([max(w[2] for w in v) for v in simds.values()])
-            first = np.array([min(w[2] for w in v) for v in simds.values()])
-            print("     per SIMD: first wave's loop done %.2f (%.2f..%.2f) | last wave's loop done %.2f (%.2f..%.2f) | last store %.2f (%.2f..%.2f)"
-                  % (first.mean(), first.min(), first.max(), loops.mean(), loops.min(), loops.max(), ends.mean(), ends.min(), ends.max()))
-            for k in sorted(simds)[:3] + sorted(simds)[len(simds) // 2: len(simds) // 2 + 3]:
-                print("     simd %06x: %s" % (k, "  ".join("[start %.2f ready %.2f loop %.2f end %.2f]" % tuple(w[:4]) for w in sorted(simds[k], key=lambda w: w[0]))))
-        if variant == 0 and tr.max() > 0:           # per-phase trace of workgroup 0: wave 0 (group A) and wave 4 (group B)
-            for wv in (0, 4):
-                r = tr[wv]
-                r = r[r > 0]
-                d = np.diff(r)
-                print("     wg 0 wave %d: barrier-to-barrier us: %s" % (wv, " ".join("%.2f" % v for v in d)), flush=True)
-    lib.lf_debug_set_lds_ablate(0)
-    lib.lf_debug_set_tapgemm_variant(2)
+        hw = full[: nw * 8].reshape(nw, 8)[:, 4].astype(np.int64)
+        _simd_report(t, hw[full[: nw * 8].reshape(nw, 8)[:, 0] > 0], t0)       # pair the waves up by the SIMD they ran on
 
 
 def _simd_report(t, hw, t0):
@@ -224,6 +198,3 @@ if __name__ == "__main__" and "--phases" in sys.argv:
             wgrad_phases(nb)
             continue
         phases(nb, sp, variant=2)
-        if "--lds" in sys.argv:
-            for ab in (0, 4):
-                phases(nb, sp, variant=0, ablate=ab)
