@@ -388,7 +388,6 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 
     // S16: the source holds bf16 -> one dwordx4 per tile is the whole 8-channel operand (xl used as raw bits)
     struct Step { u32x4 w[NT]; f32x4 xl[MT], xh[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
-    const lf_bf16* src16 = reinterpret_cast<const lf_bf16*>(a.src);
     __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
     __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
     for (int t = 0; t < g.ntaps; ++t) {
@@ -407,7 +406,9 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
     }
     const int ncb = (g.Cs + 31) >> 5;                       // 32-channel steps per tap
     const int nsteps = g.ntaps * ncb;
-    const __bf16* wp = reinterpret_cast<const __bf16*>(a.wp16) + ((long)kq * g.Cd + cob + pl) * 8;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp16, 0xffffffffu), rx = make_rsrc(a.src, 0xffffffffu),
+                                 rsc = make_rsrc(a.pro_sc, 0xffffffffu), rsh = make_rsrc(a.pro_sh, 0xffffffffu);
+    const unsigned wlane = (unsigned)(kq * g.Cd + cob + pl) * 16u;      // bytes (8 bf16 per lane and tile)
     const int wstep = g.Cd * 32;                            // bf16 elements per 32-channel step
     const int ntaps = g.ntaps;
     const int wlast = (nsteps - 1) * wstep;
@@ -418,22 +419,22 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
         const uint4 o = tab_off[wave][tc][lane];
         const unsigned okb = tab_ok[wave][tc][lane];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) S.w[n] = *reinterpret_cast<const u32x4*>(wp + wofs + n * 128);
+        for (int n = 0; n < NT; ++n) S.w[n] = __builtin_bit_cast(u32x4, ldb4(rw, wlane + n * 256, (unsigned)wofs * 2u));
         const int c8 = min(cb_ld * 32 + kq * 8, g.Cs - 8);  // a partial last step re-reads valid channels (weights are 0)
-        if constexpr (S16) {
-            S.xl[0] = *reinterpret_cast<const f32x4*>(src16 + o.x + c8);
-            S.xl[1] = *reinterpret_cast<const f32x4*>(src16 + o.y + c8);
-            S.xl[2] = *reinterpret_cast<const f32x4*>(src16 + o.z + c8);
-            S.xl[3] = *reinterpret_cast<const f32x4*>(src16 + o.w + c8);
+        if constexpr (S16) {                                 // buffer-addressed (see ldb4): bf16 elements, 16 bytes = 8 channels
+            S.xl[0] = ldb4(rx, (o.x + c8) * 2u, 0u);
+            S.xl[1] = ldb4(rx, (o.y + c8) * 2u, 0u);
+            S.xl[2] = ldb4(rx, (o.z + c8) * 2u, 0u);
+            S.xl[3] = ldb4(rx, (o.w + c8) * 2u, 0u);
         } else {
-            S.xl[0] = ldg4(a.src + o.x + c8); S.xh[0] = ldg4(a.src + o.x + c8 + 4);
-            S.xl[1] = ldg4(a.src + o.y + c8); S.xh[1] = ldg4(a.src + o.y + c8 + 4);
-            S.xl[2] = ldg4(a.src + o.z + c8); S.xh[2] = ldg4(a.src + o.z + c8 + 4);
-            S.xl[3] = ldg4(a.src + o.w + c8); S.xh[3] = ldg4(a.src + o.w + c8 + 4);
+            S.xl[0] = ldb4(rx, (o.x + c8) * 4u, 0u); S.xh[0] = ldb4(rx, (o.x + c8) * 4u + 16u, 0u);
+            S.xl[1] = ldb4(rx, (o.y + c8) * 4u, 0u); S.xh[1] = ldb4(rx, (o.y + c8) * 4u + 16u, 0u);
+            S.xl[2] = ldb4(rx, (o.z + c8) * 4u, 0u); S.xh[2] = ldb4(rx, (o.z + c8) * 4u + 16u, 0u);
+            S.xl[3] = ldb4(rx, (o.w + c8) * 4u, 0u); S.xh[3] = ldb4(rx, (o.w + c8) * 4u + 16u, 0u);
         }
         if constexpr (PROC == LF_PRO_BNRELU) {
-            S.sc0 = ldg4(a.pro_sc + c8); S.sc1 = ldg4(a.pro_sc + c8 + 4);
-            S.sh0 = ldg4(a.pro_sh + c8); S.sh1 = ldg4(a.pro_sh + c8 + 4);
+            S.sc0 = ldb4(rsc, c8 * 4u, 0u); S.sc1 = ldb4(rsc, c8 * 4u + 16u, 0u);
+            S.sh0 = ldb4(rsh, c8 * 4u, 0u); S.sh1 = ldb4(rsh, c8 * 4u + 16u, 0u);
         }
         S.ok = live ? okb : 0u;
         const int cbn = cb_ld + 1;
@@ -597,6 +598,8 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
     auto wstore = [&](int buf) {
         if (filler) { wl[buf][0][f_kb][f_co] = wreg[0]; wl[buf][1][f_kb][f_co] = wreg[1]; wl[buf][2][f_kb][f_co] = wreg[2]; }
     };
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.src, 0xffffffffu), rsc = make_rsrc(a.pro_sc, 0xffffffffu),
+                                 rsh = make_rsrc(a.pro_sh, 0xffffffffu);
     int t_ld = 0, cb_ld = 0;
     auto issue = [&](Raw& S) {
         const bool live = t_ld < ntaps;
@@ -604,14 +607,15 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
         const uint4 o = tab_off[wave][tc][lane];
         const unsigned okb = tab_ok[wave][tc][lane];
         const int c32 = cb_ld * 32;
-        S.xl[0] = ldg4(a.src + o.x + c32); S.xh[0] = ldg4(a.src + o.x + c32 + 4);
-        S.xl[1] = ldg4(a.src + o.y + c32); S.xh[1] = ldg4(a.src + o.y + c32 + 4);
-        S.xl[2] = ldg4(a.src + o.z + c32); S.xh[2] = ldg4(a.src + o.z + c32 + 4);
-        S.xl[3] = ldg4(a.src + o.w + c32); S.xh[3] = ldg4(a.src + o.w + c32 + 4);
+        const unsigned cs = (unsigned)c32 * 4u;          // scalar byte offset of the channel step (buffer-addressed, see ldb4)
+        S.xl[0] = ldb4(rx, o.x * 4u, cs); S.xh[0] = ldb4(rx, o.x * 4u + 16u, cs);
+        S.xl[1] = ldb4(rx, o.y * 4u, cs); S.xh[1] = ldb4(rx, o.y * 4u + 16u, cs);
+        S.xl[2] = ldb4(rx, o.z * 4u, cs); S.xh[2] = ldb4(rx, o.z * 4u + 16u, cs);
+        S.xl[3] = ldb4(rx, o.w * 4u, cs); S.xh[3] = ldb4(rx, o.w * 4u + 16u, cs);
         if constexpr (PROC == LF_PRO_BNRELU) {
-            const int c8 = c32 + kq * 8;
-            S.sc0 = ldg4(a.pro_sc + c8); S.sc1 = ldg4(a.pro_sc + c8 + 4);
-            S.sh0 = ldg4(a.pro_sh + c8); S.sh1 = ldg4(a.pro_sh + c8 + 4);
+            const unsigned c8 = (unsigned)(kq * 8) * 4u;
+            S.sc0 = ldb4(rsc, c8, cs); S.sc1 = ldb4(rsc, c8 + 16u, cs);
+            S.sh0 = ldb4(rsh, c8, cs); S.sh1 = ldb4(rsh, c8 + 16u, cs);
         }
         S.ok = live ? okb : 0u;
         const int cbn = cb_ld + 1;
@@ -740,6 +744,8 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
         for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
     const int ncg = g.Cs >> 4;
     const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;
+    const __amdgpu_buffer_rsrc_t rwl = make_rsrc(a.wp, 0xffffffffu), rxl = make_rsrc(a.src, 0xffffffffu);
+    const unsigned wlane = (unsigned)(kq * g.Cd + cob + pl) * 16u;
     if (g.Cs == 16 && g.ntaps == 3) {
         // the 16 -> 16 channel 1-D convs (24 launches per step): all three taps' operands are requested before the first
         // MFMA -- one memory round trip per wave instead of three (these launches are HBM-bound, a wave is ~0.2 us of MFMAs)
@@ -749,13 +755,13 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
         for (int t = 0; t < 3; ++t) {
             const int dh = g.tdh[t], dw = g.tdw[t];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) w3[t][n] = ldg4(wp + (long)t * g.Cd * 16 + n * 64);
+            for (int n = 0; n < NT; ++n) w3[t][n] = ldb4(rwl, wlane + n * 256, (unsigned)(t * g.Cd * 64));
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
                 in3[t][m] = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
                 const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-                x3[t][m] = ldg4(a.src + (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4));
+                x3[t][m] = ldb4(rxl, (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4) * 4u, 0u);
             }
         }
         f32x4 sc = zero4(), sh = zero4();
