@@ -75,7 +75,7 @@ __device__ __forceinline__ void epi_st(__amdgpu_buffer_rsrc_t r, unsigned off, f
         lf_bf16x4 b;
         b[0] = (lf_bf16)v.x; b[1] = (lf_bf16)v.y; b[2] = (lf_bf16)v.z; b[3] = (lf_bf16)v.w;
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, b), r, (int)(off * 2u), 0, 0);
-    } else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, (int)(off * 4u), 0, 0);
+    } else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, (int)(off * 4u), 0, 0);   // (nt and sc0 sc1 hints measured: both -1.2 %)
 }
 __device__ __forceinline__ f32x4 round_bf16(f32x4 v) {
     v.x = (float)(lf_bf16)v.x; v.y = (float)(lf_bf16)v.y; v.z = (float)(lf_bf16)v.z; v.w = (float)(lf_bf16)v.w;
