@@ -357,8 +357,13 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(f32x4 lo, f32x4 hi) {
     return r;
 }
 
-template <int NT, int PROC, bool S16>
-__global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
+// EPIC >= 0: epilogue flags compiled in (as in tapgemm_kernel).  FAST (no prologue, whole 32-channel steps): a padding position
+// holds the out-of-range offset and reads as zero bits, the channel step is a scalar offset -- no per-step VALU work at all on
+// bf16 tensors, where the 16 MFMAs of a step take 256 cycles and every VALU instruction beside them ~13.
+template <int NT, int PROC, bool S16, int EPIC = -1, bool FAST = false>
+__global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
+    static_assert(!FAST || PROC == 0, "FAST: the out-of-range zero must be the operand itself");
+    const int epi = EPIC >= 0 ? EPIC : epi_rt;
     constexpr bool HOISTV = true;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
@@ -399,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
             const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
             const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
             o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff);
+            if constexpr (FAST) o[m] = in ? (o[m] + kq * 8) * (S16 ? 2u : 4u) : LF_OOB;      // bytes, this lane's 8 channels
             okb |= (in ? 1u : 0u) << m;
         }
         tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -406,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
     }
     const int ncb = (g.Cs + 31) >> 5;                       // 32-channel steps per tap
     const int nsteps = g.ntaps * ncb;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp16, 0xffffffffu), rx = make_rsrc(a.src, 0xffffffffu),
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp16, 0xffffffffu),
+                                 rx = make_rsrc(a.src, FAST ? (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * (S16 ? 2 : 4), (long)LF_OOB) : 0xffffffffu),
                                  rsc = make_rsrc(a.pro_sc, 0xffffffffu), rsh = make_rsrc(a.pro_sh, 0xffffffffu);
     const unsigned wlane = (unsigned)(kq * g.Cd + cob + pl) * 16u;      // bytes (8 bf16 per lane and tile)
     const int wstep = g.Cd * 32;                            // bf16 elements per 32-channel step
@@ -421,6 +428,19 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 #pragma unroll
         for (int n = 0; n < NT; ++n) S.w[n] = __builtin_bit_cast(u32x4, ldb4(rw, wlane + n * 256, (unsigned)wofs * 2u));
         const int c8 = min(cb_ld * 32 + kq * 8, g.Cs - 8);  // a partial last step re-reads valid channels (weights are 0)
+        if constexpr (FAST) {
+            const unsigned dead = live ? 0u : LF_OOB;        // a dead step (odd step count) reads zeros
+            const unsigned cs = (unsigned)cb_ld * (S16 ? 64u : 128u);
+            if constexpr (S16) {
+                S.xl[0] = ldb4(rx, o.x | dead, cs); S.xl[1] = ldb4(rx, o.y | dead, cs);
+                S.xl[2] = ldb4(rx, o.z | dead, cs); S.xl[3] = ldb4(rx, o.w | dead, cs);
+            } else {
+                S.xl[0] = ldb4(rx, o.x | dead, cs); S.xh[0] = ldb4(rx, (o.x | dead) + 16u, cs);
+                S.xl[1] = ldb4(rx, o.y | dead, cs); S.xh[1] = ldb4(rx, (o.y | dead) + 16u, cs);
+                S.xl[2] = ldb4(rx, o.z | dead, cs); S.xh[2] = ldb4(rx, (o.z | dead) + 16u, cs);
+                S.xl[3] = ldb4(rx, o.w | dead, cs); S.xh[3] = ldb4(rx, (o.w | dead) + 16u, cs);
+            }
+        } else
         if constexpr (S16) {                                 // buffer-addressed (see ldb4): bf16 elements, 16 bytes = 8 channels
             S.xl[0] = ldb4(rx, (o.x + c8) * 2u, 0u);
             S.xl[1] = ldb4(rx, (o.y + c8) * 2u, 0u);
@@ -447,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
         bf16x8 xb[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const bool in = (S.ok >> m) & 1u;
+            const bool in = FAST || ((S.ok >> m) & 1u);
             if constexpr (S16 && PROC != LF_PRO_BNRELU) {       // raw bf16 bits: mask and use as they are
                 u32x4 r = __builtin_bit_cast(u32x4, S.xl[m]);
                 r.x = in ? r.x : 0u; r.y = in ? r.y : 0u; r.z = in ? r.z : 0u; r.w = in ? r.w : 0u;
@@ -901,6 +921,24 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         else hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0, false>), grid, dim3(256), 0, st, g, a, pro, epi);            \
     } while (0)
         LF_REQUIRE(g.Cs >= 8 && g.s_pix >= g.s_choff + 8, "tapgemm bf16: needs at least 8 source channels");
+#define LF_TG16F(EPIV) hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 0, true, EPIV, true>), grid, dim3(256), 0, st, g, a, pro, epi)
+        const bool fast16 = nt == 4 && a.s16 && pro != LF_PRO_BNRELU && g.Cs % 32 == 0 &&
+                            (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB;
+        if (fast16) {       // the bf16-tensor launches of the network at 64 output channels per workgroup
+            switch (epi) {
+                case 0: LF_TG16F(0); break;
+                case LF_EPI_RELU: LF_TG16F(LF_EPI_RELU); break;
+                case LF_EPI_MASK: LF_TG16F(LF_EPI_MASK); break;
+                case LF_EPI_ADD: LF_TG16F(LF_EPI_ADD); break;
+                case LF_EPI_STATS_SQ: LF_TG16F(LF_EPI_STATS_SQ); break;
+                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TG16F(LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TG16F(LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TG16F(LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                default: LF_TG16F(-1); break;
+            }
+        } else if (nt == 4 && a.s16 && pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) {
+            hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 1, true, LF_EPI_RELU, false>), grid, dim3(256), 0, st, g, a, pro, epi);
+        } else
         switch (nt) {
             case 4: LF_TG16(4); break;
             case 3: LF_TG16(3); break;
@@ -908,6 +946,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
             default: LF_TG16(1); break;
         }
 #undef LF_TG16
+#undef LF_TG16F
         LF_CHECK_LAUNCH("tapgemm_bf16");
         return 0;
     }
