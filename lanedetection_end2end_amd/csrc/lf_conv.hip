@@ -15,7 +15,7 @@
 // 16 MFMAs (512 cycles) is far below what the load path sustains.
 //
 // Kernels in this file: tapgemm_kernel (fp32 matrix cores, operands streamed L2 -> VGPR; the 64- / 128-channel launches of the
-// default path run on the LDS-tiled kernel of lf_convlds.hip instead), tapgemm_lean_kernel (16-channel layers,
+// tapgemm_lean_kernel (16-channel layers,
 // HBM-bound), tapgemm_bf16_kernel (precision modes bf16_mfma / bf16), tapgemm_split_kernel (modes fp32x9 / fp32x6: fp32
 // results from exact 3-way bf16 splits on the bf16 matrix cores), tapwgrad_kernel / tapwgrad16_kernel / tapwgrad_split_kernel
 // (weight gradients, split-K over pixels), the split-K reductions (one per weight gradient, or batched per backward pass)
@@ -198,6 +198,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
     if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
     const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
 
+    // (the wave-uniform row arithmetic of tapgemm_lean_kernel saves ~150 prologue instructions here too, but costs two registers:
+    // 170 instead of 168 in the MASK / ADD variants, i.e. two waves per SIMD instead of three)
     int pn[MT], pi[MT], pj[MT];
     bool pv[MT];
 #pragma unroll
@@ -735,18 +737,30 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
 // Lean variant for 16-output-channel launches (the 128x256 stage, ~3 % of the FLOPs): these are HBM-bound
 // (0.75*C = 12 FLOP/B), so the goal is bytes in flight, not MFMA issue: no operand ring, few registers,
 // many waves per SIMD; the compiler is free to hoist the next step's loads.
-template <int NT>
-__global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
-    constexpr bool S16 = false, HOISTV = false;      // the fp32 loop leaves no registers to hold the per-channel vectors
+// A wave of these launches is 48 MFMAs between a prologue and an epilogue of VALU work, 16 waves per SIMD in sequence: the
+// index arithmetic IS the kernel.  PROC / EPIC compiled in (EPIC = -1: run-time flags); with Wl % 64 == 0 a wave's 64 pixels lie
+// in one image row, so (image, row, first column) are wave-uniform: two divisions instead of eight, scalar row terms.
+template <int NT, int PROC = -1, int EPIC = -1>
+__global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g, const LfTapArgs a, const int pro_rt, const int epi_rt) {
+    constexpr bool S16 = false, HOISTV = EPIC >= 0;
+    const int pro = PROC >= 0 ? PROC : pro_rt, epi = EPIC >= 0 ? EPIC : epi_rt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
     const int cob = blockIdx.y * NT * 16;
     unsigned bx = blockIdx.x;
     if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
-    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
+    const unsigned tile0 = (bx * WG_WAVES + __builtin_amdgcn_readfirstlane(wave)) * (MT * 16);
     int pn[MT], pi[MT], pj[MT];
     bool pv[MT];
+    const bool onerow = (g.Wl & 63) == 0;
+    if (onerow) {
+        const unsigned q = tile0 < npix ? tile0 : 0u;                 // wave-uniform
+        const unsigned r = q / (unsigned)g.Wl;
+        const int j0 = (int)(q - r * (unsigned)g.Wl), n0 = (int)(r / (unsigned)g.Hl), i0 = (int)(r - (unsigned)n0 * (unsigned)g.Hl);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { pv[m] = tile0 < npix; pn[m] = n0; pi[m] = i0; pj[m] = j0 + m * 16 + pl; }
+    } else {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const unsigned p = tile0 + m * 16 + pl;
@@ -757,6 +771,7 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
         pn[m] = (int)(r / (unsigned)g.Hl);
         pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
     }
+    }
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -764,7 +779,9 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
         for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
     const int ncg = g.Cs >> 4;
     const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;
-    const __amdgpu_buffer_rsrc_t rwl = make_rsrc(a.wp, 0xffffffffu), rxl = make_rsrc(a.src, 0xffffffffu);
+    // x: num_records = the tensor, so that LF_OOB reads as 0.0f (padding without masks when there is no prologue)
+    const __amdgpu_buffer_rsrc_t rwl = make_rsrc(a.wp, 0xffffffffu),
+                                 rxl = make_rsrc(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 4, (long)LF_OOB));
     const unsigned wlane = (unsigned)(kq * g.Cd + cob + pl) * 16u;
     if (g.Cs == 16 && g.ntaps == 3) {
         // the 16 -> 16 channel 1-D convs (24 launches per step): all three taps' operands are requested before the first
@@ -781,19 +798,22 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
                 const int sy = pi[m] * g.ssh + dh, sx = pj[m] * g.ssw + dw;
                 in3[t][m] = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
                 const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
-                x3[t][m] = ldb4(rxl, (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4) * 4u, 0u);
+                const unsigned off = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff + kq * 4) * 4u;
+                x3[t][m] = ldb4(rxl, (PROC == 0 && !in3[t][m]) ? LF_OOB : off, 0u);
             }
         }
         f32x4 sc = zero4(), sh = zero4();
         if (pro == LF_PRO_BNRELU) { sc = ldg4(a.pro_sc + kq * 4); sh = ldg4(a.pro_sh + kq * 4); }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
+            if constexpr (PROC != 0) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x4 v = x3[t][m];
-                if (pro == LF_PRO_BNRELU) v = max0(v * sc + sh);
-                v.x = in3[t][m] ? v.x : 0.f; v.y = in3[t][m] ? v.y : 0.f; v.z = in3[t][m] ? v.z : 0.f; v.w = in3[t][m] ? v.w : 0.f;
-                x3[t][m] = v;
+                for (int m = 0; m < MT; ++m) {
+                    f32x4 v = x3[t][m];
+                    if (pro == LF_PRO_BNRELU) v = max0(v * sc + sh);
+                    v.x = in3[t][m] ? v.x : 0.f; v.y = in3[t][m] ? v.y : 0.f; v.z = in3[t][m] ? v.z : 0.f; v.w = in3[t][m] ? v.w : 0.f;
+                    x3[t][m] = v;
+                }
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
@@ -969,8 +989,23 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         case 3: LF_TG(3); break;
         case 2: LF_TG(2); break;
         default:
-            if (!a.dbg) hipLaunchKernelGGL(tapgemm_lean_kernel<1>, grid, dim3(256), 0, st, g, a, pro, epi);
-            else LF_TG(1);
+            if (!a.dbg) {
+#define LF_LEAN(PROV, EPIV) hipLaunchKernelGGL((tapgemm_lean_kernel<1, PROV, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi)
+                if (pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) LF_LEAN(1, LF_EPI_RELU);
+                else if (pro == LF_PRO_BNRELU) LF_LEAN(1, -1);
+                else switch (epi) {
+                    case 0: LF_LEAN(0, 0); break;
+                    case LF_EPI_RELU: LF_LEAN(0, LF_EPI_RELU); break;
+                    case LF_EPI_MASK: LF_LEAN(0, LF_EPI_MASK); break;
+                    case LF_EPI_ADD: LF_LEAN(0, LF_EPI_ADD); break;
+                    case LF_EPI_STATS_SQ: LF_LEAN(0, LF_EPI_STATS_SQ); break;
+                    case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_LEAN(0, LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                    case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_LEAN(0, LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                    case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_LEAN(0, LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                    default: LF_LEAN(0, -1); break;
+                }
+#undef LF_LEAN
+            } else LF_TG(1);
             break;
     }
 #undef LF_TG
