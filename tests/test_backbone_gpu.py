@@ -645,6 +645,48 @@ def test_bf16_tensor_mode_kernel_parity():
         lib.lf_debug_set_ops_precision(0)
 
 
+def test_fp32_kernel_parity_every_addressing_path():
+    """The fp32 conv kernels (forward + ReLU, data gradient + ReLU mask, weight / bias gradient) against fp64 torch on the shapes
+    that exercise every addressing path of the buffer-addressed kernels: interior / edge / fully-padded pixel groups of the
+    weight gradient (dilations up to the image size), 16-pixel and 4-pixel groups (W % 16 != 0), partial pixel tiles and images
+    narrower than a wave's 64 pixels (per-lane row arithmetic) next to W % 64 == 0 (wave-uniform row arithmetic), the 16-channel
+    kernel in both, batch boundaries inside a wave's pixel range.  Padding comes from out-of-range buffer reads, so a wrong offset
+    would read a NEIGHBOURING image row or another image instead of zero: the inputs have no zeros to hide that."""
+    import torch.nn.functional as F
+    from lanedetection_end2end_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    shapes = ((128, 16, 32, 0, 4), (128, 16, 32, 1, 16), (128, 32, 64, 0, 16), (128, 32, 64, 1, 8), (64, 24, 40, 0, 1),
+              (64, 24, 40, 1, 2), (64, 6, 20, 1, 2), (64, 64, 128, 1, 1), (128, 3, 12, 0, 1), (16, 32, 64, 1, 1), (16, 32, 64, 0, 2),
+              (16, 8, 24, 0, 2), (16, 16, 128, 1, 1))
+    for (C, H, W, axis, d) in shapes:
+        N = 3
+        torch.manual_seed(C + 7 * axis + d)
+        x = torch.randn(N, H, W, C, device="cuda") + 0.25
+        gy = torch.randn(N, H, W, C, device="cuda") - 0.25
+        w = torch.randn(C, C, 3, device="cuda") * (2.0 / (3 * C)) ** 0.5
+        b = torch.randn(C, device="cuda")
+        y, gx = torch.empty_like(x), torch.empty_like(x)
+        gw, gb = torch.empty_like(w), torch.empty_like(b)
+        scratch = torch.full((lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096,), float("nan"), device="cuda")
+        w4 = w.view(C, C, 3, 1) if axis == 0 else w.view(C, C, 1, 3)
+        pad, dil = ((d, 0), (d, 1)) if axis == 0 else ((0, d), (1, d))
+        xn = x.double().permute(0, 3, 1, 2).contiguous()
+        gn = gy.double().permute(0, 3, 1, 2).contiguous()
+        ref = torch.relu(F.conv2d(xn, w4.double(), b.double(), padding=pad, dilation=dil))
+        _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 1, P(scratch), st), "fwd")
+        e1 = relerr(y.permute(0, 3, 1, 2).cpu(), ref.cpu())
+        gref = torch.nn.grad.conv2d_input(xn.shape, w4.double(), gn, padding=pad, dilation=dil) * (xn > 0)
+        _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), P(x), P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
+        e2 = relerr(gx.permute(0, 3, 1, 2).cpu(), gref.cpu())
+        _lib.check(lib.lf_conv1d_bwd_weight(P(x), P(gy), P(gw), P(gb), N, H, W, C, axis, d, P(scratch), st), "wgrad")
+        wref = torch.nn.grad.conv2d_weight(xn, w4.shape, gn, padding=pad, dilation=dil)
+        e3, e4 = relerr(gw.view_as(w4).cpu(), wref.cpu()), relerr(gb.cpu(), gn.sum((0, 2, 3)).cpu())
+        print("fp32 C=%3d %2dx%3d axis %d dil %2d: fwd %.1e dgrad %.1e wgrad %.1e bias %.1e" % (C, H, W, axis, d, e1, e2, e3, e4))
+        assert e1 < 3e-6 and e2 < 3e-6 and e3 < 3e-6 and e4 < 3e-6, (C, H, W, axis, d)
+
+
 def test_split_mode_kernel_parity():
     """Precision modes "fp32x9" / "fp32x6": fp32 tensors, fp32 accumulation, every product formed on the bf16 matrix
     cores from exact 3-way splits of both operands (9 = all partial products, 6 = those above 2^-24).  Contract: as close
