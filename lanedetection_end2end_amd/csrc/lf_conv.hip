@@ -180,7 +180,9 @@ constexpr size_t LF_TAP_LDS_PER_TAP = (size_t)WG_WAVES * 64 * (sizeof(uint4) + s
 // the runtime-flag form (EPIC = -1) cost 9 us of a 30 us workgroup life -- and the slot it occupies cannot be refilled.
 // (A one-operand-set form at <= 128 registers, four workgroups per CU so that the 4096 waves of a 64-channel launch run as ONE
 // round, was measured and dropped: 72 vs 68 us -- three waves per SIMD of this form already overlap rounds.)
-template <int NT, int PROC, int EPIC = -1>
+// ROW1 (Wl % 64 == 0): a wave's 64 pixels lie in one image row, so (image, row, first column) are wave-uniform and live in
+// scalar registers: two divisions instead of eight in the prologue and ~10 vector registers less.
+template <int NT, int PROC, int EPIC = -1, bool ROW1 = false>
 __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
     constexpr bool S16 = false, HOISTV = EPIC >= 0;  // compiled-in flags: the per-channel vectors are loaded once, after the loop
@@ -196,21 +198,29 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
     const int cob = blockIdx.y * NT * 16;
     unsigned bx = blockIdx.x;
     if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
-    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
+    const unsigned tile0 = (bx * WG_WAVES + (ROW1 ? __builtin_amdgcn_readfirstlane(wave) : wave)) * (MT * 16);
 
-    // (the wave-uniform row arithmetic of tapgemm_lean_kernel saves ~150 prologue instructions here too, but costs two registers:
-    // 170 instead of 168 in the MASK / ADD variants, i.e. two waves per SIMD instead of three)
     int pn[MT], pi[MT], pj[MT];
     bool pv[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {   // 32-bit divisions: the 64-bit ones expand to ~100 instructions each
-        const unsigned p = tile0 + m * 16 + pl;
-        pv[m] = p < npix;
-        const unsigned q = pv[m] ? p : 0u;
+    if constexpr (ROW1) {
+        const unsigned q = tile0 < npix ? tile0 : 0u;
         const unsigned r = q / (unsigned)g.Wl;
-        pj[m] = (int)(q - r * (unsigned)g.Wl);
-        pn[m] = (int)(r / (unsigned)g.Hl);
-        pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
+        const int j0 = __builtin_amdgcn_readfirstlane((int)(q - r * (unsigned)g.Wl));
+        const int n0 = __builtin_amdgcn_readfirstlane((int)(r / (unsigned)g.Hl));
+        const int i0 = __builtin_amdgcn_readfirstlane((int)r) - n0 * g.Hl;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { pv[m] = tile0 < npix; pn[m] = n0; pi[m] = i0; pj[m] = j0 + m * 16 + pl; }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {   // 32-bit divisions: the 64-bit ones expand to ~100 instructions each
+            const unsigned p = tile0 + m * 16 + pl;
+            pv[m] = p < npix;
+            const unsigned q = pv[m] ? p : 0u;
+            const unsigned r = q / (unsigned)g.Wl;
+            pj[m] = (int)(q - r * (unsigned)g.Wl);
+            pn[m] = (int)(r / (unsigned)g.Hl);
+            pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
+        }
     }
 
     f32x4 acc[NT][MT];
@@ -913,7 +923,11 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), tap_lds, st, g, a, pro, epi);  \
         else hipLaunchKernelGGL((tapgemm_kernel<NTV, 0>), grid, dim3(256), tap_lds, st, g, a, pro, epi);                       \
     } while (0)
-#define LF_TG4(PROV, EPIV) hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV>), grid, dim3(256), tap_lds, st, g, a, pro, epi)
+#define LF_TG4(PROV, EPIV)                                                                                               \
+    do {                                                                                                                 \
+        if ((g.Wl & 63) == 0) hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV, true>), grid, dim3(256), tap_lds, st, g, a, pro, epi);  \
+        else hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV, false>), grid, dim3(256), tap_lds, st, g, a, pro, epi);    \
+    } while (0)
     const size_t tap_lds = LF_TAP_LDS_PER_TAP * g.ntaps;
     LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
     if (a.split && a.wp48 && !a.wp16 && lf_tapgemm_split_ok(g)) {
