@@ -450,9 +450,9 @@ def main():
                                             "tflops": round(fam[i]["flops"] / max(fam[i]["ms"], 1e-9) / 1e9, 2)}
                                  for i in range(2)},
                     "whole_step_frac_of_conv_roofline": round(ips * wl["flop"] / world / PEAK_FP32_MFMA, 4),
-                    # at 100 % matrix duty (tools/mfma_rate.hip) the chip clocks down to 136 TFLOP/s; during this workload
-                    # rocm-smi shows sclk 2.39 GHz / 1.09 kW, i.e. the datasheet peak above is the right roof
-                    "peak_at_full_matrix_duty": 136.0}
+                    # measured on this chip (tools/mfma_sustain.hip, profiles/r2_mfma_sustain.txt): a bare fp32 MFMA stream holds
+                    # 156 TFLOP/s from 10 ms to 1.7 s, i.e. the datasheet peak above is the roof the kernels can be held to
+                    "sustained_mfma_measured": 156.0}
         metric = "images/sec fwd+bwd, 256x512 2-lane bs32" if a.workload == "bev" else \
             "images/sec fwd+bwd, %s" % a.workload
         out = {"metric": metric, "value": round(ips, 2), "unit": "images/sec",
