@@ -560,9 +560,10 @@ __device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& h
 // the idle LDS buffer during A's split phase (B is reading W[s-1]'s successor W[s] from the other one).
 #undef LF_EPI_GROUPS
 #define LF_EPI_GROUPS 2
-template <int NT, int PROC, int TERMS>
-__global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi) {
-    constexpr bool S16 = false, HOISTV = false;
+template <int NT, int PROC, int TERMS, int EPIC = -1>
+__global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
+    const int epi = EPIC >= 0 ? EPIC : epi_rt;      // compiled-in epilogue flags, as in tapgemm_kernel
+    constexpr bool S16 = false, HOISTV = EPIC >= 0;
     constexpr int WAVES = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
@@ -936,8 +937,21 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         b.wp16 = a.wp48;
         const dim3 grid2((unsigned)(npix / (2 * PIX_PER_WG)), g.Cd / 64);     // 512-pixel workgroups (two 4-wave groups)
         if (a.split == 9) {
-            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 9>), grid2, dim3(512), 0, st, g, b, pro, epi);
-            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 9>), grid2, dim3(512), 0, st, g, b, pro, epi);
+#define LF_TS9(PROV, EPIV) hipLaunchKernelGGL((tapgemm_split_kernel<4, PROV, 9, EPIV>), grid2, dim3(512), 0, st, g, b, pro, epi)
+            if (pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) LF_TS9(1, LF_EPI_RELU);
+            else if (pro == LF_PRO_BNRELU) LF_TS9(1, -1);
+            else switch (epi) {
+                case 0: LF_TS9(0, 0); break;
+                case LF_EPI_RELU: LF_TS9(0, LF_EPI_RELU); break;
+                case LF_EPI_MASK: LF_TS9(0, LF_EPI_MASK); break;
+                case LF_EPI_ADD: LF_TS9(0, LF_EPI_ADD); break;
+                case LF_EPI_STATS_SQ: LF_TS9(0, LF_EPI_STATS_SQ); break;
+                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TS9(0, LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TS9(0, LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TS9(0, LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                default: LF_TS9(0, -1); break;
+            }
+#undef LF_TS9
         } else {
             if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 6>), grid2, dim3(512), 0, st, g, b, pro, epi);
             else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 6>), grid2, dim3(512), 0, st, g, b, pro, epi);
