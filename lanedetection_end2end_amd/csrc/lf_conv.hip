@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         }
         // (each lane reads back only what it wrote: no barrier needed)
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 4, (long)LF_OOB));
-        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp, 0xffffffffu);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp, 0xffffffffu), rsc = make_rsrc(a.pro_sc, 0xffffffffu), rsh = make_rsrc(a.pro_sh, 0xffffffffu);
         const unsigned wlane = (unsigned)(kq * g.Cd + cob + pl) * 16u;      // bytes
         const int wstep = g.Cd * 64;                       // bytes per 16-channel step
         const int ntaps = g.ntaps;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
             S.x[1] = ldb4(rx, o.y, c16);
             S.x[2] = ldb4(rx, o.z, c16);
             S.x[3] = ldb4(rx, o.w, c16);
-            if constexpr (PROC == LF_PRO_BNRELU) { S.sc = ldg4(a.pro_sc + cg_ld * 16 + kq * 4); S.sh = ldg4(a.pro_sh + cg_ld * 16 + kq * 4); }
+            if constexpr (PROC == LF_PRO_BNRELU) { S.sc = ldb4(rsc, (unsigned)kq * 16u, c16); S.sh = ldb4(rsh, (unsigned)kq * 16u, c16); }
             S.ok = live ? okb : 0u;
             // advance (scalar selects, no branches); a dead step re-reads the last live operands
             const int cgn = cg_ld + 1;
@@ -1297,6 +1297,8 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
         }
     };
 
+    // (A third operand set -- loads two groups ahead -- spills: the three inlined loop bodies push the accumulators to scratch,
+    // 185 us instead of 62.)
     WStep A, B;
     auto run = [&](auto BIAS_c, auto PRO_c) __attribute__((always_inline)) {
         auto step = [&](const WStep& S) __attribute__((always_inline)) { compute(S, BIAS_c, PRO_c); };
