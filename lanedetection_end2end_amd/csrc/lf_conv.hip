@@ -1068,10 +1068,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // BFM (bf16 tensors, 64-channel blocks on both sides): the four K=4 fp32 MFMAs of an iteration's four pixel
 // sub-steps become ONE v_mfma_f32_16x16x16_bf16 per tile -- a lane's four pixels (p+kq, +4, +8, +12) are exactly its
 // four k of the K=16 step -- with the operands assembled from the raw 8-byte loads by v_perm_b32 (no widening).
-template <bool XV, bool GV, int XT, int GT, int U, bool S16, bool BFM = false>
-__global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro,
+// PROT: 0 / 1 = the BN+ReLU prologue flag compiled in (the fp32 64-channel-block launches of the network), -1 = run-time
+template <bool XV, bool GV, int XT, int GT, int U, bool S16, bool BFM = false, int PROT = -1>
+__global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro_rt,
                                                       const long pps, const int write_bias, const int gxs) {
     constexpr int XTiles = XV ? 4 : XT, GTiles = GV ? 4 : GT;
+    const int pro = PROT >= 0 ? (PROT ? LF_PRO_BNRELU : LF_PRO_NONE) : pro_rt;
     constexpr int XB = XTiles * 16, GB = GTiles * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
@@ -1320,9 +1322,14 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
         }
     };
     if (niter > 0) {
-        const bool prologue = pro == LF_PRO_BNRELU;
-        if (need_bias) { if (prologue) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
-        else { if (prologue) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
+        if constexpr (PROT >= 0) {
+            if (need_bias) run(std::true_type{}, std::integral_constant<bool, PROT == 1>{});
+            else run(std::false_type{}, std::integral_constant<bool, PROT == 1>{});
+        } else {
+            const bool prologue = pro == LF_PRO_BNRELU;
+            if (need_bias) { if (prologue) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+            else { if (prologue) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
+        }
     }
     if (a.dbg) { asm volatile("" ::"v"(acc[0][0][0])); tstamp[2] = __builtin_amdgcn_s_memrealtime(); }
     // ---- reduce the 4 waves of the workgroup through LDS, wave 0 writes one partial row
@@ -1774,6 +1781,8 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
         if (a.s16 && c.u == 4 && XV && GV) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true, (XV && GV)>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
         else if (a.s16 && c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
         else if (a.s16) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);   \
+        else if (c.u == 4 && XV && GV && pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, false, false, (XV && GV) ? 1 : -1>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
+        else if (c.u == 4 && XV && GV) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, false, false, (XV && GV) ? 0 : -1>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
         else if (c.u == 4) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, false>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
         else hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 1, false>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);  \
     } while (0)
