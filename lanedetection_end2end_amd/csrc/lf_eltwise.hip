@@ -40,43 +40,58 @@ __device__ __forceinline__ void block_reduce_quads(f32x4& a1, f32x4& a2, int Q, 
 
 struct StatParts { LfStatPart p[2]; int n; };
 
-__global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float* __restrict__ rmean, float* __restrict__ rvar,
-                                                             float momentum, float eps, int training,
-                                                             float* __restrict__ scale, float* __restrict__ shift,
-                                                             float* __restrict__ asc, float* __restrict__ ash) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;   // 16 channels x 64 row groups
-    __shared__ double sm[64][16][2];
-    double s1 = 0.0, s2 = 0.0;
-    if (training && c < C) {
-        for (int k = 0; k < sp.n; ++k) {
-            const LfStatPart& q = sp.p[k];
-            const int cc = c - q.ch_off;
-            if (cc < 0 || cc >= q.C) continue;
-            int r = rg;
-            for (; r + 64 < q.nrows; r += 128) {
-                const float a0 = q.rows[((long)r * 2 + 0) * q.C + cc], a1 = q.rows[((long)r * 2 + 1) * q.C + cc];
-                const float b0 = q.rows[((long)(r + 64) * 2 + 0) * q.C + cc], b1 = q.rows[((long)(r + 64) * 2 + 1) * q.C + cc];
-                s1 += (double)a0 + (double)b0;
-                s2 += (double)a1 + (double)b1;
-            }
-            for (; r < q.nrows; r += 64) {
-                s1 += (double)q.rows[((long)r * 2 + 0) * q.C + cc];
-                s2 += (double)q.rows[((long)r * 2 + 1) * q.C + cc];
-            }
+// Column sums of the partial rows for the 4 channels c0..c0+3 by one 256-thread block: thread t takes rows t, t + 256, ... as
+// 16-byte loads (independent: all in flight at once), fp64 accumulation, wave shuffle + 4-slot LDS combine, fixed order.
+// (The first version -- 16 channels x 64 row groups per 1024-thread block, scalar loads, a 64-step serial combine -- ran on 4-8
+// workgroups: 7 us for a kernel that is pure latency.)
+__device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, double (&s1)[4], double (&s2)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+    for (int k = 0; k < sp.n; ++k) {
+        const LfStatPart& q = sp.p[k];
+        const int cc = c0 - q.ch_off;
+        if (cc < 0 || cc >= q.C) continue;
+        for (int r = threadIdx.x; r < q.nrows; r += 256) {
+            const f32x4 a = ld4(q.rows + ((long)r * 2 + 0) * q.C + cc), b = ld4(q.rows + ((long)r * 2 + 1) * q.C + cc);
+            s1[0] += (double)a.x; s1[1] += (double)a.y; s1[2] += (double)a.z; s1[3] += (double)a.w;
+            s2[0] += (double)b.x; s2[1] += (double)b.y; s2[2] += (double)b.z; s2[3] += (double)b.w;
         }
     }
-    sm[rg][threadIdx.x & 15][0] = s1;
-    sm[rg][threadIdx.x & 15][1] = s2;
+    __shared__ double sm[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sm[w][i] = s1[i]; sm[w][4 + i] = s2[i]; }
+    }
     __syncthreads();
-    if (rg == 0 && c < C) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s1[i] = (sm[0][i] + sm[1][i]) + (sm[2][i] + sm[3][i]); s2[i] = (sm[0][4 + i] + sm[1][4 + i]) + (sm[2][4 + i] + sm[3][4 + i]); }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ rmean, float* __restrict__ rvar,
+                                                            float momentum, float eps, int training,
+                                                            float* __restrict__ scale, float* __restrict__ shift,
+                                                            float* __restrict__ asc, float* __restrict__ ash) {
+    const int c0 = blockIdx.x * 4;
+    double s1[4], s2[4];
+    if (training) stat_rows_sum4(sp, c0, s1, s2);
+    const int c = c0 + (int)threadIdx.x;
+    if (threadIdx.x < 4 && c < C) {
         double mean, var;
         if (training) {
-            s1 = 0.0; s2 = 0.0;
-            for (int r = 0; r < 64; ++r) { s1 += sm[r][threadIdx.x][0]; s2 += sm[r][threadIdx.x][1]; }
-            mean = s1 / count;
-            var = s2 / count - mean * mean;
+            double t1 = s1[0], t2 = s2[0];          // (select chain: no dynamic register indexing)
+            if (threadIdx.x == 1) { t1 = s1[1]; t2 = s2[1]; }
+            if (threadIdx.x == 2) { t1 = s1[2]; t2 = s2[2]; }
+            if (threadIdx.x == 3) { t1 = s1[3]; t2 = s2[3]; }
+            mean = t1 / count;
+            var = t2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
             rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mean);
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -143,40 +158,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // terms of the data gradient vanish (c1 = c2 = 0); the parameter gradients are the same sums.
 // (mean_scale = 1 / count in training mode, 0 in eval mode -- decided on the host: a run-time `training ? :` in here made hipcc
 // unroll the final sum into 128 registers + 564 bytes of scratch, 19 us per launch instead of 6)
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(StatParts sp, int C, double mean_scale, float* __restrict__ c1,
-                                                             float* __restrict__ c2, float* __restrict__ ggamma,
-                                                             float* __restrict__ gbeta) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
-    __shared__ double sm[64][16][2];
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        for (int k = 0; k < sp.n; ++k) {
-            const LfStatPart& q = sp.p[k];
-            const int cc = c - q.ch_off;
-            if (cc < 0 || cc >= q.C) continue;
-            int r = rg;
-            for (; r + 64 < q.nrows; r += 128) {
-                const float a0 = q.rows[((long)r * 2 + 0) * q.C + cc], a1 = q.rows[((long)r * 2 + 1) * q.C + cc];
-                const float b0 = q.rows[((long)(r + 64) * 2 + 0) * q.C + cc], b1 = q.rows[((long)(r + 64) * 2 + 1) * q.C + cc];
-                s1 += (double)a0 + (double)b0;
-                s2 += (double)a1 + (double)b1;
-            }
-            for (; r < q.nrows; r += 64) {
-                s1 += (double)q.rows[((long)r * 2 + 0) * q.C + cc];
-                s2 += (double)q.rows[((long)r * 2 + 1) * q.C + cc];
-            }
-        }
-    }
-    sm[rg][threadIdx.x & 15][0] = s1;
-    sm[rg][threadIdx.x & 15][1] = s2;
-    __syncthreads();
-    if (rg == 0 && c < C) {
-        s1 = 0.0; s2 = 0.0;
-        for (int r = 0; r < 64; ++r) { s1 += sm[r][threadIdx.x][0]; s2 += sm[r][threadIdx.x][1]; }
-        c1[c] = (float)(s1 * mean_scale);
-        c2[c] = (float)(s2 * mean_scale);
-        ggamma[c] = (float)s2;
-        gbeta[c] = (float)s1;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int C, double mean_scale, float* __restrict__ c1,
+                                                            float* __restrict__ c2, float* __restrict__ ggamma,
+                                                            float* __restrict__ gbeta) {
+    const int c0 = blockIdx.x * 4;
+    double s1[4], s2[4];
+    stat_rows_sum4(sp, c0, s1, s2);
+    const int c = c0 + (int)threadIdx.x;
+    if (threadIdx.x < 4 && c < C) {
+        double t1 = s1[0], t2 = s2[0];
+        if (threadIdx.x == 1) { t1 = s1[1]; t2 = s2[1]; }
+        if (threadIdx.x == 2) { t1 = s1[2]; t2 = s2[2]; }
+        if (threadIdx.x == 3) { t1 = s1[3]; t2 = s2[3]; }
+        c1[c] = (float)(t1 * mean_scale);
+        c2[c] = (float)(t2 * mean_scale);
+        ggamma[c] = (float)t2;
+        gbeta[c] = (float)t1;
     }
 }
 
@@ -549,7 +546,8 @@ int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count,
     StatParts sp;
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(lf_cdiv(C, 16)), dim3(1024), 0, st, sp, C, count, gamma, beta,
+    for (int i = 0; i < nparts; ++i) LF_REQUIRE(parts[i].C % 4 == 0 && parts[i].ch_off % 4 == 0, "bn_finalize: channel ranges must be multiples of 4");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(lf_cdiv(C, 4)), dim3(256), 0, st, sp, C, count, gamma, beta,
                        running_mean, running_var, momentum, eps, training, scale, shift, asc, ash);
     LF_CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
@@ -586,7 +584,8 @@ int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count,
     StatParts sp;
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 16)), dim3(1024), 0, st, sp, C, training ? 1.0 / count : 0.0, c1, c2,
+    for (int i = 0; i < nparts; ++i) LF_REQUIRE(parts[i].C % 4 == 0 && parts[i].ch_off % 4 == 0, "bn_bwd_finalize: channel ranges must be multiples of 4");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 4)), dim3(256), 0, st, sp, C, training ? 1.0 / count : 0.0, c1, c2,
                        ggamma, gbeta);
     LF_CHECK_LAUNCH("bn_bwd_finalize");
     return 0;
