@@ -47,9 +47,14 @@ __device__ __forceinline__ f32x4 ldb4(__amdgpu_buffer_rsrc_t r, unsigned voff, u
 }
 constexpr unsigned LF_OOB = 0xffff0000u;      // byte offset beyond every tensor the launcher admits (< 4 GiB - 64 KiB)
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+// ReLU as a signed-integer maximum of the bit patterns (negative floats are negative integers): ONE v_max_i32 per element;
+// fmaxf compiles to a canonicalising v_max_f32 v, v, v followed by the v_max_f32 with 0 -- twice the VALU work in the BN+ReLU
+// operand prologue, where every VALU instruction issues beside the partner wave's MFMA stream
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 max0(f32x4 v) {
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    return v;
+    i32x4 b = __builtin_bit_cast(i32x4, v);
+    b.x = b.x > 0 ? b.x : 0; b.y = b.y > 0 ? b.y : 0; b.z = b.z > 0 ? b.z : 0; b.w = b.w > 0 ? b.w : 0;
+    return __builtin_bit_cast(f32x4, b);
 }
 __device__ __forceinline__ f32x4 keep_pos(f32x4 v, f32x4 m) {
     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
@@ -97,55 +102,69 @@ __device__ __forceinline__ float sum16(float v) {
 }
 
 #define LF_EPI_GROUPS 1      /* 4-wave groups per workgroup; the 512-thread split kernel redefines it */
+#define LF_EPI_ONE_TILE false  /* tapgemm_kernel: true for the per-lane-row form of the three-tensor epilogue (one register short) */
 #define LF_TAPGEMM_EPILOGUE \
-    /* Pixel-tile outer, channel-tile inner: the NT loads of one operand tensor issued back to back cover one pixel's  \
-     * contiguous NT*16-channel run, so every cache line is touched once while it is hot (the channel-tile-outer order \
-     * revisited each line NT times with the whole grid's working set in between: 4x the HBM reads with bf16 tensors). */ \
+    /* Pixel-tile outer, channel-tile inner: the loads of one operand tensor issued back to back cover one pixel's     \
+     * contiguous channel run, so every cache line is touched once while it is hot (the channel-tile-outer order        \
+     * revisited each line NT times with the whole grid's working set in between: 4x the HBM reads with bf16 tensors). \
+     * The channel tiles of a pixel tile go in chunks of NC = 2 (one 128-byte line of fp32): with all NT tiles' operand \
+     * loads in flight at once the three-tensor epilogues (ADD + MASK + BN-backward sums) needed 270+ registers and     \
+     * spilled 13-29 of them to scratch.  NOBIAS: data-gradient epilogues (compiled-in flags) carry no bias vector. */  \
     const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0; \
+    constexpr bool NOBIAS = EPIC >= 0 && (EPIC & (LF_EPI_MASK | LF_EPI_ADD | LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) != 0; \
+    constexpr int NC = (NT % 2 == 0 && !LF_EPI_ONE_TILE) ? 2 : 1; \
+    /* MASKBN + STATS_XHAT together want four per-channel vectors per tile: the mask's two are re-read (L1) instead of held */ \
+    constexpr bool HOISTM = HOISTV && !(EPIC >= 0 && (EPIC & LF_EPI_MASKBN) && (EPIC & LF_EPI_STATS_XHAT)); \
     __builtin_amdgcn_s_setprio(3);   /* ahead of the partner wave's MFMA stream: the sooner this wave retires, the sooner its slot refills */ \
     const __amdgpu_buffer_rsrc_t r_dst = make_rsrc(a.dst, 0xffffffffu), r_add = make_rsrc(a.add_src, 0xffffffffu), \
                                  r_msk = make_rsrc(a.mask_src, 0xffffffffu), r_aux = make_rsrc(a.aux, 0xffffffffu), \
                                  r_bias = make_rsrc(a.bias, 0xffffffffu), r_msc = make_rsrc(a.msc, 0xffffffffu), \
                                  r_msh = make_rsrc(a.msh, 0xffffffffu), r_asc = make_rsrc(a.asc, 0xffffffffu), \
                                  r_ash = make_rsrc(a.ash, 0xffffffffu), r_dm = make_rsrc(a.dm, 0xffffffffu); \
-    f32x4 s1[NT], s2[NT], bs[NT], hv[HOISTV ? NT : 1][4]; \
+    f32x4 s1[NT], s2[NT], bs[NOBIAS ? 1 : NT], hv[HOISTV ? NT : 1][4]; \
 _Pragma("unroll") \
     for (int n = 0; n < NT; ++n) { \
         const int co = cob + n * 16 + kq * 4; \
         s1[n] = zero4(); s2[n] = zero4(); \
-        bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4(); \
+        if constexpr (!NOBIAS) bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4(); \
         if (HOISTV) { \
-            if (epi & LF_EPI_MASKBN) { hv[n][0] = ldb4(r_msc, co * 4u, 0u); hv[n][1] = ldb4(r_msh, co * 4u, 0u); } \
+            if (HOISTM && (epi & LF_EPI_MASKBN)) { hv[n][0] = ldb4(r_msc, co * 4u, 0u); hv[n][1] = ldb4(r_msh, co * 4u, 0u); } \
             if (epi & LF_EPI_STATS_XHAT) { hv[n][2] = ldb4(r_asc, co * 4u, 0u); hv[n][3] = ldb4(r_ash, co * 4u, 0u); } \
         } \
     } \
 _Pragma("unroll") \
     for (int m = 0; m < MT; ++m) { \
         const unsigned dbase = (unsigned)(((pn[m] * g.Hd + pi[m] * g.dsh + g.dah) * g.Wd + pj[m] * g.dsw + g.daw) * g.d_pix + g.d_choff + cob + kq * 4); \
-        f32x4 la[NT], lm[NT], lx[NT], ld[NT]; \
 _Pragma("unroll") \
-        for (int n = 0; n < NT; ++n) { \
-            if (epi & LF_EPI_ADD) la[n] = epi_ld<S16>(r_add, dbase + n * 16); \
-            if (epi & LF_EPI_MASK) lm[n] = epi_ld<S16>(r_msk, dbase + n * 16); \
-            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[n] = epi_ld<S16>(r_aux, dbase + n * 16); \
-            if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[n] = ldb4(r_dm, (unsigned)(pn[m] * g.Cd + cob + n * 16 + kq * 4) * 4u, 0u); \
+        for (int n0 = 0; n0 < NT; n0 += NC) { \
+        f32x4 la[NC], lm[NC], lx[NC], ld[NC]; \
+_Pragma("unroll") \
+        for (int j = 0; j < NC; ++j) { \
+            const int n = n0 + j; \
+            if (epi & LF_EPI_ADD) la[j] = epi_ld<S16>(r_add, dbase + n * 16); \
+            if (epi & LF_EPI_MASK) lm[j] = epi_ld<S16>(r_msk, dbase + n * 16); \
+            if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[j] = epi_ld<S16>(r_aux, dbase + n * 16); \
+            if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[j] = ldb4(r_dm, (unsigned)(pn[m] * g.Cd + cob + n * 16 + kq * 4) * 4u, 0u); \
         } \
 _Pragma("unroll") \
-        for (int n = 0; n < NT; ++n) { \
-            f32x4 v = acc[n][m] + bs[n]; \
-            if (epi & LF_EPI_ADD) v += la[n]; \
-            if (epi & LF_EPI_MASK) v = keep_pos(v, lm[n]); \
+        for (int j = 0; j < NC; ++j) { \
+            const int n = n0 + j; \
+            f32x4 v = acc[n][m]; \
+            if constexpr (!NOBIAS) v += bs[n]; \
+            if (epi & LF_EPI_ADD) v += la[j]; \
+            if (epi & LF_EPI_MASK) v = keep_pos(v, lm[j]); \
             const int co = cob + n * 16 + kq * 4;   /* per-channel vectors: L1-resident, re-read instead of held in registers */ \
-            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[n] * (HOISTV ? hv[HOISTV ? n : 0][0] : ldb4(r_msc, co * 4u, 0u)) + (HOISTV ? hv[HOISTV ? n : 0][1] : ldb4(r_msh, co * 4u, 0u))); \
+            if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[j] * (HOISTM ? hv[HOISTV ? n : 0][0] : ldb4(r_msc, co * 4u, 0u)) + (HOISTM ? hv[HOISTV ? n : 0][1] : ldb4(r_msh, co * 4u, 0u))); \
             if (epi & LF_EPI_RELU) v = max0(v); \
             if (S16) v = round_bf16(v);   /* statistics are taken from the values as stored */ \
             if (pv[m]) epi_st<S16>(r_dst, dbase + n * 16, v); \
             if (!pv[m]) v = zero4(); \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
-                const f32x4 gm = a.dm ? v * ld[n] : v; \
-                s1[n] += gm; s2[n] += gm * (lx[n] * (HOISTV ? hv[HOISTV ? n : 0][2] : ldb4(r_asc, co * 4u, 0u)) + (HOISTV ? hv[HOISTV ? n : 0][3] : ldb4(r_ash, co * 4u, 0u))); \
+                const f32x4 gm = a.dm ? v * ld[j] : v; \
+                s1[n] += gm; s2[n] += gm * (lx[j] * (HOISTV ? hv[HOISTV ? n : 0][2] : ldb4(r_asc, co * 4u, 0u)) + (HOISTV ? hv[HOISTV ? n : 0][3] : ldb4(r_ash, co * 4u, 0u))); \
             } \
+        } \
         } \
     } \
     if (stats) { \
@@ -182,14 +201,15 @@ constexpr size_t LF_TAP_LDS_PER_TAP = (size_t)WG_WAVES * 64 * (sizeof(uint4) + s
 // round, was measured and dropped: 72 vs 68 us -- three waves per SIMD of this form already overlap rounds.)
 // ROW1 (Wl % 64 == 0): a wave's 64 pixels lie in one image row, so (image, row, first column) are wave-uniform and live in
 // scalar registers: two divisions instead of eight in the prologue and ~10 vector registers less.
-template <int NT, int PROC, int EPIC = -1, bool ROW1 = false>
+// DBG: per-wave phase stamps (tools/kbench.py --phases); compiled only into the instantiation lf_debug_conv1d_fwd_phases launches
+template <int NT, int PROC, int EPIC = -1, bool ROW1 = false, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
     constexpr bool S16 = false, HOISTV = EPIC >= 0;  // compiled-in flags: the per-channel vectors are loaded once, after the loop
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
-    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DBG) tstamp[0] = __builtin_amdgcn_s_memrealtime();
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);       // < 2^31, checked by the launcher
     // Workgroup b runs on XCD b % 8 (observed dispatch order).  Give every XCD a CONTIGUOUS range of pixel
     // tiles so that the halo rows neighbouring tiles share (and both halves of blockIdx.y) meet in one L2.
@@ -311,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
                     acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
         };
         static_assert(MT == 4, "tab_off packs 4 pixel tiles");
-        if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memrealtime();
+        if constexpr (DBG) tstamp[1] = __builtin_amdgcn_s_memrealtime();
         Step A, B;
         issue(A);
         const int npairs = (nsteps + 1) >> 1;
@@ -329,15 +349,19 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         }
     }
 
-    if (a.dbg) {   // make the stamp wait for the last MFMA: touch one accumulator
+    if constexpr (DBG) {   // make the stamp wait for the last MFMA: touch one accumulator
         asm volatile("" ::"v"(acc[0][0][0]));
         tstamp[2] = __builtin_amdgcn_s_memrealtime();
     }
+#undef LF_EPI_ONE_TILE
+#define LF_EPI_ONE_TILE (!ROW1 && EPIC == (LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT))
     LF_TAPGEMM_EPILOGUE
-    if (a.dbg) {
+#undef LF_EPI_ONE_TILE
+#define LF_EPI_ONE_TILE false
+    if constexpr (DBG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
+        if (lane == 0 && a.dbg) {
             unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WG_WAVES + wave) * 8;
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
             unsigned hwid, xcc;                   // which SIMD the wave ran on (tools/kbench.py --phases pairs the waves up)
@@ -560,7 +584,7 @@ __device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& h
 // the idle LDS buffer during A's split phase (B is reading W[s-1]'s successor W[s] from the other one).
 #undef LF_EPI_GROUPS
 #define LF_EPI_GROUPS 2
-template <int NT, int PROC, int TERMS, int EPIC = -1>
+template <int NT, int PROC, int TERMS, int EPIC = -1, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     const int epi = EPIC >= 0 ? EPIC : epi_rt;      // compiled-in epilogue flags, as in tapgemm_kernel
     constexpr bool S16 = false, HOISTV = EPIC >= 0;
@@ -569,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
     const int pl = lane & 15, kq = lane >> 4;
     const int grp = wave >> 2;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
-    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DBG) tstamp[0] = __builtin_amdgcn_s_memrealtime();
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
     const int cob = blockIdx.y * NT * 16;
     unsigned bx = blockIdx.x;
@@ -661,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
     static_assert(TERMS == 9 || TERMS == 6, "9 = every partial product, 6 = those above 2^-24");
     Raw R;
     bf16x8 xb[MT][3];
-    if (a.dbg) tstamp[1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DBG) tstamp[1] = __builtin_amdgcn_s_memrealtime();
     if (grp == 0) wfetch();       // W[0]
     issue(R);                     // pixels of step 0
     if (grp == 1) __syncthreads();            // B starts one phase late
@@ -728,15 +752,15 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
         __builtin_amdgcn_sched_barrier(0);
     }
     if (grp == 0) __syncthreads();            // A pairs B's extra first barrier (B's last matrix phase)
-    if (a.dbg) {
+    if constexpr (DBG) {
         asm volatile("" ::"v"(acc[0][0][0]));
         tstamp[2] = __builtin_amdgcn_s_memrealtime();
     }
     LF_TAPGEMM_EPILOGUE
-    if (a.dbg) {
+    if constexpr (DBG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
+        if (lane == 0 && a.dbg) {
             unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 8;
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
         }
@@ -930,17 +954,25 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         else hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV, false>), grid, dim3(256), tap_lds, st, g, a, pro, epi);    \
     } while (0)
     const size_t tap_lds = LF_TAP_LDS_PER_TAP * g.ntaps;
+    // the compiled-in data-gradient epilogues (mask / residual / BN-backward sums) carry no bias vector (NOBIAS): a launch
+    // that combines one of them with a bias takes the run-time-flag kernel
+    const int epis = ((epi & (LF_EPI_MASK | LF_EPI_ADD | LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) && a.bias) ? -2 : epi;
     LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
     if (a.split && a.wp48 && !a.wp16 && lf_tapgemm_split_ok(g)) {
         LF_REQUIRE(a.split == 9 || a.split == 6, "tapgemm: split must be 9 or 6 (got %d)", a.split);
         LfTapArgs b = a;
         b.wp16 = a.wp48;
         const dim3 grid2((unsigned)(npix / (2 * PIX_PER_WG)), g.Cd / 64);     // 512-pixel workgroups (two 4-wave groups)
+        if (a.dbg) {       // phase stamps (tools/kbench.py --phases): the plain conv only
+            LF_REQUIRE(pro == LF_PRO_NONE && epi == 0, "tapgemm: phase stamps are compiled into the plain convolution only");
+            if (a.split == 9) hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 9, 0, true>), grid2, dim3(512), 0, st, g, b, pro, epi);
+            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 6, -1, true>), grid2, dim3(512), 0, st, g, b, pro, epi);
+        } else
         if (a.split == 9) {
 #define LF_TS9(PROV, EPIV) hipLaunchKernelGGL((tapgemm_split_kernel<4, PROV, 9, EPIV>), grid2, dim3(512), 0, st, g, b, pro, epi)
             if (pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) LF_TS9(1, LF_EPI_RELU);
             else if (pro == LF_PRO_BNRELU) LF_TS9(1, -1);
-            else switch (epi) {
+            else switch (epis) {
                 case 0: LF_TS9(0, 0); break;
                 case LF_EPI_RELU: LF_TS9(0, LF_EPI_RELU); break;
                 case LF_EPI_MASK: LF_TS9(0, LF_EPI_MASK); break;
@@ -973,7 +1005,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         const bool fast16 = nt == 4 && a.s16 && pro != LF_PRO_BNRELU && g.Cs % 32 == 0 &&
                             (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB;
         if (fast16) {       // the bf16-tensor launches of the network at 64 output channels per workgroup
-            switch (epi) {
+            switch (epis) {
                 case 0: LF_TG16F(0); break;
                 case LF_EPI_RELU: LF_TG16F(LF_EPI_RELU); break;
                 case LF_EPI_MASK: LF_TG16F(LF_EPI_MASK); break;
@@ -998,11 +1030,18 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         LF_CHECK_LAUNCH("tapgemm_bf16");
         return 0;
     }
+    if (a.dbg) {           // phase stamps (tools/kbench.py --phases): the plain 64-channel-slab convolution only
+        LF_REQUIRE(nt == 4 && pro == LF_PRO_NONE && epi == 0 && !a.wp16, "tapgemm: phase stamps are compiled into the plain fp32 convolution only");
+        if ((g.Wl & 63) == 0) hipLaunchKernelGGL((tapgemm_kernel<4, 0, 0, true, true>), grid, dim3(256), tap_lds, st, g, a, pro, epi);
+        else hipLaunchKernelGGL((tapgemm_kernel<4, 0, 0, false, true>), grid, dim3(256), tap_lds, st, g, a, pro, epi);
+        LF_CHECK_LAUNCH("tapgemm (stamps)");
+        return 0;
+    }
     switch (nt) {
         case 4:
             if (pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) LF_TG4(1, LF_EPI_RELU);
             else if (pro == LF_PRO_BNRELU) LF_TG4(1, -1);
-            else switch (epi) {
+            else switch (epis) {
                 case 0: LF_TG4(0, 0); break;
                 case LF_EPI_RELU: LF_TG4(0, LF_EPI_RELU); break;
                 case LF_EPI_MASK: LF_TG4(0, LF_EPI_MASK); break;
@@ -1017,11 +1056,11 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         case 3: LF_TG(3); break;
         case 2: LF_TG(2); break;
         default:
-            if (!a.dbg) {
+            {
 #define LF_LEAN(PROV, EPIV) hipLaunchKernelGGL((tapgemm_lean_kernel<1, PROV, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi)
                 if (pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) LF_LEAN(1, LF_EPI_RELU);
                 else if (pro == LF_PRO_BNRELU) LF_LEAN(1, -1);
-                else switch (epi) {
+                else switch (epis) {
                     case 0: LF_LEAN(0, 0); break;
                     case LF_EPI_RELU: LF_LEAN(0, LF_EPI_RELU); break;
                     case LF_EPI_MASK: LF_LEAN(0, LF_EPI_MASK); break;
@@ -1033,7 +1072,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
                     default: LF_LEAN(0, -1); break;
                 }
 #undef LF_LEAN
-            } else LF_TG(1);
+            }
             break;
     }
 #undef LF_TG
@@ -1069,7 +1108,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // sub-steps become ONE v_mfma_f32_16x16x16_bf16 per tile -- a lane's four pixels (p+kq, +4, +8, +12) are exactly its
 // four k of the K=16 step -- with the operands assembled from the raw 8-byte loads by v_perm_b32 (no widening).
 // PROT: 0 / 1 = the BN+ReLU prologue flag compiled in (the fp32 64-channel-block launches of the network), -1 = run-time
-template <bool XV, bool GV, int XT, int GT, int U, bool S16, bool BFM = false, int PROT = -1>
+template <bool XV, bool GV, int XT, int GT, int U, bool S16, bool BFM = false, int PROT = -1, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro_rt,
                                                       const long pps, const int write_bias, const int gxs) {
     constexpr int XTiles = XV ? 4 : XT, GTiles = GV ? 4 : GT;
@@ -1078,7 +1117,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
-    if (a.dbg) tstamp[0] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DBG) tstamp[0] = __builtin_amdgcn_s_memrealtime();
     // 1-D grid of gx * ntaps * (channel-block pairs) workgroups.  Workgroup L runs on XCD L % 8 (observed): each
     // XCD gets a contiguous run of the (pixel-split, channel-block, tap) order with the tap fastest, so all jobs of
     // one pixel range -- which read the same G rows and overlapping X rows -- follow each other through ONE L2
@@ -1129,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
     // x: num_records = the tensor, so that the out-of-range offset LF_OOB reads as zero (the conv's padding); the launcher
     // keeps tensors below LF_OOB bytes
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)((long)g.N * g.Hs * g.Ws * g.s_pix << (S16 ? 1 : 2))),
-                                 rg = make_rsrc(a.g, 0xffffffffu);
+                                 rg = make_rsrc(a.g, (unsigned)((long)g.N * g.Hd * g.Wd * g.d_pix << (S16 ? 1 : 2)));
     f32x4 psc, psh;
     float psc1[XTiles], psh1[XTiles];
     if (pro == LF_PRO_BNRELU) {
@@ -1306,20 +1345,30 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
         auto step = [&](const WStep& S) __attribute__((always_inline)) { compute(S, BIAS_c, PRO_c); };
         wload(A);
         advance();
-        if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tstamp[1] = __builtin_amdgcn_s_memrealtime(); }
-        __builtin_amdgcn_s_setprio(3);              // priority falls with progress (see tapgemm_kernel): the waves of a SIMD finish together
-        const int q1 = niter >> 2, q2 = niter >> 1, q3 = q1 + q2;
-        for (int it = 0;;) {
-            if (it == q1) __builtin_amdgcn_s_setprio(2);
-            if (it == q2) __builtin_amdgcn_s_setprio(1);
-            if (it == q3) __builtin_amdgcn_s_setprio(0);
-            if (it + 1 < niter) { wload(B); advance(); }
-            step(A);
-            if (++it >= niter) break;
-            if (it + 1 < niter) { wload(A); advance(); }
-            step(B);
-            if (++it >= niter) break;
+        if constexpr (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tstamp[1] = __builtin_amdgcn_s_memrealtime(); }
+        // Structured loop: pairs of groups (A then B), an odd last group peeled -- one loop body whose accumulators stay in place
+        // (the first form, a for(;;) with two exits and conditional prefetches, made hipcc rename the 64 accumulator registers
+        // from MFMA to MFMA and copy them at every join: 256 registers, 10 of them spilled in the prologue variant).
+        // The prefetch behind the last group reads the next wave's first group -- or, past the tensors, zeros from the bounded
+        // buffer resources -- and is never used.  Priority falls with progress (quarters): the waves of a SIMD finish together.
+        const int npairs = niter >> 1, qp = npairs >> 2;
+#pragma nounroll
+        for (int ph = 0; ph < 4; ++ph) {
+            switch (ph) {
+                case 0: __builtin_amdgcn_s_setprio(3); break;
+                case 1: __builtin_amdgcn_s_setprio(2); break;
+                case 2: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
+            }
+            const int n = ph < 3 ? qp : npairs - 3 * qp;
+            for (int i = 0; i < n; ++i) {
+                wload(B); advance();
+                step(A);
+                wload(A); advance();
+                step(B);
+            }
         }
+        if (niter & 1) step(A);
     };
     if (niter > 0) {
         if constexpr (PROT >= 0) {
@@ -1331,7 +1380,7 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
             else { if (prologue) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
         }
     }
-    if (a.dbg) { asm volatile("" ::"v"(acc[0][0][0])); tstamp[2] = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (DBG) { asm volatile("" ::"v"(acc[0][0][0])); tstamp[2] = __builtin_amdgcn_s_memrealtime(); }
     // ---- reduce the 4 waves of the workgroup through LDS, wave 0 writes one partial row
     __builtin_amdgcn_s_setprio(3);
     __shared__ float red[WG_WAVES - 1][XTiles * GTiles * 4][64];
@@ -1388,10 +1437,10 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
             }
         }
     }
-    if (a.dbg) {
+    if constexpr (DBG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
+        if (lane == 0 && a.dbg) {
             unsigned long long* d = a.dbg + ((unsigned long long)blockIdx.x * WG_WAVES + wave) * 8;
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -1776,6 +1825,12 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
         return 0;
     }
     dim3 grid(c.gx * g.ntaps * (g.Cs / xb) * (g.Cd / gb));
+    if (a.dbg) {           // phase stamps (tools/kbench.py --phases --wgrad): the fp32 64-channel-block kernel without prologue only
+        LF_REQUIRE(c.xv && c.gv && c.u == 4 && !a.s16 && pro == LF_PRO_NONE, "tapwgrad: phase stamps are compiled into the plain fp32 kernel only");
+        hipLaunchKernelGGL((tapwgrad_kernel<true, true, 4, 4, 4, false, false, 0, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);
+        LF_CHECK_LAUNCH("tapwgrad (stamps)");
+        return 0;
+    }
 #define LF_WG(XV, GV, XT, GT)                                                                                     \
     do {                                                                                                          \
         if (a.s16 && c.u == 4 && XV && GV) hipLaunchKernelGGL((tapwgrad_kernel<XV, GV, XT, GT, 4, true, (XV && GV)>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx); \
