@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 
 from lanedetection_end2end_amd import geometry
-from lanedetection_end2end_amd.clas import Classification  # noqa: F401
+from lanedetection_end2end_amd.clas import ClassificationBEV as Classification  # noqa: F401  (four 3-way line heads, :198-205)
 from lanedetection_end2end_amd.fit import WeightedLeastSquares
 from lanedetection_end2end_amd.lsq import BEVNet as Net, activation_layer  # noqa: F401
 

@@ -1,7 +1,9 @@
 """The ``--clas`` line-type / horizon heads and the inference-side lane decoding.
 
-``Classification`` mirrors BP/Networks/LSQ_layer.py:150-207 (BEV/Networks/LSQ_layer.py:170-228 is the same
-class): four Conv-BatchNorm-ReLU blocks on the encoder output, a pooling layer, fully connected layers.
+``Classification`` mirrors BP/Networks/LSQ_layer.py:150-207: four Conv-BatchNorm-ReLU blocks on the encoder output, a
+pooling layer, fully connected layers.  The BEV tree's class (BEV/Networks/LSQ_layer.py:170-228) has the same trunk and
+the same horizon head but a DIFFERENT line head -- four ``fully_connected_line{1..4}`` ``Linear(128, 3)`` whose outputs
+are concatenated to (N, 3, 4), consumed by ``nn.CrossEntropyLoss`` (BEV/main.py:88,252) -- ``ClassificationBEV`` below.
 The conv trunk runs as ONE C-ABI call per direction (``lf_convchain_forward`` / ``_backward``) directly on
 the NHWC encoder output inside the backbone's workspace; pooling + NCHW flatten is ``lf_poolflat_*``; the
 ``nn.Linear`` layers are plain library GEMMs.
@@ -130,12 +132,19 @@ class Classification(nn.Module):
         self.maxpool = nn.MaxPool2d((2, 2), stride=2)
         if class_type == 'line':
             self.fully_connected1 = nn.Linear(64 * rows * cols // 4, 128)
-            self.fully_connected_line1 = nn.Linear(128, 4)
+            self._make_line_heads()
         else:
             self.fully_connected_horizon = nn.Linear(64 * rows, resize)
         self._channels = (channels_in, 128, 128, 64, 64)
         self._plans = {}
         self._ptr_cache = (None, None)
+
+    def _make_line_heads(self):
+        """BP: one 4-way head (BP/Networks/LSQ_layer.py:186-187)."""
+        self.fully_connected_line1 = nn.Linear(128, 4)
+
+    def _line_logits(self, f):
+        return self.fully_connected_line1(f)
 
     def _batchnorms(self):
         return [self.conv1_bn, self.conv2_bn, self.conv3_bn, self.conv4_bn]
@@ -175,9 +184,25 @@ class Classification(nn.Module):
         if self.class_type == 'line':
             f = _PoolFlatFn.apply(y, 0)
             f = F.relu(self.fully_connected1(f))
-            return self.fully_connected_line1(f)
+            return self._line_logits(f)
         f = _PoolFlatFn.apply(y, 1)
         return self.fully_connected_horizon(f)
+
+
+class ClassificationBEV(Classification):
+    """The BEV tree's ``Classification`` (BEV/Networks/LSQ_layer.py:170-228): same trunk and horizon head; the line
+    head is four 3-way classifiers ``fully_connected_line1..4`` (``Linear(128, 3)`` each, :198-205) whose logits are
+    stacked to (N, 3, 4) -- class axis 1, lane axis 2 (:218-226) -- for ``nn.CrossEntropyLoss`` (BEV/main.py:88,252).
+    The four heads keep their own parameters (``state_dict`` keys of the reference) and run as ONE (128 -> 12) GEMM."""
+
+    def _make_line_heads(self):
+        for i in range(1, 5):
+            setattr(self, "fully_connected_line%d" % i, nn.Linear(128, 3))
+
+    def _line_logits(self, f):
+        heads = [getattr(self, "fully_connected_line%d" % i) for i in range(1, 5)]
+        y = F.linear(f, torch.cat([h.weight for h in heads], 0), torch.cat([h.bias for h in heads], 0))    # (N, 12), head-major
+        return y.view(f.size(0), 4, 3).transpose(1, 2)                                                       # (N, 3, 4)
 
 
 def resize_coordinates(array):

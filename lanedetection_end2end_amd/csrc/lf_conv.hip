@@ -337,14 +337,19 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         const int npairs = (nsteps + 1) >> 1;
         // (Priority falling with progress makes the two waves of a SIMD finish together instead of ~12 us apart -- measured
         // neutral at 128 channels and 15 % SLOWER at 64, where a third / fourth wave waits for the slot of the first finisher.)
+        // The fences pin the next step's loads behind the FIRST quarter of the current step's MFMAs (three quarters of a step of
+        // lead).  Left to the scheduler the position depends on the register pressure of the rest of the kernel: a change in the
+        // epilogue moved the loads behind the third quarter and cost the 64-channel RELU / MASK launches 6-8 us (r3a).
         for (int pr = 0; pr < npairs; ++pr) {
             finish(A);
             mma(A, 0);
             issue(B);
+            __builtin_amdgcn_sched_barrier(0);
             mma(A, 1); mma(A, 2); mma(A, 3);
             finish(B);
             mma(B, 0);
             issue(A);
+            __builtin_amdgcn_sched_barrier(0);
             mma(B, 1); mma(B, 2); mma(B, 3);
         }
     }

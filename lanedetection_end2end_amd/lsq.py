@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import erfnet, fit, geometry
-from .clas import Classification
+from .clas import Classification, ClassificationBEV
 
 
 def activation_layer(activation='square', no_cuda=False):
@@ -29,6 +29,7 @@ class _LaneFitNet(nn.Module):
     beta_dtype = torch.float32
     max_order = 2
     cholesky_drops_reg = False       # BP only: its --use_cholesky branch is GELS, which has no regulariser
+    classification_cls = Classification      # the tree's own --clas head class (the BEV tree's line head differs)
 
     def _common_init(self, args, M, backbone_cls):
         self.nclasses = args.nclasses
@@ -53,8 +54,9 @@ class _LaneFitNet(nn.Module):
         self.classification_branch = bool(getattr(args, "clas", False))
         if self.classification_branch:
             # LSQ_layer.py:247-254 (BP) / :270-277 (BEV): both heads read the (32, 64) encoder output
-            self.line_classification = Classification('line', size=(32, 64), channels_in=128, resize=resize).cuda()
-            self.horizon_estimation = Classification('horizon', size=(32, 64), channels_in=128, resize=resize).cuda()
+            cls = self.classification_cls
+            self.line_classification = cls('line', size=(32, 64), channels_in=128, resize=resize).cuda()
+            self.horizon_estimation = cls('horizon', size=(32, 64), channels_in=128, resize=resize).cuda()
         self.net.export_encoder_output = self.classification_branch
         # precision mode of the backbone (erfnet.Net.precision): "fp32" unless args.precision says otherwise
         self.net.precision = getattr(args, "precision", "fp32")
@@ -107,7 +109,9 @@ class _LaneFitNet(nn.Module):
 
 class BEVNet(_LaneFitNet):
     """``Net(args)``; ``forward(input, end_to_end) ->
-    (beta0, beta1, beta2, beta3, masked, M, output, line, horizon)`` (BEV/Networks/LSQ_layer.py:290-326)."""
+    (beta0, beta1, beta2, beta3, masked, M, output, line, horizon)`` (BEV/Networks/LSQ_layer.py:290-326);
+    with ``--clas`` the line output is (N, 3, 4) (four 3-way heads, ``ClassificationBEV``)."""
+    classification_cls = ClassificationBEV
 
     def __init__(self, args):
         super().__init__()

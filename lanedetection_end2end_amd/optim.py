@@ -21,11 +21,23 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = float(grad_scale)
         self._tables = {}
 
+    def load_state_dict(self, state_dict):
+        """A loaded state replaces ``exp_avg`` / ``exp_avg_sq`` / ``step``: the cached device tables hold the OLD buffers' addresses
+        and the old device-side step counts, so they are dropped (mid-run resume / rollback)."""
+        super().load_state_dict(state_dict)
+        self._tables = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = {}
+
     def _table(self, gi, plist):
         """Device tables for one param group: records {p, g, m, v, numel, step[2]} and the (tensor, chunk) work list.  Rebuilt --
-        with the step counts of ``self.state`` in BOTH slots -- when the set of tensors with a gradient or a buffer address
-        changed; between rebuilds the kernel advances the counts on the device (slot parity alternates per launch)."""
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        with the step counts of ``self.state`` in BOTH slots -- when the set of tensors with a gradient or any buffer address
+        (parameter, gradient, moments) changed; between rebuilds the kernel advances the counts on the device (slot parity
+        alternates per launch)."""
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
+                    for p in plist)
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == key:
             return cached
@@ -83,8 +95,16 @@ class _FusedMomentum(torch.optim.Optimizer):
         self.grad_scale = float(grad_scale)
         self._tables = {}
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)      # new state buffers: the cached device tables point at the old ones
+        self._tables = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = {}
+
     def _table(self, gi, plist):
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) + tuple(self.state[p][n].data_ptr() for n in self._state_names) for p in plist)
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == key:
             return cached

@@ -19,8 +19,9 @@ from . import fit_oracle
 BN_EPS, BN_MOM = 1e-5, 0.1          # nn.BatchNorm2d defaults (LSQ_layer.py:159,165,169,173)
 
 
-def clas_param_spec(class_type, rows=32, cols=64, channels_in=128, resize=256):
-    """state_dict keys/shapes of ``Classification`` in registration order (LSQ_layer.py:152-190)."""
+def clas_param_spec(class_type, rows=32, cols=64, channels_in=128, resize=256, tree="bp"):
+    """state_dict keys/shapes of ``Classification`` in registration order (BP/Networks/LSQ_layer.py:152-190; ``tree="bev"``:
+    BEV/Networks/LSQ_layer.py:172-207, whose line head is four ``Linear(128, 3)``)."""
     spec = OrderedDict()
     for name, ci, co, k in (("conv1", channels_in, 128, 1), ("conv2", 128, 128, 3), ("conv3", 128, 64, 3),
                             ("conv4", 64, 64, 3)):
@@ -34,8 +35,13 @@ def clas_param_spec(class_type, rows=32, cols=64, channels_in=128, resize=256):
     if class_type == "line":
         spec["fully_connected1.weight"] = (128, 64 * rows * cols // 4)
         spec["fully_connected1.bias"] = (128,)
-        spec["fully_connected_line1.weight"] = (4, 128)
-        spec["fully_connected_line1.bias"] = (4,)
+        if tree == "bev":
+            for i in range(1, 5):
+                spec["fully_connected_line%d.weight" % i] = (3, 128)
+                spec["fully_connected_line%d.bias" % i] = (3,)
+        else:
+            spec["fully_connected_line1.weight"] = (4, 128)
+            spec["fully_connected_line1.bias"] = (4,)
     else:
         spec["fully_connected_horizon.weight"] = (resize, 64 * rows)
         spec["fully_connected_horizon.bias"] = (resize,)
@@ -89,11 +95,16 @@ def classification_trunk(x, P, training=True, stats_out=None):
 
 
 def classification_forward(x, P, class_type, training=True, stats_out=None):
-    """x (N,128,rows,cols) -> line logits (N,4) or horizon logits (N,resize) -- LSQ_layer.py:192-207."""
+    """x (N,128,rows,cols) -> line logits (N,4) or horizon logits (N,resize) -- BP/Networks/LSQ_layer.py:192-207.
+    With the BEV tree's parameters (``fully_connected_line4`` present) the line logits are the four 3-way heads stacked
+    to (N,3,4): ``cat((x1,x2,x3,x4), 2)`` of (N,3,1,1) views -- BEV/Networks/LSQ_layer.py:218-226."""
     y = classification_trunk(x, P, training, stats_out)
     if class_type == "line":
         f = F.max_pool2d(y, 2, 2).reshape(y.shape[0], -1)
         f = F.relu(F.linear(f, P["fully_connected1.weight"], P["fully_connected1.bias"]))
+        if "fully_connected_line4.weight" in P:
+            return torch.stack([F.linear(f, P["fully_connected_line%d.weight" % i], P["fully_connected_line%d.bias" % i])
+                                for i in range(1, 5)], 2)
         return F.linear(f, P["fully_connected_line1.weight"], P["fully_connected_line1.bias"])
     f = y.mean(3).reshape(y.shape[0], -1)                     # AvgPool2d((1, cols)) with cols == width
     return F.linear(f, P["fully_connected_horizon.weight"], P["fully_connected_horizon.bias"])

@@ -23,14 +23,17 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 HEAD_N = 2
 
 
-def clas_inputs(class_type):
+def clas_inputs(class_type, tree="bp"):
     """Encoder-like input (post-ReLU, N x 128 x 32 x 64) and the upstream gradient of the logits.
     Seed 83: the smallest |pre-ReLU value| over the four blocks is 1.4e-6 (fp64), clear of fp32 rounding --
-    seeds with a 3e-8 near-tie make fp32 and fp64 runs take different ReLU branches at one element."""
+    seeds with a 3e-8 near-tie make fp32 and fp64 runs take different ReLU branches at one element.
+    ``tree="bev"``: the BEV line head's logits are (N, 3, 4)."""
     rng = np.random.default_rng(83)
     x = np.maximum(rng.standard_normal((HEAD_N, 128, 32, 64)), 0).astype(np.float32)
     nout = 4 if class_type == "line" else 256
     g = rng.standard_normal((HEAD_N, nout)).astype(np.float32)
+    if tree == "bev" and class_type == "line":
+        g = np.random.default_rng(84).standard_normal((HEAD_N, 3, 4)).astype(np.float32)
     return x, g
 
 
@@ -50,11 +53,13 @@ def decode_inputs(order, N=6, L=4):
     return beta, line, horizon
 
 
-def gen_heads(ref, out):
-    for class_type in ("line", "horizon"):
-        x, g = clas_inputs(class_type)
+def gen_heads(ref, out, tree="bp"):
+    """``tree="bev"``: the BEV tree's class (BEV/Networks/LSQ_layer.py:170-228) -- only its line head differs from BP's
+    (four ``Linear(128, 3)`` -> (N,3,4)), so only that one is stored (-> tests/golden/clas_bev.npz)."""
+    for class_type in (("line",) if tree == "bev" else ("line", "horizon")):
+        x, g = clas_inputs(class_type, tree)
         for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
-            P = clas_oracle.make_clas_params(class_type, seed=7)
+            P = clas_oracle.make_clas_params(class_type, seed=7, tree=tree)
             m = ref.LSQ_layer.Classification(class_type, size=(32, 64), channels_in=128, resize=256)
             assert list(m.state_dict().keys()) == list(P.keys())
             m.load_state_dict(P)
@@ -124,6 +129,11 @@ def main():
     gen_heads(ref_shims.load("bp"), out)
     gen_decode(out)
     path = os.path.join(OUT, "clas.npz")
+    np.savez_compressed(path, **out)
+    print(path, "%.1f KB" % (os.path.getsize(path) / 1024), len(out), "arrays")
+    out = {}
+    gen_heads(ref_shims.load("bev"), out, tree="bev")
+    path = os.path.join(OUT, "clas_bev.npz")
     np.savez_compressed(path, **out)
     print(path, "%.1f KB" % (os.path.getsize(path) / 1024), len(out), "arrays")
 

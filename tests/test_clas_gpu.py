@@ -36,17 +36,28 @@ def _oracle_head(class_type, x, g, P32, training=True):
     return y.detach(), xt.grad, P, stats
 
 
-@pytest.mark.parametrize("class_type", ["line", "horizon"])
-def test_classification_head(golden_clas, class_type):
-    from lanedetection_end2end_amd.bp.Networks.LSQ_layer import Classification
-    x, g = clas_inputs(class_type)
-    P32 = clas_oracle.make_clas_params(class_type, seed=7)
+@pytest.fixture(scope="module")
+def golden_clas_bev():
+    return np.load(os.path.join(GOLDEN, "clas_bev.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("tree,class_type", [("bp", "line"), ("bp", "horizon"), ("bev", "line")])
+def test_classification_head(golden_clas, golden_clas_bev, tree, class_type):
+    """bev/line: the BEV tree's head (four Linear(128,3) -> (N,3,4)), state_dict keys and values of the real BEV class."""
+    if tree == "bev":
+        from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Classification
+        golden_clas = golden_clas_bev
+    else:
+        from lanedetection_end2end_amd.bp.Networks.LSQ_layer import Classification
+    x, g = clas_inputs(class_type, tree)
+    P32 = clas_oracle.make_clas_params(class_type, seed=7, tree=tree)
     m = Classification(class_type, size=(32, 64), channels_in=128, resize=256)
     assert list(m.state_dict().keys()) == list(P32.keys())
     m.load_state_dict(P32)
     m = m.cuda().train()
     xt = torch.from_numpy(x).cuda().requires_grad_(True)        # plain NCHW: the module converts
     y = m(xt)
+    assert tree != "bev" or y.shape == (x.shape[0], 3, 4)
     (y * torch.from_numpy(g).cuda()).sum().backward()
     yo, gxo, Po, stats = _oracle_head(class_type, x, g, P32)
     pre = "%s_f64_" % class_type
@@ -88,6 +99,46 @@ def test_classification_on_channels_last_view_and_batch():
     a = m(x)
     b = m(x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2))
     assert torch.equal(a, b) and a.shape == (3, 256)
+
+
+def test_bev_net_with_clas_heads_feeds_cross_entropy():
+    """BEV Net(args.clas=True): line logits (N,3,4) consumed by nn.CrossEntropyLoss with (N,4) integer targets, horizon
+    logits (N,resize) by BCEWithLogitsLoss -- the statements of BEV/main.py:88-89,249-253 -- and the heads' gradient reaches
+    the encoder through the shared encoder output."""
+    from argparse import Namespace
+    from lanedetection_end2end_amd.bev.Loss_crit import Area_Loss
+    from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Net
+    N, R = 2, 256
+    args = Namespace(batch_size=N, nclasses=2, resize=R, end_to_end=True, mod="erfnet", layers=18, channels_in=3,
+                     pretrained=False, pool=True, activation_layer="square", no_cuda=False, order=2, reg_ls=0.0,
+                     use_cholesky=False, mask_percentage=0.3, clas=True, loss_policy="area", weight_funct="none", weight_seg=30)
+    model = Net(args)
+    keys = list(model.state_dict().keys())
+    for i in range(1, 5):
+        assert "line_classification.fully_connected_line%d.weight" % i in keys
+        assert tuple(model.state_dict()["line_classification.fully_connected_line%d.weight" % i].shape) == (3, 128)
+    assert "horizon_estimation.fully_connected_horizon.weight" in keys
+    model.net.load_state_dict(erfnet_oracle.make_params(seed=5, out_channels=2))
+    model.line_classification.load_state_dict(clas_oracle.make_clas_params("line", seed=11, tree="bev"))
+    model.horizon_estimation.load_state_dict(clas_oracle.make_clas_params("horizon", seed=12))
+    model = model.cuda().train()
+    x = torch.from_numpy(inputs.images(N, R, 2 * R, seed=71)).cuda()
+    gt = torch.from_numpy(inputs.bev_gt_params(N, seed=72)).cuda()
+    rng = np.random.default_rng(5)
+    gt_line = torch.from_numpy(rng.integers(0, 3, (N, 4))).cuda()
+    gt_hor = torch.from_numpy((rng.uniform(0, 1, (N, R)) > 0.5).astype(np.float32)).cuda()
+    b0, b1, _, _, _, _, _, line, horizon = model(x, True)
+    assert line.shape == (N, 3, 4) and horizon.shape == (N, R)
+    crit = Area_Loss(2, "none")
+    loss_fit = crit(b0, gt[:, 0]) + crit(b1, gt[:, 1])
+    loss_cls = torch.nn.CrossEntropyLoss()(line, gt_line) + torch.nn.BCEWithLogitsLoss()(horizon, gt_hor)
+    _, line_pred = torch.max(line, 1)                  # BEV/main.py:251
+    assert line_pred.shape == (N, 4)
+    (loss_fit + loss_cls).backward()
+    g_enc = model.net.encoder.initial_block.conv.weight.grad
+    assert torch.isfinite(g_enc).all() and g_enc.abs().max() > 0
+    for i in range(1, 5):
+        assert getattr(model.line_classification, "fully_connected_line%d" % i).weight.grad.abs().max() > 0
 
 
 def _bp_args(N, R, K, clas):

@@ -21,11 +21,20 @@ def _grad_sample(g):
     return g if g.size <= 20000 else g.reshape(-1)[::97]
 
 
-@pytest.mark.parametrize("class_type", ["line", "horizon"])
+@pytest.fixture(scope="module")
+def golden_clas_bev():
+    return np.load(os.path.join(GOLDEN, "clas_bev.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("tree,class_type", [("bp", "line"), ("bp", "horizon"), ("bev", "line")])
 @pytest.mark.parametrize("tag,dtype,tol", [("f64", torch.float64, 1e-11), ("f32", torch.float32, 2e-4)])
-def test_classification_head(golden_clas, class_type, tag, dtype, tol):
-    x, g = clas_inputs(class_type)
-    P = clas_oracle.cast_params(clas_oracle.make_clas_params(class_type, seed=7), dtype)
+def test_classification_head(golden_clas, golden_clas_bev, tree, class_type, tag, dtype, tol):
+    """bev/line: the BEV tree's four 3-way heads -> (N,3,4) (BEV/Networks/LSQ_layer.py:198-205,218-226), golden from the
+    real BEV class (oracle/gen_golden_clas.py -> clas_bev.npz)."""
+    if tree == "bev":
+        golden_clas = golden_clas_bev
+    x, g = clas_inputs(class_type, tree)
+    P = clas_oracle.cast_params(clas_oracle.make_clas_params(class_type, seed=7, tree=tree), dtype)
     for k, v in P.items():
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_(True)
@@ -34,6 +43,7 @@ def test_classification_head(golden_clas, class_type, tag, dtype, tol):
     y = clas_oracle.classification_forward(xt, P, class_type, True, stats)
     (y * torch.from_numpy(g).to(dtype)).sum().backward()
     pre = "%s_%s_" % (class_type, tag)
+    assert y.shape == golden_clas[pre + "train_out"].shape and (tree != "bev" or y.shape[1:] == (3, 4))
     assert relerr(y.detach().numpy(), golden_clas[pre + "train_out"]) < tol
     assert relerr(xt.grad.numpy()[:, ::8, ::4, ::4], golden_clas[pre + "gx_sample"]) < tol
     for k in ("conv1_bn.running_mean", "conv4_bn.running_var"):

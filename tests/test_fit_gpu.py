@@ -329,3 +329,42 @@ def test_fused_sgd_rmsprop_match_torch(kind):
     assert torch.equal(ua, ub)
     with pytest.raises(KeyError):
         define_optim("lbfgs", pa, 1e-2, 0.0)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd", "rmsprop"])
+def test_fused_optimizers_step_load_step(kind):
+    """Mid-run resume / rollback: an optimizer that has ALREADY stepped loads a state_dict (new moment
+    buffers, other step counts) and keeps stepping -- the cached device tables must follow the loaded state, i.e. the result
+    equals the torch optimizer taken through the same sequence."""
+    import copy
+    from lanedetection_end2end_amd.optim import define_optim
+    torch.manual_seed(2)
+    shapes = [(64, 64, 3, 1), (128,), (5000,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = define_optim(kind, pa, 1e-2, 1e-3)
+    ob = {"adam": lambda p: torch.optim.Adam(p, lr=1e-2, weight_decay=1e-3),
+          "sgd": lambda p: torch.optim.SGD(p, lr=1e-2, momentum=0.9, weight_decay=1e-3),
+          "rmsprop": lambda p: torch.optim.RMSprop(p, lr=1e-2, momentum=0.9, weight_decay=1e-3)}[kind](pb)
+
+    def both_step(n):
+        for _ in range(n):
+            for a, b in zip(pa, pb):
+                g = torch.randn_like(a)
+                a.grad, b.grad = g.clone(), g.clone()
+            oa.step()
+            ob.step()
+    both_step(3)
+    snap_opt = copy.deepcopy(ob.state_dict())                 # the checkpoint: torch's own format
+    snap_par = [b.detach().clone() for b in pb]
+    both_step(4)                                              # run on ...
+    for a, b, s in zip(pa, pb, snap_par):                     # ... then roll both back to the checkpoint
+        a.data.copy_(s)
+        b.data.copy_(s)
+    oa.load_state_dict(copy.deepcopy(snap_opt))
+    ob.load_state_dict(copy.deepcopy(snap_opt))
+    both_step(3)
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) < 3e-6 * float(b.abs().max())
+    if kind == "adam":
+        assert oa.state[pa[0]]["step"] == 6
