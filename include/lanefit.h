@@ -157,6 +157,10 @@ long lf_erfnet_dropmask_offset(const lf_erfnet_plan* plan, int i);      /* float
 int lf_erfnet_dropmask_channels(const lf_erfnet_plan* plan, int i);
 long lf_erfnet_encoder_offset(const lf_erfnet_plan* plan);             /* float offset of the encoder output (N,H/8,W/8,128) NHWC */
 long lf_erfnet_activation_offset(const lf_erfnet_plan* plan, int layer, int slot);
+/* head = 0 / 1 selects output_conv / output_conv2; head = -1 = ENCODER ONLY (Net.forward(only_encode=True),
+ * BEV/Networks/ERFNet.py:151-153): the decoder does not run (its BatchNorm running statistics stay untouched, as in the
+ * reference, where the decoder is never called on that branch), logits may be NULL; the matching backward takes
+ * head = -1 too, with grad_encoder as the incoming gradient. */
 int lf_erfnet_forward(const lf_erfnet_plan* plan, const float* img, const float* const* params_host,
                       const float* const* params_dev, float* const* running_host, const float* dropmask,
                       int training, int head, float* logits, void* workspace, size_t workspace_bytes, void* stream);

@@ -23,6 +23,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <utility>
+
 #include "lf_conv.h"
 #include "lf_types.h"
 
@@ -95,14 +98,25 @@ __device__ __forceinline__ unsigned split_pair(f32x2& v) {
     v.y -= __uint_as_float(u & 0xffff0000u);
     return u;
 }
-// sum over the 16 lanes that share l>>4 (xor 1,2,4,8 stays inside the 16-lane group)
+// sum over the 16 lanes that share l>>4 (one DPP row): lane pairs, quads (quad_perm), then the four quad totals by row
+// rotations of 4 and 8 -- every lane ends with the row total (associated differently per quad; the caller reads lane 0 of the
+// row).  DPP adds need neither the lane id nor the LDS crossbar that __shfl_xor (ds_bpermute) goes through.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float sum16(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);     // row_ror:4
+    v += dpp_mov<0x128>(v);     // row_ror:8
     return v;
 }
 
 #define LF_EPI_GROUPS 1      /* 4-wave groups per workgroup; the 512-thread split kernel redefines it */
 #define LF_EPI_ONE_TILE false  /* tapgemm_kernel: true for the per-lane-row form of the three-tensor epilogue (one register short) */
+#define LF_EPI_TID threadIdx.x  /* tapgemm_kernel: its per-tile laundered copy */
+#define LF_EPI_ROW1 false      /* tapgemm_kernel: its ROW1 (a wave's 64 pixels in one image row) */
 #define LF_TAPGEMM_EPILOGUE \
     /* Pixel-tile outer, channel-tile inner: the loads of one operand tensor issued back to back cover one pixel's     \
      * contiguous channel run, so every cache line is touched once while it is hot (the channel-tile-outer order        \
@@ -144,7 +158,7 @@ _Pragma("unroll") \
             if (epi & LF_EPI_ADD) la[j] = epi_ld<S16>(r_add, dbase + n * 16); \
             if (epi & LF_EPI_MASK) lm[j] = epi_ld<S16>(r_msk, dbase + n * 16); \
             if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[j] = epi_ld<S16>(r_aux, dbase + n * 16); \
-            if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[j] = ldb4(r_dm, (unsigned)(pn[m] * g.Cd + cob + n * 16 + kq * 4) * 4u, 0u); \
+            if ((epi & LF_EPI_STATS_XHAT) && a.dm && !LF_EPI_ROW1) ld[j] = ldb4(r_dm, (unsigned)(pn[m] * g.Cd + cob + n * 16 + kq * 4) * 4u, 0u); \
         } \
 _Pragma("unroll") \
         for (int j = 0; j < NC; ++j) { \
@@ -161,10 +175,18 @@ _Pragma("unroll") \
             if (!pv[m]) v = zero4(); \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
-                const f32x4 gm = a.dm ? v * ld[j] : v; \
+                const f32x4 gm = (a.dm && !LF_EPI_ROW1) ? v * ld[j] : v; \
                 s1[n] += gm; s2[n] += gm * (lx[j] * (HOISTV ? hv[HOISTV ? n : 0][2] : ldb4(r_asc, co * 4u, 0u)) + (HOISTV ? hv[HOISTV ? n : 0][3] : ldb4(r_ash, co * 4u, 0u))); \
             } \
         } \
+        } \
+    } \
+    if (LF_EPI_ROW1 && (epi & LF_EPI_STATS_XHAT) && a.dm) { \
+        /* a wave's pixels lie in ONE image: the Dropout2d factor of (image, channel) scales the wave's sums once */ \
+_Pragma("unroll") \
+        for (int n = 0; n < NT; ++n) { \
+            const f32x4 dmv = ldb4(r_dm, (unsigned)(pn[0] * g.Cd + cob + n * 16 + kq * 4) * 4u, 0u); \
+            s1[n] *= dmv; s2[n] *= dmv; \
         } \
     } \
     if (stats) { \
@@ -182,8 +204,8 @@ _Pragma("unroll") \
             } \
         } \
         __syncthreads(); \
-        if ((threadIdx.x & 255) < NT * 4 * 8) { \
-            const int tg = threadIdx.x >> 8, tt = threadIdx.x & 255; \
+        if ((LF_EPI_TID & 255) < NT * 4 * 8) { \
+            const int tg = LF_EPI_TID >> 8, tt = LF_EPI_TID & 255; \
             const int j = tt & 7, q = (tt >> 3) & 3, n = tt >> 5; \
             const float v = sred[tg][0][n][q][j] + sred[tg][1][n][q][j] + sred[tg][2][n][q][j] + sred[tg][3][n][q][j]; \
             const int co = cob + n * 16 + q * 4 + (j & 3); \
@@ -206,8 +228,6 @@ template <int NT, int PROC, int EPIC = -1, bool ROW1 = false, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
     constexpr bool S16 = false, HOISTV = EPIC >= 0;  // compiled-in flags: the per-channel vectors are loaded once, after the loop
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
     if constexpr (DBG) tstamp[0] = __builtin_amdgcn_s_memrealtime();
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);       // < 2^31, checked by the launcher
@@ -215,9 +235,26 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
     // tiles so that the halo rows neighbouring tiles share (and both halves of blockIdx.y) meet in one L2.
     // (A persistent loop over tiles and a 3-set operand ring were measured and dropped: at batch 32 every
     // layer is one or two rounds of resident workgroups, and the extra live state cost more than it hid.)
+    // Round 3: the grid is sized to the workgroups the chip holds at once (launcher: occupancy x CUs) and a workgroup walks its
+    // tiles first, first + stride, ... -- so WHICH workgroup (hence which CU: they are dealt breadth-first) processes the tiles
+    // beyond the first round is fixed by construction, one extra tile per CU.  Left to the dispatcher, the 256 second-round
+    // workgroups of a 64-channel launch (1024 workgroups, 768 resident) went to whichever CUs retired workgroups first: with the
+    // three co-resident workgroups of a CU finishing together, a third of the CUs took three more and the rest none -- 71.5
+    // instead of 58.5 us, decided by details as small as dead code behind the epilogue (r3 A/B runs, tools/ab_conv.py).
     const int cob = blockIdx.y * NT * 16;
-    unsigned bx = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const unsigned ntiles = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
+    unsigned t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
+    if ((gridDim.x & 7u) == 0 && (ntiles & 7u) == 0) {
+        const unsigned per = ntiles >> 3;
+        t_first = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); t_stride = gridDim.x >> 3; t_end = (blockIdx.x & 7u) * per + per;
+    }
+    for (unsigned bx = t_first; bx < t_end; bx += t_stride) {
+    // (the thread index is laundered per tile: hoisted out of the tile loop, the per-lane constants derived from it would
+    // stay live across the whole body -- 10-20 registers, the difference between three and two waves per SIMD)
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, kq = lane >> 4;
     const unsigned tile0 = (bx * WG_WAVES + (ROW1 ? __builtin_amdgcn_readfirstlane(wave) : wave)) * (MT * 16);
 
     int pn[MT], pi[MT], pj[MT];
@@ -360,12 +397,24 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
     }
 #undef LF_EPI_ONE_TILE
 #define LF_EPI_ONE_TILE (!ROW1 && EPIC == (LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT))
+#undef LF_EPI_TID
+#define LF_EPI_TID tid
+#undef LF_EPI_ROW1
+#define LF_EPI_ROW1 ROW1
     LF_TAPGEMM_EPILOGUE
 #undef LF_EPI_ONE_TILE
 #define LF_EPI_ONE_TILE false
+#undef LF_EPI_TID
+#define LF_EPI_TID threadIdx.x
+#undef LF_EPI_ROW1
+#define LF_EPI_ROW1 false
+    if (stats && bx + t_stride < t_end) __syncthreads();      // the statistics staging area is reused by the next tile
+    __builtin_amdgcn_s_setprio(0);
+    }   // tiles of this workgroup
     if constexpr (DBG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memrealtime();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         if (lane == 0 && a.dbg) {
             unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WG_WAVES + wave) * 8;
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
@@ -938,6 +987,30 @@ int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a) {
     return lf_cdiv((long)g.N * g.Hl * g.Wl, PIX_PER_WG);
 }
 
+namespace {
+// Workgroups of `kernel` the whole chip holds at once (occupancy x CUs), cached per (kernel, dynamic LDS bytes).
+template <typename K>
+int resident_workgroups(K kernel, size_t lds) {
+    static std::map<std::pair<const void*, size_t>, int> cache;
+    const std::pair<const void*, size_t> key(reinterpret_cast<const void*>(kernel), lds);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int dev = 0, cus = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, lds) != hipSuccess || nb < 1 || cus < 1)
+        return cache[key] = 1 << 30;                 // unknown: one tile per workgroup
+    return cache[key] = nb * cus;
+}
+// tapgemm_kernel walks its pixel tiles with stride gridDim.x: launch no more workgroups than are resident at once (a multiple
+// of 8 per XCD dealing), so that the tiles beyond the first round are spread one per CU by construction
+template <typename K>
+void launch_tapgemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
+    const unsigned res = (unsigned)resident_workgroups(kernel, lds) / grid.y;
+    if (grid.x > res && res >= 8) grid.x = res & ~7u;
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, g, a, pro, epi);
+}
+}  // namespace
+
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st) {
     LF_REQUIRE(g.Cs % 16 == 0 && g.Cd % 16 == 0, "tapgemm: channels must be multiples of 16 (Cs=%d Cd=%d)", g.Cs, g.Cd);
     LF_REQUIRE(g.s_pix % 4 == 0 && g.s_choff % 4 == 0 && g.d_pix % 4 == 0 && g.d_choff % 4 == 0, "tapgemm: unaligned channel layout");
@@ -950,13 +1023,13 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     LF_REQUIRE((long)g.N * g.Hd * g.Wd * g.d_pix * 4 < (long)LF_OOB, "tapgemm: destination tensor too large for 32-bit byte offsets");
 #define LF_TG(NTV)                                                                                                       \
     do {                                                                                                                 \
-        if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_kernel<NTV, 1>), grid, dim3(256), tap_lds, st, g, a, pro, epi);  \
-        else hipLaunchKernelGGL((tapgemm_kernel<NTV, 0>), grid, dim3(256), tap_lds, st, g, a, pro, epi);                       \
+        if (pro == LF_PRO_BNRELU) launch_tapgemm(tapgemm_kernel<NTV, 1>, grid, tap_lds, st, g, a, pro, epi);  \
+        else launch_tapgemm(tapgemm_kernel<NTV, 0>, grid, tap_lds, st, g, a, pro, epi);                       \
     } while (0)
 #define LF_TG4(PROV, EPIV)                                                                                               \
     do {                                                                                                                 \
-        if ((g.Wl & 63) == 0) hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV, true>), grid, dim3(256), tap_lds, st, g, a, pro, epi);  \
-        else hipLaunchKernelGGL((tapgemm_kernel<4, PROV, EPIV, false>), grid, dim3(256), tap_lds, st, g, a, pro, epi);    \
+        if ((g.Wl & 63) == 0) launch_tapgemm(tapgemm_kernel<4, PROV, EPIV, true>, grid, tap_lds, st, g, a, pro, epi);  \
+        else launch_tapgemm(tapgemm_kernel<4, PROV, EPIV, false>, grid, tap_lds, st, g, a, pro, epi);    \
     } while (0)
     const size_t tap_lds = LF_TAP_LDS_PER_TAP * g.ntaps;
     // the compiled-in data-gradient epilogues (mask / residual / BN-backward sums) carry no bias vector (NOBIAS): a launch

@@ -815,13 +815,13 @@ int lf_pointwise_bwd(const float* x, const float* gy, const float* w, float* gx,
         hipLaunchKernelGGL(pointwise_bwd_data_kernel, dim3(grid_for(npix, 4096)), dim3(256), 0, st, gy, w, gx, npix, (long)h * w_, C, K);
         LF_CHECK_LAUNCH("pointwise_bwd_data");
     }
-    if (gw) {
+    if (gw || gb) {       // weight and bias gradients are independent requests (a frozen weight with a trainable bias)
         LF_REQUIRE(scratch, "lf_pointwise_bwd: scratch missing");
         const int rows = lf_cdiv(npix, 256);
         float* brows = scratch + (long)rows * K * C;
         hipLaunchKernelGGL(pointwise_wgrad_kernel, dim3(rows), dim3(256), 0, st, x, gy, scratch, brows, npix, (long)h * w_, C, K, 256);
         LF_CHECK_LAUNCH("pointwise_wgrad");
-        LF_TRY(lf_rows_reduce_launch(scratch, rows, K * C, gw, 0, st));
+        if (gw) LF_TRY(lf_rows_reduce_launch(scratch, rows, K * C, gw, 0, st));
         if (gb) LF_TRY(lf_rows_reduce_launch(brows, rows, K, gb, 0, st));
     }
     return 0;

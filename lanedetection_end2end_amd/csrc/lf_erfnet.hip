@@ -408,13 +408,20 @@ int bn_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int npart
                               c.at(b.ash), c.st);
 }
 
-int forward_layers(const Ctx& c, const float* img) {
+int encoder_layers(const lf_erfnet_plan* P) {     // layers [0, n) = the encoder (everything before the first UpsamplerBlock)
+    int n = 0;
+    for (const Layer& L : P->layers) { if (L.kind == K_UP) break; ++n; }
+    return n;
+}
+
+int forward_layers(const Ctx& c, const float* img, int nlayers) {
     const lf_erfnet_plan* P = c.P;
     const int N = P->N;
     float* stat0 = c.at(P->off_stat0);
     float* stat1 = c.at(P->off_stat1);
     int layer_idx = 0;
     for (const Layer& L : P->layers) {
+        if (layer_idx >= nlayers) break;
         P->prof_layer = layer_idx++;
         const long npo = (long)N * L.Hout * L.Wout;
         if (L.kind == K_DOWN) {
@@ -544,7 +551,7 @@ Prep prep_for(const Ctx& c, const Layer& Lp) {
     return p;
 }
 
-int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float* g2) {
+int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float* g2, int nlayers) {
     // on entry g0 holds d loss / d (output of the last block), NHWC.  The three buffers rotate roles:
     // `in` = incoming gradient, X / Y = scratch; every layer leaves its result in one of them.
     const lf_erfnet_plan* P = c.P;
@@ -554,7 +561,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
     float* in = g0;
     bool prepped = false;        // `in` already masked by the layer's output ReLU, BN sums in stat0
     int prep_rows = 0;
-    for (int li = (int)P->layers.size() - 1; li >= 0; --li) {
+    for (int li = nlayers - 1; li >= 0; --li) {
         const Layer& L = P->layers[li];
         P->prof_layer = 100 + li;
         const long npo = (long)N * L.Hout * L.Wout;
@@ -691,16 +698,19 @@ extern "C" {
 // dropmask: device buffer of lf_erfnet_dropmask_floats() floats or NULL; head = 0 (output_conv) or 1
 // (output_conv2); logits out (N,Cout,H,W) NCHW; enc_out: optional NHWC->NCHW copy target is NOT
 // produced here (the encoder output stays in the workspace: lf_erfnet_export_encoder).
+// head = -1: ENCODER ONLY (Net.forward(only_encode=True), ERFNet.py:151-153): the decoder layers do not run -- their BatchNorm
+// running statistics stay untouched, as in the reference, where the decoder is never called -- and logits may be NULL.
 int lf_erfnet_forward(const lf_erfnet_plan* P, const float* img, const float* const* params_host,
                       const float* const* params_dev, float* const* running_host, const float* dropmask, int training,
                       int head, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
-    LF_REQUIRE(P && img && params_host && params_dev && running_host && logits && workspace, "lf_erfnet_forward: null pointer");
+    LF_REQUIRE(P && img && params_host && params_dev && running_host && (logits || head < 0) && workspace, "lf_erfnet_forward: null pointer");
     LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_forward: workspace too small");
-    LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_forward: head %d out of range", head);
+    LF_REQUIRE(head >= -1 && head < P->n_heads, "lf_erfnet_forward: head %d out of range", head);
     Ctx c{P, (float*)workspace, params_host, nullptr, running_host, dropmask, training, (hipStream_t)stream};
     c.s16 = P->precision == 2;
     LF_TRY(upload_and_pack(c, params_dev));
-    LF_TRY(forward_layers(c, img));
+    if (head < 0) return forward_layers(c, img, encoder_layers(P));
+    LF_TRY(forward_layers(c, img, (int)P->layers.size()));
     return lf_head_fwd(c.at(P->head_in), params_host[P->p_head_w[head]], params_host[P->p_head_b[head]], logits, P->N, P->H / 2,
                        P->W / 2, P->Cout + head, c.s16, c.st);   // output_conv2 has one more channel (ERFNet.py:125-126)
 }
@@ -710,17 +720,31 @@ int lf_erfnet_forward(const lf_erfnet_plan* P, const float* img, const float* co
 // training: the mode the forward ran in (0 = running statistics: BatchNorm backward is then the affine map's);
 // grads_host: n_params device pointers receiving d loss / d param (NULL entries are skipped:
 // encoder.output_conv, the unused head).  Gradients are WRITTEN, not accumulated.
+// head = -1: backward of the encoder-only forward: grad_encoder is the incoming gradient (required), grad_logits is ignored,
+// decoder parameters receive no gradient (their grads_host entries must be NULL).
 int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* grad_logits,
                        const float* grad_encoder, const float* const* params_host, float* const* grads_host,
                        const float* dropmask, int training, int head, void* workspace, size_t workspace_bytes, void* stream) {
-    LF_REQUIRE(P && img && grad_logits && params_host && grads_host && workspace, "lf_erfnet_backward: null pointer");
+    LF_REQUIRE(P && img && (grad_logits || head < 0) && params_host && grads_host && workspace, "lf_erfnet_backward: null pointer");
     LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_backward: workspace too small");
-    LF_REQUIRE(head >= 0 && head < P->n_heads, "lf_erfnet_backward: head %d out of range", head);
+    LF_REQUIRE(head >= -1 && head < P->n_heads, "lf_erfnet_backward: head %d out of range", head);
     Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, training, (hipStream_t)stream};
     c.g_enc = grad_encoder;
     c.s16 = P->precision == 2;
     LF_REQUIRE(!(c.s16 && grad_encoder), "lf_erfnet_backward: grad_encoder is not supported with bf16 tensors (mode 2)");
     float *gA = c.at(P->off_gA), *gB = c.at(P->off_gB), *gC = c.at(P->off_gC);
+    if (head < 0) {       // encoder only: the incoming gradient IS d loss / d (encoder output); the pass overwrites its buffers
+        LF_REQUIRE(grad_encoder, "lf_erfnet_backward: the encoder-only backward needs grad_encoder");
+        const int ne = encoder_layers(P);
+        const Layer& Le = P->layers[ne - 1];
+        const size_t bytes = (size_t)P->N * Le.Hout * Le.Wout * Le.Cout * sizeof(float);
+        if (hipMemcpyAsync(gA, grad_encoder, bytes, hipMemcpyDeviceToDevice, c.st) != hipSuccess)
+            return lf_fail("lf_erfnet_backward: copy of grad_encoder failed");
+        c.g_enc = nullptr;
+        LF_TRY(backward_layers(c, img, gA, gB, gC, ne));
+        if (!c.reduce_jobs.empty()) LF_TRY(lf_wgrad_reduce_batch_launch(c.reduce_jobs.data(), (int)c.reduce_jobs.size(), c.st));
+        return 0;
+    }
     const int h = P->H / 2, w = P->W / 2, K = P->Cout + head;
     const int pw = P->p_head_w[head], pb = P->p_head_b[head];
     if (grads_host[pw]) {
@@ -730,7 +754,7 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
         if (grads_host[pb]) LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, K, grads_host[pb], 0, c.st));
     }
     LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.s16, c.st));
-    LF_TRY(backward_layers(c, img, gA, gB, gC));
+    LF_TRY(backward_layers(c, img, gA, gB, gC, (int)P->layers.size()));
     if (!c.reduce_jobs.empty()) LF_TRY(lf_wgrad_reduce_batch_launch(c.reduce_jobs.data(), (int)c.reduce_jobs.size(), c.st));
     return 0;
 }

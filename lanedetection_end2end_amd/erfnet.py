@@ -146,7 +146,9 @@ class _BackboneFn(torch.autograd.Function):
         N, H, W = plan.shape
         dev = x.device
         ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
-        logits = torch.empty(N, net.out_channels + head, H, W, dtype=torch.float32, device=dev)
+        # head = -1: encoder only (only_encode=True): no decoder launches, no logits
+        logits = (torch.empty(N, net.out_channels + head, H, W, dtype=torch.float32, device=dev) if head >= 0 else
+                  torch.empty(0, dtype=torch.float32, device=dev))
         params = [p.detach() for p in params]
         for p in params:
             assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
@@ -156,9 +158,11 @@ class _BackboneFn(torch.autograd.Function):
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         running = net._ptrs.get("running", net._running_buffers())
         _lib.check(lib.lf_erfnet_forward(plan.handle, _lib.ptr(x), host, _lib.ptr(devarr), running,
-                                         _lib.ptr(dropmask), int(training), head, _lib.ptr(logits), _lib.ptr(ws),
-                                         plan.ws_bytes, _lib.stream()), "lf_erfnet_forward")
+                                         _lib.ptr(dropmask), int(training), head, _lib.ptr(logits) if head >= 0 else None,
+                                         _lib.ptr(ws), plan.ws_bytes, _lib.stream()), "lf_erfnet_forward")
         ctx.set_materialize_grads(False)
+        if head < 0:
+            ctx.mark_non_differentiable(logits)
         if net.export_encoder_output and ctx.precision == 2:
             # bf16 tensors: the in-place view is bf16 and takes no gradient (the --clas heads are an fp32 path)
             nenc = N * (H // 8) * (W // 8) * 128
@@ -180,8 +184,12 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, glogits, genc):
         lib = _lib.load()
-        if glogits is None:      # only the encoder output was used downstream
-            N, H, W = ctx.plan.shape
+        N, H, W = ctx.plan.shape
+        if ctx.head < 0:         # encoder-only forward: the incoming gradient is the encoder output's
+            glogits = None
+            if genc is None:
+                genc = torch.zeros(N, H // 8, W // 8, 128, dtype=torch.float32, device=ctx.x.device)
+        elif glogits is None:    # only the encoder output was used downstream
             glogits = torch.zeros(N, ctx.net.out_channels + ctx.head, H, W, dtype=torch.float32, device=ctx.x.device)
         if genc is not None:
             genc = genc.contiguous()
@@ -200,7 +208,8 @@ class _BackboneFn(torch.autograd.Function):
             else:
                 grads.append(None)
         ctx.net._flat_grad = flat
-        glogits = glogits.contiguous()
+        if glogits is not None:
+            glogits = glogits.contiguous()
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _lib.ptr(genc),
                                           ctx.net._ptrs.get("params", params), ctx.net._ptrs.get("grads", grads), _lib.ptr(ctx.dropmask), ctx.training,
@@ -235,7 +244,7 @@ class _PointwiseFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(wt) if ctx.needs_input_grad[1] else None
-        gb = torch.empty(K, dtype=torch.float32, device=x.device) if (gw is not None and ctx.needs_input_grad[2]) else None
+        gb = torch.empty(K, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[2] else None     # independent of gw
         scratch = torch.empty(lib.lf_pointwise_scratch_floats(N, h, w, C, K), dtype=torch.float32, device=x.device)
         _lib.check(lib.lf_pointwise_bwd(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(wt), _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), N, h, w,
                                         C, K, _lib.ptr(scratch), _lib.stream()), "lf_pointwise_bwd")
@@ -250,9 +259,9 @@ class Net(nn.Module):
     output itself (the decoder's second head is never built, :128-163).
 
     ``only_encode=True`` returns ``encoder.forward(input, predict=True)`` = ``output_conv`` (1x1, 128 -> num_classes) of the
-    encoder output, (N, num_classes, H/8, W/8) (ERFNet.py:86-95,151-153); the engine still runs its whole plan (the decoder's
-    work is discarded: the reference's training loops never take this branch), and the result is differentiable through the
-    encoder like the ``--clas`` heads' input.
+    encoder output, (N, num_classes, H/8, W/8) (ERFNet.py:86-95,151-153); the engine stops after the encoder (head = -1:
+    the decoder's BatchNorm running statistics and ``num_batches_tracked`` stay untouched, as in the reference), and the
+    result is differentiable through the encoder like the ``--clas`` heads' input.
 
     Deviations: ``encoder_output`` is a channels-last view of the engine's workspace (logical shape (N,128,H/8,W/8) as in
     the reference, differentiable: the ``--clas`` heads train through it); no gradient is produced for the input image.
@@ -309,6 +318,8 @@ class Net(nn.Module):
 
     def _used_param_mask(self, head):
         names = [n for n, _ in self.named_parameters()]
+        if head < 0:             # encoder only: no decoder parameter takes part (encoder.output_conv is a separate autograd node)
+            return [n.startswith("encoder.") and not n.startswith("encoder.output_conv.") for n in names]
         unused_head = "decoder.output_conv." if head == 1 else "decoder.output_conv2."
         return [not (n.startswith("encoder.output_conv.") or n.startswith(unused_head)) for n in names]
 
@@ -362,13 +373,14 @@ class Net(nn.Module):
             if self.precision == "bf16":
                 raise NotImplementedError("only_encode reads an fp32 encoder output: use precision 'fp32' or 'bf16_mfma'")
             self.export_encoder_output = True
+            head = -1                                 # the engine stops after the encoder: decoder BN statistics untouched
         try:
             logits, enc = _BackboneFn.apply(self, plan, x, head, self.training, dropmask, *params)
         finally:
             self.export_encoder_output = export
         if only_encode:
             if self.training:
-                torch._foreach_add_([m.num_batches_tracked for m in self._batchnorms()], 1)
+                torch._foreach_add_([m.num_batches_tracked for m in self.encoder.modules() if isinstance(m, nn.BatchNorm2d)], 1)
             return _PointwiseFn.apply(enc, self.encoder.output_conv.weight, self.encoder.output_conv.bias)
         if self.training:
             torch._foreach_add_([m.num_batches_tracked for m in self._batchnorms()], 1)

@@ -57,3 +57,14 @@ def relerr(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def tie_tolerant_err(a, b, tol):
+    """(fraction of elements further than tol * max|b| from b, relative L2 error).  For gradients that pass through ReLUs of
+    ~1e6 pre-activations: the smallest |pre-activation| of such a tensor is ~1e-6, inside fp32 rounding, so an fp32 forward may
+    take the other branch of ONE ReLU than the fp64 oracle; the gradient then differs on the receptive field of that element
+    (a 5x5 patch per 3x3 layer below it) and nowhere else.  A wrong kernel fails both numbers; a flipped tie moves neither."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    d = np.abs(a - b)
+    return float((d > tol * np.abs(b).max()).mean()), float(np.sqrt((d ** 2).sum() / max((b ** 2).sum(), 1e-300)))

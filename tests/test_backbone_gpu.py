@@ -249,6 +249,42 @@ def test_only_encode_predict_branch():
               "encoder.layers.2.bn1.weight", "encoder.initial_block.conv.weight"):
         assert relerr(g[k].grad.cpu(), Pd[k].grad) < 2e-4, k
     assert g["decoder.output_conv.weight"].grad is None or float(g["decoder.output_conv.weight"].grad.abs().max()) == 0.0
+    assert g["decoder.layers.1.bn1.weight"].grad is None        # the decoder does not run at all on this branch
+
+
+def test_only_encode_leaves_the_decoder_alone_and_bias_only_training():
+    """only_encode=True in TRAIN mode: the reference returns after the encoder, so the decoder's BatchNorm running statistics
+    and num_batches_tracked stay as they were (the engine stops after the encoder: head = -1); the encoder's advance.  And a
+    frozen encoder.output_conv.weight with a trainable bias still gets its bias gradient."""
+    N, H, W = 2, 64, 128
+    net, P = build()
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0
+    before = {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}
+    net.encoder.output_conv.weight.requires_grad_(False)
+    x = torch.from_numpy(inputs.images(N, H, W, seed=53))
+    y = net(x.cuda(), True, only_encode=True)
+    gy = torch.from_numpy(np.random.default_rng(4).standard_normal(tuple(y.shape)).astype(np.float32)).cuda()
+    (y * gy).sum().backward()
+    after = net.state_dict()
+    for k, v in before.items():
+        if k.startswith("decoder."):
+            assert torch.equal(after[k], v), k
+        elif "num_batches" in k:
+            assert int(after[k]) == int(v) + 1, k
+        elif k.endswith("running_mean") and k.startswith("encoder.layers.3."):
+            assert not torch.equal(after[k], v), k
+    assert net.encoder.output_conv.weight.grad is None
+    gb = net.encoder.output_conv.bias.grad
+    assert gb is not None and relerr(gb.cpu(), gy.sum((0, 2, 3)).cpu()) < 1e-5
+    # train-mode value vs the fp64 oracle's encoder (batch statistics)
+    Pd = erfnet_oracle.cast_params(P, torch.float64)
+    enc, _ = erfnet_oracle.erfnet_forward(x.double(), Pd, training=True)
+    yo = torch.nn.functional.conv2d(enc, Pd["encoder.output_conv.weight"], Pd["encoder.output_conv.bias"])
+    assert relerr(y.detach().cpu(), yo) < 1e-4
+    assert net.encoder.initial_block.conv.weight.grad is not None and net.decoder.output_conv.weight.grad is None
 
 
 def test_eval_mode_backward_is_the_affine_batchnorm():
