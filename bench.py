@@ -40,7 +40,8 @@ PEAK_HBM = 8.0e12                   # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s 
 # together with the commit it was measured at; None when the file is missing
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 CALIBRATION_FILE = os.path.join(ROOT, "profiles", "cpu_port_calibration.json")
-TIMED_BLOCKS = 5                    # the timed region = TIMED_BLOCKS blocks of --steps steps each; the median block is reported
+TIMED_BLOCKS = 5                    # the timed region = at least TIMED_BLOCKS blocks of --steps steps each; the median block is reported
+TIMED_REGION_S = 6.5                # ... and enough blocks to span this many seconds (an outside sampler with a 5 s period sees the GPU busy)
 
 
 def make_args(batch):
@@ -119,12 +120,12 @@ def cpu_baseline_and_parity(precision):
             times.append(time.perf_counter() - t0)
         return x, gt, out, times
     x4, gt4, o32, t4 = timed(4, 61, 8.0, 8)
-    _, _, _, t32 = timed(32, 161, 1.0, 2)
+    _, _, _, t32 = timed(32, 161, 60.0, 3)          # three steps of the headline's batch (~25 s each leg on 64 threads)
     cal = _load_json(CALIBRATION_FILE)
     base = {"value": round(4 / float(np.median(t4[1:] or t4)), 3), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "batch 4, 256x512, 2 lanes: fp32 backbone + fp64 fit and loss, fwd + bwd, %d steps (median of all but the "
                       "first); batch 32: %d steps" % (len(t4), len(t32)),
-            "batch32": {"value": round(32 / float(min(t32)), 3), "unit": "images/sec"},
+            "batch32": {"value": round(32 / float(np.median(t32)), 3), "unit": "images/sec", "steps": len(t32)},
             "port_over_reference": None if cal is None else
             {"ratio": round(cal["ratio_port_over_reference"], 3), "measured_on": "%s, %d threads, batch %d"
              % (cal["cpu"], cal["threads"], cal["batch"]), "source": "profiles/cpu_port_calibration.json"}}
@@ -160,6 +161,39 @@ def cpu_baseline_and_parity(precision):
               "ok": bool(tb[0] <= max(2 * tb[2], 1e-5) and tl[0] <= max(2 * tl[2], 1e-5) and
                          e2e_oracle.relerr(beta, c["beta"]) <= 1e-5)}
     return base, parity
+
+
+def miopen_baseline(B, R, steps=20, warmup=5):
+    """The reference's step on the vendor stack (PyTorch-ROCm eager: MIOpen convolutions and batch norm with
+    cudnn.benchmark = True, rocBLAS bmm / inverse; oracle/vendor_baseline.py) at the headline's batch, timed AFTER the
+    timed region like cpu_baseline -- what the reference's users get on this GPU by calling .cuda() (BEV/main.py:77-83,
+    SURVEY.md 8c).  A second, non-graded baseline; never imported by the package."""
+    from oracle import fit_oracle, inputs, vendor_baseline
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        P = vendor_baseline.trainable_params(4, "cuda")
+        x = torch.from_numpy(inputs.images(B, R, 2 * R, seed=100)).cuda()
+        gt = torch.from_numpy(inputs.bev_gt_params(B, seed=200)).cuda()
+        grid = vendor_baseline.bev_grid(R, "cuda")
+        zr = fit_oracle.zero_rows_of(R, 0.3)
+        for _ in range(warmup):
+            vendor_baseline.bev_step(x, P, gt, grid, zr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _, _ = vendor_baseline.bev_step(x, P, gt, grid, zr)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if not torch.isfinite(loss):
+            return {"value": None, "note": "non-finite loss on the vendor path"}
+        return {"value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
+                "kind": "port on PyTorch-ROCm / MIOpen (torch %s, cudnn.benchmark=True)" % torch.__version__,
+                "sample": "batch %d, %dx%d, 2 lanes, fp32, train mode with Dropout2d, fwd + bwd, optimizer excluded; "
+                          "%d + %d steps" % (B, R, 2 * R, warmup, steps)}
+    finally:
+        torch.backends.cudnn.benchmark = prev
+        torch.cuda.empty_cache()
 
 
 def run_epoch(a, rank, world, dist):
@@ -291,6 +325,10 @@ def main():
                          "whole training epoch over 3626 synthetic frames, 32 per GPU (uint8 frames -> on-device input pipeline "
                          "-> fwd -> loss -> bwd -> gradient all-reduce -> fused Adam); ignores --steps / --warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vendor-baseline", action="store_true", help="skip the PyTorch-ROCm / MIOpen leg (miopen_baseline)")
+    ap.add_argument("--min-seconds", type=float, default=TIMED_REGION_S,
+                    help="the timed region repeats its --steps-step block until it spans this many seconds (default 6.5: an outside "
+                         "sampler with a 5 s period then sees the GPU busy); the median block is reported")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rank plumbing check on a box without GPUs (tests/test_bench_contract_cpu.py): rendezvous over "
                          "gloo, the barrier-bracketed timing loop around a CPU stand-in step (the flat 8.25 MB gradient all-reduce), "
@@ -388,12 +426,22 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()                                   # one more untimed step, clocked: sizes the number of blocks
+    torch.cuda.synchronize()
+    est = max(time.perf_counter() - t0, 1e-4)
+    nblocks = max(TIMED_BLOCKS, min(200, int(np.ceil(a.min_seconds / (est * a.steps)))))
+    if world > 1:                            # every rank must run the same number of blocks (collectives inside)
+        nb = torch.tensor([nblocks], device="cuda")
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
+        nblocks = int(nb)
     statuses.clear()
-    # timed region: TIMED_BLOCKS blocks of exactly --steps steps, each bracketed by barrier + synchronize on both sides and
-    # reduced with MAX over the ranks; the MEDIAN block is the reported one (the region spans seconds, so that clocks are
-    # settled and an outside sampler sees the GPU busy)
+    # timed region: nblocks blocks of exactly --steps steps, each bracketed by barrier + synchronize on both sides and reduced
+    # with MAX over the ranks; the MEDIAN block is the reported one (the region spans >= 6.5 s, so that clocks are settled and
+    # an outside sampler with a 5 s period sees the GPU busy)
     blocks = []
-    for _ in range(TIMED_BLOCKS):
+    for _ in range(nblocks):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -410,6 +458,16 @@ def main():
             dtb = float(t)
         blocks.append(dtb)
     dt = float(np.median(blocks))
+    grad_check = None
+    if reducer is not None:
+        reducer.check()                      # the signature of the last all-reduce (inspected lazily inside the loop)
+        # debug field: every rank must hold bit-identical reduced gradients (two integer checksums of the bucket's bits)
+        bits = reducer.last_flat.view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 251 + 1)).sum()])
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        grad_check = {"ranks": world, "bucket_elements": int(reducer.last_flat.numel()),
+                      "bit_identical_across_ranks": bool(all(torch.equal(allc[0], c) for c in allc))}
     bad = int(torch.stack(statuses).abs().sum()) if statuses else 0
     if bad or not torch.isfinite(loss):
         raise SystemExit("bench: singular normal matrix / non-finite loss inside the timed region")
@@ -434,8 +492,12 @@ def main():
         dom = 0 if fam[0]["ms"] >= fam[1]["ms"] else 1
         d = fam[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        # family 0 runs on the bf16 matrix cores in --precision bf16 (the weight gradient stays fp32)
-        peak = PEAK_BF16_MFMA if (a.precision in ("bf16", "bf16_mfma") and dom == 0) else PEAK_FP32_MFMA
+        # matrix cores each family runs on: family 0 (conv forward + data gradient) uses the bf16 cores in both bf16 modes; the
+        # weight gradient uses them in mode "bf16" only (v_mfma_f32_16x16x16_bf16 on the raw bf16 tensors), fp32 in "bf16_mfma"
+        fam_peak = [PEAK_BF16_MFMA if a.precision in ("bf16", "bf16_mfma") else PEAK_FP32_MFMA,
+                    PEAK_BF16_MFMA if a.precision == "bf16" else PEAK_FP32_MFMA]
+        peak = fam_peak[dom]
+        step_peak = PEAK_BF16_MFMA if a.precision in ("bf16", "bf16_mfma") else PEAK_FP32_MFMA
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak / 1e12,
                     "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4),
                     # HBM-side bytes per launch of the family's representative launch (128-channel 3-tap conv, batch 32:
@@ -447,9 +509,11 @@ def main():
                     "avg_launch_us": round(1e3 * d["ms"] / max(d["launches"], 1), 2),
                     "launches_per_step": d["launches"] / psteps,
                     "families": {names[i]: {"ms_per_step": round(fam[i]["ms"] / psteps, 3),
-                                            "tflops": round(fam[i]["flops"] / max(fam[i]["ms"], 1e-9) / 1e9, 2)}
+                                            "tflops": round(fam[i]["flops"] / max(fam[i]["ms"], 1e-9) / 1e9, 2),
+                                            "peak_tflops": fam_peak[i] / 1e12}
                                  for i in range(2)},
-                    "whole_step_frac_of_conv_roofline": round(ips * wl["flop"] / world / PEAK_FP32_MFMA, 4),
+                    "whole_step_frac_of_conv_roofline": round(ips * wl["flop"] / world / step_peak, 4),
+                    "whole_step_roofline_peak_tflops": step_peak / 1e12,
                     # measured on this chip (tools/mfma_sustain.hip, profiles/r2_mfma_sustain.txt): a bare fp32 MFMA stream holds
                     # 156 TFLOP/s from 10 ms to 1.7 s, i.e. the datasheet peak above is the roof the kernels can be held to
                     "sustained_mfma_measured": 156.0}
@@ -459,16 +523,19 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": {"fp32": "f32", "fp32x9": "f32 (split x9)", "fp32x6": "f32 (split x6)", "bf16_mfma": "bf16 MFMA operands (fp32 accumulate, fp32 tensors); weight gradient f32",
-                         "bf16": "bf16 (MFMA operands + activation/gradient tensors; fp32 accumulate, weight gradient on "
-                                 "fp32 MFMA, fp32 parameters/statistics/fit)"}[a.precision],
+                         "bf16": "bf16 (MFMA operands + activation/gradient tensors; fp32 accumulate; weight gradient on the bf16 "
+                                 "matrix cores too, v_mfma_f32_16x16x16_bf16; fp32 parameters/statistics/fit)"}[a.precision],
                "data": "synthetic",
                "config": {"workload": "%s, batch %d per GPU, "
                                       "%s, train mode (BN batch stats, Dropout2d %s), fwd+bwd, optimizer excluded"
                                       % (wl["desc"], B, a.precision, "off" if a.no_dropout else "on"),
                           "global_batch": world * B, "parallelism": "dp%d" % world,
                           "grad_allreduce": ("flat fp32 bucket, %s over %d ranks" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else "none"},
-               "timed_blocks_ms_per_step": [round(1e3 * t / a.steps, 3) for t in blocks],
+               "timed_blocks_ms_per_step": [round(1e3 * t / a.steps, 3) for t in blocks[:12]],
+               "timed_blocks": len(blocks), "timed_region_s": round(float(sum(blocks)), 2),
                "roofline": roofline}
+        if grad_check is not None:
+            out["grad_allreduce_check"] = grad_check
         if a.precision in ("bf16", "bf16_mfma"):
             # the bf16 backbone is reported against BOTH roofs.  Algorithmic HBM bytes per step = every saved
             # activation written once and read back twice (next layer's operand / backward's mask + weight-gradient operand)
@@ -498,6 +565,10 @@ def main():
                                     "note": "same workload, precision mode fp32x9 (fp32 tensors and accumulation, exact "
                                             "products via bf16 x3 splits on the bf16 matrix cores; weight gradient on the "
                                             "fp32 cores); parity tests hold it to the fp32 tolerances"}
+        if world == 1 and not a.no_vendor_baseline and a.workload == "bev":
+            out["miopen_baseline"] = miopen_baseline(B, R)
+            if out["miopen_baseline"].get("value"):
+                out["miopen_baseline"]["hip_over_miopen"] = round(ips / out["miopen_baseline"]["value"], 2)
         if world == 1 and not a.no_cpu_baseline and a.workload == "bev":
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(a.precision)
     if world > 1:
@@ -505,6 +576,10 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+        if out.get("parity") is not None and not out["parity"]["ok"]:
+            sys.stderr.write("bench: PARITY FAILED -- the HIP path is further from the fp64 CPU run than the criterion allows: %s\n"
+                             % json.dumps(out["parity"]))
+            sys.exit(3)
 
 
 if __name__ == "__main__":

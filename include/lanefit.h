@@ -94,6 +94,11 @@ int lf_gels_bwd(const float* A, const float* b, const float* x, const double* zi
 int lf_area_loss(const void* beta, long beta_stride, const void* gt, int N, int order,
                  int weight_funct, int dtype, void* loss, void* grad, void* stream);
 
+/* MSE_Loss.forward -- BEV/Loss_crit.py:137-150 (BP/Loss_crit.py:147-160): nn.MSELoss() of params.squeeze(-1) against
+ * gt_params = mean over ALL n = N * (order + 1) elements of the squared difference (--loss_policy mse).  params, gt: n
+ * contiguous elements of dtype (LF_F32 / LF_F64); loss out: 1 element; grad out: n elements = 2 (params - gt) / n. */
+int lf_mse_loss(const void* params, const void* gt, long n, int dtype, void* loss, void* grad, void* stream);
+
 /* backprojection_loss.forward -- BP/Loss_crit.py:202-218 (constants of :166-200 passed in).
  *   beta (N,order+1) fp64 (stride beta_stride), x_gt/valid (N,S) fp64, Y (S,order+1) fp64,
  *   y_prime (S) fp64, minv_host: 9 doubles (row-major M^-1) read on the HOST at call time.

@@ -30,6 +30,7 @@ def _declare(lib):
         "lf_gels_fwd": (I, [P, P, I, L, I, P, P, P, P, P]),
         "lf_gels_bwd": (I, [P, P, P, P, P, I, L, I, P, P, P]),
         "lf_area_loss": (I, [P, L, P, I, I, I, I, P, P, P]),
+        "lf_mse_loss": (I, [P, P, L, I, P, P, P]),
         "lf_backproj_loss": (I, [P, L, P, P, P, P, P, I, I, I, P, P, P, P]),
         "lf_ce2d_fwd": (I, [P, P, P, I, I, I, I, P, P, P]),
         "lf_ce2d_bwd": (I, [P, P, P, I, I, I, I, P, P, P, P]),

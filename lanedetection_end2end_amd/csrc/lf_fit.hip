@@ -741,6 +741,38 @@ extern "C" int lf_area_loss(const void* beta, long beta_stride, const void* gt, 
     return 0;
 }
 
+namespace {
+// MSE_Loss: mean over all n elements of (p - q)^2 and its gradient 2 (p - q) / n; one block, fp64 accumulation
+template <typename T>
+__global__ __launch_bounds__(256) void mse_loss_kernel(const T* __restrict__ p, const T* __restrict__ q, long n,
+                                                      T* __restrict__ loss, T* __restrict__ grad) {
+    __shared__ double sw[4];
+    double acc = 0.0;
+    const double inv = 1.0 / (double)n;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const double d = (double)p[i] - (double)q[i];
+        acc += d * d;
+        grad[i] = (T)(2.0 * d * inv);
+    }
+    acc = lf_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (T)(((sw[0] + sw[1]) + (sw[2] + sw[3])) * inv);
+}
+}  // namespace
+
+extern "C" int lf_mse_loss(const void* params, const void* gt, long n, int dtype, void* loss, void* grad, void* stream) {
+    LF_REQUIRE(params && gt && loss && grad && n > 0, "lf_mse_loss: bad arguments");
+    if (dtype == LF_F64)
+        hipLaunchKernelGGL(mse_loss_kernel<double>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)params, (const double*)gt, n,
+                           (double*)loss, (double*)grad);
+    else
+        hipLaunchKernelGGL(mse_loss_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)params, (const float*)gt, n,
+                           (float*)loss, (float*)grad);
+    LF_CHECK_LAUNCH("mse_loss");
+    return 0;
+}
+
 extern "C" int lf_backproj_loss(const double* beta, long beta_stride, const double* x_gt, const double* valid,
                                 const double* Y, const double* y_prime, const double* minv_host, int N, int S,
                                 int order, double* loss, double* x_cal_valid, double* grad, void* stream) {

@@ -24,70 +24,109 @@ def broadcast_parameters(module, src=0, group=None):
             t.copy_(f)
 
 
-class FlatGradAllReduce:
-    """Average ``p.grad`` over the ranks in ONE all-reduce.
+TAIL = 8          # trailing fp32 slots of the flat bucket reserved for the reducer (signature of the active parameter set)
 
-    Parameters whose grad is None on this rank (``encoder.output_conv`` never gets one, ERFNet.py:84,92-93;
-    the unused head when ``pretrained``) are skipped.  The set of participating parameters may CHANGE between steps -- the
-    reference's pretrained schedule flips ``end_to_end`` mid-run (BEV/main.py get_flags): ``decoder.output_conv2`` stops
-    and ``decoder.output_conv`` starts receiving gradients -- but it must change identically on every rank (all ranks run
-    the same schedule).  That is verified, not assumed: each call first all-reduces (MAX) a two-word signature of the local
-    set; ranks that disagree all raise instead of hanging in a size-mismatched collective.
+
+class FlatGradAllReduce:
+    """Average ``p.grad`` over the ranks in ONE all-reduce of a FIXED-SIZE bucket.
+
+    The bucket always spans ALL parameters (in order) plus ``TAIL`` slots: a parameter whose grad is None on this rank
+    (``encoder.output_conv`` never gets one, ERFNet.py:84,92-93; the unused head when ``pretrained``) contributes zeros and
+    keeps ``grad = None``.  The set of parameters WITH a gradient may change between steps -- the reference's pretrained
+    schedule flips ``end_to_end`` mid-run (BEV/main.py get_flags): ``decoder.output_conv2`` stops and ``decoder.output_conv``
+    starts receiving gradients -- but it must change identically on every rank.  That is verified, not assumed, and WITHOUT a
+    second collective or a host sync in the step: two small hashes (h, h^2 pairs) of the local set ride in the tail of the same
+    all-reduce -- the ranks agree iff mean(h^2) == mean(h)^2 -- and the reduced tail is inspected at the START OF THE NEXT
+    call (or by ``check()``), when the collective that produced it has long completed: the host runs a full step ahead.
+    Because the bucket size never depends on the active set, a disagreement cannot produce a size-mismatched collective.
+    On RCCL the reduction is ``ReduceOp.AVG`` (no separate divide pass); gloo (CPU tests) sums and divides.
     """
 
     def __init__(self, params, group=None, flat_provider=None):
-        """``flat_provider``: optional callable returning one contiguous tensor of which every ``p.grad`` is a
-        view, in parameter order (``erfnet.Net.flat_grad``): then the all-reduce runs in place on it, without
-        the flatten / unflatten copies."""
+        """``flat_provider``: optional callable returning one contiguous fp32 tensor of ``sum(p.numel()) + TAIL`` elements in
+        which every non-None ``p.grad`` is a view at the parameter's running offset (``erfnet.Net.flat_grad``): the
+        all-reduce then runs in place on it, without flatten / unflatten copies."""
         self.params = list(params)
         self.group = group
         self.active = None
         self.flat_provider = flat_provider
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.total = off
+        self._pending = None          # reduced tail of the previous call, not yet inspected
+        self._sig_cache = (None, None)
+        self.last_flat = None         # the bucket of the last call (tests: ranks must hold identical bits after the reduce)
 
-    def _agree(self, active):
-        """All ranks must hold gradients for the same parameters: MAX over ranks of (h, -h) is (h, -h) only if every h is equal."""
-        h = 0
+    @staticmethod
+    def _hashes(active):
+        h1 = h2 = 0
         for i in active:
-            h = (h * 1000003 + i + 1) % 2147483629
-        h = h * 4096 + (len(active) % 4096)
-        dev = self.params[0].device if self.params else torch.device("cpu")
-        sig = torch.tensor([h, -h], dtype=torch.int64, device=dev)
-        dist.all_reduce(sig, op=dist.ReduceOp.MAX, group=self.group)
-        if int(sig[0]) != -int(sig[1]):
-            raise RuntimeError("data-parallel ranks disagree on the set of parameters with gradients (%d tensors here)" % len(active))
+            h1 = (h1 * 31 + i + 1) % 1021
+            h2 = (h2 * 37 + i + 7) % 1019
+        return float(h1), float(h2), float(len(active) % 1024)
 
-    def _in_place_flat(self, grads):
+    def _signature(self, active, device):
+        """Device tensor [1, h1, h1^2, h2, h2^2, n, n^2, 0] for this active set (cached: the set rarely changes)."""
+        key = (tuple(active), device)
+        if self._sig_cache[0] != key:
+            h1, h2, n = self._hashes(active)
+            self._sig_cache = (key, torch.tensor([1.0, h1, h1 * h1, h2, h2 * h2, n, n * n, 0.0], dtype=torch.float32, device=device))
+        return self._sig_cache[1]
+
+    def check(self):
+        """Inspect the signature the PREVIOUS all-reduce carried (one small D2H read of a long-finished result).  Raises on
+        every rank when the ranks reduced different parameter sets."""
+        if self._pending is None:
+            return
+        t, world = self._pending
+        self._pending = None
+        v = [float(x) for x in t.tolist()]
+        scale = 1.0 if abs(v[0] - 1.0) < 1e-3 else float(world)       # AVG leaves the leading 1 at 1, SUM at world
+        m = [x / scale for x in v]
+        for k in (1, 3, 5):
+            if abs(m[k + 1] - m[k] * m[k]) > 0.01:
+                raise RuntimeError("data-parallel ranks disagree on the set of parameters with gradients (%d tensors here)"
+                                   % len(self.active or []))
+
+    def _in_place_flat(self, grads, active):
         flat = self.flat_provider() if self.flat_provider is not None else None
-        if flat is None or flat.numel() != sum(g.numel() for g in grads):
+        if flat is None or flat.numel() != self.total + TAIL or flat.dtype != torch.float32:
             return None
-        ptr, esz = flat.data_ptr(), flat.element_size()
-        for g in grads:                       # every gradient must sit exactly at its running offset
-            if g.data_ptr() != ptr or not g.is_contiguous():
+        base, esz = flat.data_ptr(), flat.element_size()
+        for g, i in zip(grads, active):       # every gradient must sit exactly at its parameter's offset
+            if g.data_ptr() != base + self.offsets[i] * esz or not g.is_contiguous():
                 return None
-            ptr += g.numel() * esz
         return flat
 
     def __call__(self):
         world = dist.get_world_size(self.group)
+        self.check()                          # last step's signature (its collective finished a step ago)
         active = [i for i, p in enumerate(self.params) if p.grad is not None]
         self.active = active
-        if world == 1:
-            return 0
-        self._agree(active)
-        if not active:
+        if world == 1 or not self.params:
             return 0
         grads = [self.params[i].grad for i in active]
-        flat = self._in_place_flat(grads)
-        if flat is not None:
+        flat = self._in_place_flat(grads, active) if active else None
+        in_place = flat is not None
+        if not in_place:
+            dev = grads[0].device if grads else self.params[0].device
+            flat = torch.zeros(self.total + TAIL, dtype=torch.float32, device=dev)
+            for g, i in zip(grads, active):
+                flat[self.offsets[i]: self.offsets[i] + g.numel()].copy_(g.reshape(-1))
+        flat[self.total:].copy_(self._signature(active, flat.device))
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)        # RCCL: sum and scale in the collective
+        else:
             dist.all_reduce(flat, group=self.group)
             flat.div_(world)
-            return flat.numel()
-        flat = _flatten_dense_tensors(grads)
-        dist.all_reduce(flat, group=self.group)
-        flat.div_(world)
-        for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
-            g.copy_(f)
-        return flat.numel()
+        self._pending = (flat[self.total:].clone(), world)
+        self.last_flat = flat
+        if not in_place:
+            for g, i in zip(grads, active):
+                g.copy_(flat[self.offsets[i]: self.offsets[i] + g.numel()].view_as(g))
+        return sum(g.numel() for g in grads)
 
 
 def epoch_batches(n_items, per_rank_batch, rank=0, world=1, seed=0, epoch=0, shuffle=True):

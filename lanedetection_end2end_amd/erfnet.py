@@ -199,14 +199,24 @@ class _BackboneFn(torch.autograd.Function):
         # all parameter gradients are views of ONE flat buffer (module order): a data-parallel run all-reduces
         # it in place, with no flatten / copy-back kernels (dp.FlatGradAllReduce picks it up via flat_grad())
         want = [bool(n and u) for n, u in zip(needs, used)]
-        flat = torch.empty(sum(p.numel() for p, w in zip(params, want) if w), dtype=torch.float32, device=params[0].device)
-        grads, off = [], 0
+        # The flat buffer always spans ALL parameters (module order) plus dp.TAIL reducer slots, so its size never depends on
+        # which parameters take part: unused ones (encoder.output_conv, the other head) leave zero-filled holes and keep
+        # grad = None; the data-parallel bucket is this very buffer (dp.FlatGradAllReduce: fixed-size collective).
+        from .dp import TAIL
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total + TAIL, dtype=torch.float32, device=params[0].device)
+        grads, off, hole = [], 0, None
         for p, w in zip(params, want):
             if w:
                 grads.append(flat[off: off + p.numel()].view(p.shape))
-                off += p.numel()
+                if hole is not None:
+                    flat[hole: off].zero_()
+                    hole = None
             else:
                 grads.append(None)
+                hole = off if hole is None else hole
+            off += p.numel()
+        flat[(total if hole is None else hole):].zero_()          # trailing hole + the reducer's tail
         ctx.net._flat_grad = flat
         if glogits is not None:
             glogits = glogits.contiguous()

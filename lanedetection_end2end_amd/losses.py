@@ -62,14 +62,15 @@ class Area_Loss(nn.Module):
 
 
 class MSE_Loss(nn.Module):
-    """MSE on curve parameters (BEV/Loss_crit.py:137-150) -- "next" row, plain torch."""
+    """``--loss_policy mse``: ``nn.MSELoss()`` of ``params.squeeze(-1)`` against ``gt_params`` -- the mean over all
+    N x (order + 1) elements (BEV/Loss_crit.py:137-150, BP/Loss_crit.py:147-160); ``forward(params, gt_params, compute=True)``.
+    One launch for the loss and its gradient (``lf_mse_loss``); like ``nn.MSELoss`` it wants equal shapes after the squeeze."""
 
     def __init__(self, options=None):
         super().__init__()
-        self.loss_crit = nn.MSELoss()
 
     def forward(self, params, gt_params, compute=True):
-        return self.loss_crit(params.squeeze(-1), gt_params)
+        return ops.MSELossFn.apply(params.squeeze(-1), gt_params)
 
 
 class CrossEntropyLoss2d(nn.Module):
@@ -80,12 +81,28 @@ class CrossEntropyLoss2d(nn.Module):
         super().__init__()
         w = [1.0] + [float(weight)] * nclasses if seg else [1.0] * (nclasses + 1)
         self.register_buffer("weights", torch.tensor(w, dtype=torch.float32), persistent=False)
-        self.check_targets = True       # raise on a label outside [0, C) like nn.NLLLoss (one D2H sync per call)
+        # A label outside [0, C) raises like nn.NLLLoss's device assert does -- and, like it, not inside the offending call:
+        # the kernel counts such labels (they carry weight 0), the count of call k is read at the START of call k + 1 (or by
+        # flush()), when it has long been computed, so the loss adds no host sync to the step.  "always": read it in the call
+        # itself (one D2H sync per step); False: never (the count stays in ops.CrossEntropy2dFn.last_acc[2]).
+        self.check_targets = True
+        self._pending = None
+
+    def flush(self):
+        """Raise now if the previous call saw a label outside [0, C)."""
+        pend, self._pending = self._pending, None
+        if pend is not None and float(pend[0][2]) != 0.0:
+            raise RuntimeError("cross entropy: %d target value(s) outside [0, %d)" % (int(pend[0][2]), pend[1]))
 
     def forward(self, inputs, targets):
         if targets.dim() == 4:
             targets = targets[:, 0, :, :]
-        return ops.CrossEntropy2dFn.apply(inputs, targets.long(), self.weights, self.check_targets)
+        if self.check_targets:
+            self.flush()
+        loss = ops.CrossEntropy2dFn.apply(inputs, targets.long(), self.weights, self.check_targets == "always")
+        if self.check_targets:
+            self._pending = (ops.CrossEntropy2dFn.last_acc, inputs.shape[1])
+        return loss
 
 
 class backprojection_loss(nn.Module):

@@ -99,6 +99,29 @@ class AreaLossFn(torch.autograd.Function):
         return (grad * gout).view(ctx.pshape), None, None, None
 
 
+class MSELossFn(torch.autograd.Function):
+    """mean((params - gt)^2) over all elements and its gradient in one launch (lf_mse_loss)."""
+
+    @staticmethod
+    def forward(ctx, params, gt):
+        lib = _lib.load()
+        p = params.contiguous()
+        q = gt.to(p.dtype).contiguous()
+        if p.dtype not in (torch.float32, torch.float64) or p.shape != q.shape:
+            raise RuntimeError("MSE_Loss: params %s %s vs gt %s" % (tuple(p.shape), p.dtype, tuple(q.shape)))
+        loss = torch.empty((), dtype=p.dtype, device=p.device)
+        grad = torch.empty_like(p)
+        _lib.check(lib.lf_mse_loss(_lib.ptr(p), _lib.ptr(q), p.numel(), 1 if p.dtype == torch.float64 else 0, _lib.ptr(loss),
+                                   _lib.ptr(grad), _lib.stream()), "lf_mse_loss")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return grad * gout, None
+
+
 class BackprojLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, params, x_gt, valid, Y, y_prime, minv):

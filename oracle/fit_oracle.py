@@ -251,6 +251,14 @@ def gels_backward(A, b, x, AtA, grad_out):
 # ----------------------------------------------------------------------------
 
 
+def mse_loss(params, gt):
+    """``MSE_Loss.forward`` -- BEV/Loss_crit.py:137-150: ``nn.MSELoss()(params.squeeze(-1), gt_params)`` = the mean of the
+    squared difference over ALL elements.  Returns (loss, d loss / d params) with the gradient in params' shape."""
+    p = np.asarray(params, dtype=np.float64)
+    d = p.reshape(len(p), -1) - np.asarray(gt, dtype=np.float64)
+    return float((d ** 2).mean()), (2.0 * d / d.size).reshape(p.shape)
+
+
 def area_loss(beta, gt, order=2, weight_funct="none", t=0.7):
     """``Area_Loss.forward`` -- BEV/Loss_crit.py:98-134.  beta (N,d+1[,1]), gt (N,d+1).
 

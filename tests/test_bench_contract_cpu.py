@@ -60,9 +60,7 @@ def test_single_rank_dry_run():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    path = os.path.join(ROOT, "profiles", "r2_bench.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r1_bench.json")
+    path = next(p for p in (os.path.join(ROOT, "profiles", "r%d_bench.json" % r) for r in (3, 2, 1)) if os.path.exists(p))
     d = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):

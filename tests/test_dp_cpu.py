@@ -49,21 +49,38 @@ def _worker(rank, world, port, out):
     net.decoder.output_conv.weight.grad = saved
     # in-place path: gradients that are views of one flat buffer are reduced without copies
     act = [p for nme, p in net.named_parameters() if not nme.startswith("encoder.output_conv")]
-    flat = torch.full((sum(p.numel() for p in act),), float(rank + 1))
+    # (the bucket spans ALL parameters + dp.TAIL slots: the parameters without a gradient are zero-filled holes)
+    allp = list(net.parameters())
+    total = sum(p.numel() for p in allp)
+    flat = torch.zeros(total + dp.TAIL)
     off = 0
-    for p in act:
-        p.grad = flat[off: off + p.numel()].view(p.shape)
+    for nme, p in net.named_parameters():
+        if not nme.startswith("encoder.output_conv"):
+            flat[off: off + p.numel()] = float(rank + 1)
+            p.grad = flat[off: off + p.numel()].view(p.shape)
+        else:
+            p.grad = None
         off += p.numel()
     red2 = dp.FlatGradAllReduce(net.parameters(), flat_provider=lambda: flat)
-    assert red2._in_place_flat([p.grad for p in act]) is flat
+    active = [i for i, p in enumerate(allp) if p.grad is not None]
+    assert red2._in_place_flat([allp[i].grad for i in active], active) is flat
     red2()
-    ok &= bool(torch.allclose(flat, torch.full_like(flat, 1.5))) and act[3].grad.data_ptr() >= flat.data_ptr()
-    # a rank-dependent active set is detected on EVERY rank (signature all-reduce), nobody hangs in a mismatched collective
+    red2.check()
+    ok &= bool(torch.allclose(torch.cat([p.grad.reshape(-1) for p in act]), torch.full((sum(p.numel() for p in act),), 1.5)))
+    ok &= act[3].grad.data_ptr() >= flat.data_ptr() and red2.last_flat is flat
+    # both ranks hold bit-identical buckets after the reduce
+    mine = flat.clone()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    ok &= bool(torch.equal(both[0], both[1]))
+    # a rank-dependent active set is detected on EVERY rank -- by the signature riding in the SAME fixed-size collective (no
+    # size mismatch, nobody hangs), reported when the reduced tail is inspected: at the next call, or by check()
     failed = False
     if rank == 0:
         net.encoder.output_conv.weight.grad = torch.zeros_like(net.encoder.output_conv.weight)
+    reducer()                                           # returns: the host does not wait for the collective
     try:
-        reducer()
+        reducer.check()
     except RuntimeError:
         failed = True
     out.put((rank, same_params, ok, n, n2, failed, len(names)))

@@ -215,9 +215,18 @@ def test_cross_entropy(lf, golden_fit):
     # a label outside [0, C) raises like nn.NLLLoss does (instead of reading the weight table out of bounds) ...
     bad = tt.copy()
     bad[0, 3, 5] = 255
+    # -- asynchronously, like torch's device assert: the call returns, the NEXT call (or flush()) reports it; no host sync
+    # inside the step
+    crit(dev(zz), dev(bad))
+    with pytest.raises(RuntimeError):
+        crit.flush()
+    crit(dev(zz), dev(bad))
+    with pytest.raises(RuntimeError):
+        crit(dev(zz), dev(tt))
+    crit.check_targets = "always"
     with pytest.raises(RuntimeError):
         crit(dev(zz), dev(bad))
-    # ... and with the check deferred it is counted and carries weight 0 in loss and gradient
+    # ... and with the check off it is counted and carries weight 0 in loss and gradient
     crit.check_targets = False
     z3 = dev(zz).requires_grad_(True)
     L3 = crit(z3, dev(bad))
@@ -368,3 +377,28 @@ def test_fused_optimizers_step_load_step(kind):
         assert float((a - b).abs().max()) < 3e-6 * float(b.abs().max())
     if kind == "adam":
         assert oa.state[pa[0]]["step"] == 6
+
+
+@pytest.mark.parametrize("tree", ["bev", "bp"])
+@pytest.mark.parametrize("D,dtype,tol", [(3, torch.float32, 2e-6), (4, torch.float64, 1e-13)])
+def test_mse_loss_policy(tree, D, dtype, tol):
+    """--loss_policy mse (BEV/Loss_crit.py:52-53,137-150): MSE_Loss through define_loss_crit of either tree == the real
+    reference's value and gradient (tests/golden/mse.npz), one launch (lf_mse_loss)."""
+    import os
+    from argparse import Namespace
+    from conftest import GOLDEN
+    from oracle.gen_golden_mse import mse_inputs
+    mod = __import__("lanedetection_end2end_amd.%s.Loss_crit" % tree, fromlist=["define_loss_crit"])
+    opts = Namespace(loss_policy="mse", order=D - 1, weight_funct="none", weight_seg=30, nclasses=2, no_cuda=False, resize=256,
+                     no_mapping=False)
+    crit, _ = mod.define_loss_crit(opts)
+    assert type(crit).__name__ == "MSE_Loss"
+    G = np.load(os.path.join(GOLDEN, "mse.npz"))
+    p, g = mse_inputs(D)
+    pt = torch.from_numpy(p).to(dtype).cuda().requires_grad_(True)
+    L = crit(pt, torch.from_numpy(g).to(dtype).cuda())
+    (3.0 * L).backward()                                    # the upstream factor reaches the gradient
+    tag = "f64"
+    assert abs(float(L) - float(G["%s_d%d_%s_loss" % (tree, D, tag)])) < tol * max(float(G["%s_d%d_%s_loss" % (tree, D, tag)]), 1e-30) * 10
+    assert relerr(pt.grad.cpu().numpy() / 3.0, G["%s_d%d_%s_grad" % (tree, D, tag)]) < tol * 10
+    assert pt.grad.shape == pt.shape

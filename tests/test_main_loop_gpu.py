@@ -1,0 +1,122 @@
+"""The reference's training-loop body executed on the mirror (Missing #5).
+
+The reference itself is absent on the GPU box, so its main.py cannot run here; this is a replica of the statement sequence of
+BEV/main.py:200-266 -- same import names through the path arrangement of tools/run_reference_main.py (the mirrored tree first
+on sys.path: ``from Networks.LSQ_layer import Net``, ``from Loss_crit import define_loss_crit, polynomial``), a stub loader
+yielding the loader's 6-tuples, ``model(input, end_to_end)`` -> per-lane ``criterion`` -> ``loss.item()`` -> ``zero_grad /
+backward / step``, the ``except RuntimeError: continue`` skip of a singular batch, the --clas branch, and the exact-area metric
+on ``.cpu()`` copies."""
+import importlib
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def bev_tree_on_path():
+    tree = os.path.join(ROOT, "lanedetection_end2end_amd", "bev")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "Networks" or k.startswith("Networks.") or k == "Loss_crit"}
+    sys.path.insert(0, tree)
+    try:
+        yield
+    finally:
+        sys.path.remove(tree)
+        for k in [k for k in sys.modules if k == "Networks" or k.startswith("Networks.") or k == "Loss_crit"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+class AverageMeter:          # BEV/Networks/utils.py AverageMeter, the four lines the loop uses
+    def __init__(self):
+        self.sum, self.count = 0.0, 0
+
+    def update(self, val, n=1):
+        self.sum += val * n
+        self.count += n
+
+
+@pytest.mark.parametrize("clas", [False, True])
+def test_bev_main_loop_body(bev_tree_on_path, clas):
+    Net = importlib.import_module("Networks.LSQ_layer").Net              # BEV/main.py:24
+    Loss_crit = importlib.import_module("Loss_crit")                      # BEV/main.py:23
+    define_loss_crit, polynomial = Loss_crit.define_loss_crit, Loss_crit.polynomial
+    from lanedetection_end2end_amd.optim import define_optim             # same signature as Networks.utils.define_optim
+    N, R = 2, 64
+    args = Namespace(batch_size=N, nclasses=2, resize=R, end_to_end=True, mod="erfnet", layers=18, channels_in=3, pretrained=False,
+                     pool=True, activation_layer="square", no_cuda=False, order=2, reg_ls=0.0, use_cholesky=False,
+                     mask_percentage=0.3, clas=clas, loss_policy="area", weight_funct="none", weight_seg=30, optimizer="adam",
+                     learning_rate=1e-4, weight_decay=0.0, clip_grad_norm=0, weight_fit=1.0, weight_class=1.0)
+    torch.manual_seed(3)
+    model = Net(args)                                                      # main.py:74
+    if not args.no_cuda:
+        model = model.cuda()                                               # main.py:77-83
+    optimizer = define_optim(args.optimizer, model.parameters(), args.learning_rate, args.weight_decay)   # main.py:80-81
+    criterion, criterion_seg = define_loss_crit(args)                      # main.py:87
+    criterion_line_class = nn.CrossEntropyLoss().cuda()                    # main.py:88
+    criterion_horizon = nn.BCEWithLogitsLoss().cuda()                      # main.py:89
+    rng = np.random.default_rng(11)
+
+    def loader(nbatches):                                                  # the 6-tuple of Load_Data_new.__getitem__ batches
+        for i in range(nbatches):
+            yield (torch.from_numpy(inputs.images(N, R, 2 * R, seed=300 + i)), torch.zeros(N, R, 2 * R, dtype=torch.int64),
+                   torch.from_numpy(inputs.bev_gt_params(N, seed=400 + i)), torch.arange(N) + i * N,
+                   torch.from_numpy(rng.integers(0, 3, (N, 4))), torch.from_numpy((rng.uniform(0, 1, (N, R)) > 0.5).astype(np.float32)))
+
+    losses, exact_area = AverageMeter(), AverageMeter()
+    model.train()                                                          # main.py:197
+    skipped, stepped = 0, 0
+    w0 = model.net.encoder.initial_block.conv.weight.detach().clone()
+    for i, (input, gt, params, idx, gt_line, gt_horizon) in enumerate(loader(4)):
+        if not args.no_cuda:
+            input, params = input.cuda(non_blocking=True), params.cuda(non_blocking=True)
+            input = input.float()
+        assert params.size(1) == 4
+        gt0, gt1, gt2, gt3 = params[:, 0, :], params[:, 1, :], params[:, 2, :], params[:, 3, :]
+        if i == 1:          # a batch whose weight maps vanish: singular normal matrix -> RuntimeError -> skipped (main.py:216-219)
+            keep = (model.net.decoder.output_conv.weight.detach().clone(), model.net.decoder.output_conv.bias.detach().clone())
+            with torch.no_grad():
+                model.net.decoder.output_conv.weight.zero_()
+                model.net.decoder.output_conv.bias.zero_()
+        try:
+            beta0, beta1, beta2, beta3, weightmap_zeros, M, output_net, outputs_line, outputs_horizon = model(input, args.end_to_end)
+        except RuntimeError as e:
+            assert i == 1, e
+            skipped += 1
+            with torch.no_grad():
+                model.net.decoder.output_conv.weight.copy_(keep[0])
+                model.net.decoder.output_conv.bias.copy_(keep[1])
+            continue
+        assert beta2 is None and beta3 is None and tuple(M.shape) == (N, 3, 3)
+        loss = criterion(beta0, gt0) + criterion(beta1, gt1)                # main.py:223
+        if args.clas:                                                       # main.py:246-253
+            gt_horizon, gt_line = gt_horizon.cuda(non_blocking=True), gt_line.cuda(non_blocking=True)
+            _, line_pred = torch.max(outputs_line, 1)
+            loss_horizon = criterion_horizon(outputs_horizon, gt_horizon)
+            loss_line = criterion_line_class(outputs_line, gt_line)
+            loss = loss * args.weight_fit + (loss_line + loss_horizon) * args.weight_class
+            assert line_pred.shape == (N, 4)
+        else:
+            assert outputs_line is None and outputs_horizon is None
+        losses.update(loss.item(), input.size(0))                          # main.py:257
+        optimizer.zero_grad()                                               # main.py:264-266
+        loss.backward()
+        optimizer.step()
+        stepped += 1
+        with torch.no_grad():                                               # main.py:273-280: exact area on .cpu() copies
+            trap_left = polynomial(beta0.cpu()).trapezoidal(polynomial(gt0.cpu()))
+            trap_right = polynomial(beta1.cpu()).trapezoidal(polynomial(gt1.cpu()))
+            exact_area.update(((trap_left + trap_right) / 2).mean().item(), input.size(0))
+    assert skipped == 1 and stepped == 3 and losses.count == 3 * N
+    assert np.isfinite(losses.sum) and np.isfinite(exact_area.sum) and exact_area.sum > 0
+    assert not torch.equal(model.net.encoder.initial_block.conv.weight.detach(), w0)       # the optimizer moved the weights
+    assert all(torch.isfinite(p).all() for p in model.parameters())

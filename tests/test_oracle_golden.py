@@ -229,3 +229,18 @@ def test_e2e_oracle_matches_reference_goldens(golden_e2e):
     assert np.abs(o["x_cal"] - golden_e2e["e2e_bp_xcal_f64"]).max() < 1e-6         # pixels
     assert abs(o["loss"] - float(golden_e2e["e2e_bp_loss_f64"])) < 1e-8 * abs(o["loss"])
     assert relerr(o["dlogits"][:, :, ::16, ::16], golden_e2e["e2e_bp_dlogits_sample_f64"]) < 1e-6
+
+
+@pytest.mark.parametrize("tree", ["bev", "bp"])
+@pytest.mark.parametrize("D", [3, 4])
+def test_mse_loss_vs_reference_golden(tree, D):
+    """fit_oracle.mse_loss vs the real reference's MSE_Loss (--loss_policy mse; oracle/gen_golden_mse.py)."""
+    import os
+    from conftest import GOLDEN
+    from oracle.gen_golden_mse import mse_inputs
+    G = np.load(os.path.join(GOLDEN, "mse.npz"))
+    p, g = mse_inputs(D)
+    L, grad = fit_oracle.mse_loss(p, g)
+    assert abs(L - float(G["%s_d%d_f64_loss" % (tree, D)])) < 1e-14
+    assert np.abs(grad - G["%s_d%d_f64_grad" % (tree, D)]).max() < 1e-15
+    assert abs(L - float(G["%s_d%d_f32_loss" % (tree, D)])) < 1e-6 * L
