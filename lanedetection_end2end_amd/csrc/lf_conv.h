@@ -30,7 +30,7 @@ enum {
     LF_EPI_ADD = 4,         // v += add_src                    (residual / accumulated gradient)
     LF_EPI_STATS_SQ = 8,    // per-channel sum v, sum v^2      (BatchNorm forward statistics)
     LF_EPI_MASKBN = 16,     // v = (aux*msc+msh) > 0 ? v : 0   (ReLU backward through a recomputed BN)
-    LF_EPI_STATS_XHAT = 32  // per-channel sum v, sum v*xhat, xhat = aux*asc+ash  (BatchNorm backward)
+    LF_EPI_STATS_XHAT = 32  // per-channel sum v, sum v*aux (RAW: lf_bn_bwd_finalize turns the pair into sum v*xhat, xhat = aux*rstd - mean*rstd, in fp64)
 };
 
 struct LfTapArgs {
@@ -50,7 +50,7 @@ struct LfTapArgs {
     const float* aux;
     const float* msc;       // [Cd] forward BN scale/shift (MASKBN)
     const float* msh;
-    const float* asc;       // [Cd] rstd, -mean*rstd (STATS_XHAT)
+    const float* asc;       // (unused since round 3: the BatchNorm-backward sums are written raw)
     const float* ash;
     const float* dm;        // optional Dropout2d keep-mask [N][Cd] applied to the STATS_XHAT sums only (gm = v * dm)
     float* stats;           // [rows][2][Cd] per-workgroup partial sums, rows = lf_tapgemm_stat_rows()

@@ -127,15 +127,15 @@ __device__ __forceinline__ float sum16(float v) {
     const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0; \
     constexpr bool NOBIAS = EPIC >= 0 && (EPIC & (LF_EPI_MASK | LF_EPI_ADD | LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) != 0; \
     constexpr int NC = (NT % 2 == 0 && !LF_EPI_ONE_TILE) ? 2 : 1; \
-    /* MASKBN + STATS_XHAT together want four per-channel vectors per tile: the mask's two are re-read (L1) instead of held */ \
+    /* MASKBN + STATS_XHAT: the mask's two per-channel vectors are re-read (L1) instead of held -- 32 registers, the difference \
+     * between two and three waves per SIMD for that variant */ \
     constexpr bool HOISTM = HOISTV && !(EPIC >= 0 && (EPIC & LF_EPI_MASKBN) && (EPIC & LF_EPI_STATS_XHAT)); \
     __builtin_amdgcn_s_setprio(3);   /* ahead of the partner wave's MFMA stream: the sooner this wave retires, the sooner its slot refills */ \
     const __amdgpu_buffer_rsrc_t r_dst = make_rsrc(a.dst, 0xffffffffu), r_add = make_rsrc(a.add_src, 0xffffffffu), \
                                  r_msk = make_rsrc(a.mask_src, 0xffffffffu), r_aux = make_rsrc(a.aux, 0xffffffffu), \
                                  r_bias = make_rsrc(a.bias, 0xffffffffu), r_msc = make_rsrc(a.msc, 0xffffffffu), \
-                                 r_msh = make_rsrc(a.msh, 0xffffffffu), r_asc = make_rsrc(a.asc, 0xffffffffu), \
-                                 r_ash = make_rsrc(a.ash, 0xffffffffu), r_dm = make_rsrc(a.dm, 0xffffffffu); \
-    f32x4 s1[NT], s2[NT], bs[NOBIAS ? 1 : NT], hv[HOISTV ? NT : 1][4]; \
+                                 r_msh = make_rsrc(a.msh, 0xffffffffu), r_dm = make_rsrc(a.dm, 0xffffffffu); \
+    f32x4 s1[NT], s2[NT], bs[NOBIAS ? 1 : NT], hv[HOISTV ? NT : 1][2]; \
 _Pragma("unroll") \
     for (int n = 0; n < NT; ++n) { \
         const int co = cob + n * 16 + kq * 4; \
@@ -143,7 +143,6 @@ _Pragma("unroll") \
         if constexpr (!NOBIAS) bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4(); \
         if (HOISTV) { \
             if (HOISTM && (epi & LF_EPI_MASKBN)) { hv[n][0] = ldb4(r_msc, co * 4u, 0u); hv[n][1] = ldb4(r_msh, co * 4u, 0u); } \
-            if (epi & LF_EPI_STATS_XHAT) { hv[n][2] = ldb4(r_asc, co * 4u, 0u); hv[n][3] = ldb4(r_ash, co * 4u, 0u); } \
         } \
     } \
 _Pragma("unroll") \
@@ -176,7 +175,7 @@ _Pragma("unroll") \
             if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
             if (epi & LF_EPI_STATS_XHAT) { \
                 const f32x4 gm = (a.dm && !LF_EPI_ROW1) ? v * ld[j] : v; \
-                s1[n] += gm; s2[n] += gm * (lx[j] * (HOISTV ? hv[HOISTV ? n : 0][2] : ldb4(r_asc, co * 4u, 0u)) + (HOISTV ? hv[HOISTV ? n : 0][3] : ldb4(r_ash, co * 4u, 0u))); \
+                s1[n] += gm; s2[n] += gm * lx[j];      /* RAW second sum: the finalise kernel applies x^ = t * rstd - mean * rstd in fp64 */ \
             } \
         } \
         } \
@@ -371,23 +370,34 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         if constexpr (DBG) tstamp[1] = __builtin_amdgcn_s_memrealtime();
         Step A, B;
         issue(A);
+        finish(A);
         const int npairs = (nsteps + 1) >> 1;
         // (Priority falling with progress makes the two waves of a SIMD finish together instead of ~12 us apart -- measured
         // neutral at 128 channels and 15 % SLOWER at 64, where a third / fourth wave waits for the slot of the first finisher.)
-        // The fences pin the next step's loads behind the FIRST quarter of the current step's MFMAs (three quarters of a step of
-        // lead).  Left to the scheduler the position depends on the register pressure of the rest of the kernel: a change in the
-        // epilogue moved the loads behind the third quarter and cost the 64-channel RELU / MASK launches 6-8 us (r3a).
+        // Step order, pinned by scheduling fences: first quarter of this step's MFMAs, the next step's loads, two more quarters,
+        // then the operand prologue of the next step (BN+ReLU / BatchNorm-backward transform: pure VALU work on the OTHER
+        // register set, its loads had 32 MFMAs to land) interleaved with the last quarter -- the prologue's VALU instructions
+        // issue in the shadow of MFMAs instead of in front of them.  (Where the loads sit inside the step does not matter at
+        // three waves per SIMD: r3 sweep over six positions.)
         for (int pr = 0; pr < npairs; ++pr) {
-            finish(A);
             mma(A, 0);
-            issue(B);
             __builtin_amdgcn_sched_barrier(0);
-            mma(A, 1); mma(A, 2); mma(A, 3);
+            issue(B);                                   // (behind the first quarter: its eight dead operand registers are reused)
+            __builtin_amdgcn_sched_barrier(0);
+            mma(A, 1); mma(A, 2);
+            __builtin_amdgcn_sched_barrier(0);
             finish(B);
+            mma(A, 3);
+            __builtin_amdgcn_sched_barrier(0);
             mma(B, 0);
+            __builtin_amdgcn_sched_barrier(0);
             issue(A);
             __builtin_amdgcn_sched_barrier(0);
-            mma(B, 1); mma(B, 2); mma(B, 3);
+            mma(B, 1); mma(B, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(A);
+            mma(B, 3);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

@@ -235,8 +235,8 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
     int l = P->L - 1;
     LF_TRY(lf_bn_bwd_reduce(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], nullptr, stat, npix, P->C[l + 1], ppi, 0, st));
     LfStatPart rp = {stat, lf_bn_bwd_reduce_rows(npix), P->C[l + 1], 0};
-    LF_TRY(lf_bn_bwd_finalize(&rp, 1, P->C[l + 1], (double)npix, ws + P->c1[l], ws + P->c2[l], grads_host[4 * l + 2],
-                              grads_host[4 * l + 3], training, st));
+    LF_TRY(lf_bn_bwd_finalize(&rp, 1, P->C[l + 1], (double)npix, ws + P->asc[l], ws + P->ash[l], ws + P->c1[l], ws + P->c2[l],
+                              grads_host[4 * l + 2], grads_host[4 * l + 3], training, st));
     LF_TRY(lf_bn_bwd_apply(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], params_host[4 * l + 2], ws + P->c1[l],
                            ws + P->c2[l], nullptr, A, nullptr, npix, P->C[l + 1], ppi, 0, st));
     float *gz = A, *other = B;      // gz = d loss / d z_i
@@ -271,8 +271,8 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
         a.stats = stat;
         LF_TRY(lf_tapgemm_launch(P->dg[i], a, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, st));
         LfStatPart sp = {stat, lf_tapgemm_stat_rows_for(P->dg[i], a), P->C[i], 0};
-        LF_TRY(lf_bn_bwd_finalize(&sp, 1, P->C[i], (double)npix, ws + P->c1[j], ws + P->c2[j], grads_host[4 * j + 2],
-                                  grads_host[4 * j + 3], training, st));
+        LF_TRY(lf_bn_bwd_finalize(&sp, 1, P->C[i], (double)npix, ws + P->asc[j], ws + P->ash[j], ws + P->c1[j], ws + P->c2[j],
+                                  grads_host[4 * j + 2], grads_host[4 * j + 3], training, st));
         LF_TRY(lf_bn_bwd_apply(other, nullptr, ws + P->z[j], ws + P->asc[j], ws + P->ash[j], params_host[4 * j + 2],
                                ws + P->c1[j], ws + P->c2[j], nullptr, gz, nullptr, npix, P->C[i], ppi, 0, st));
         // gz now holds d loss / d z_{i-1} (written over the consumed gradient), `other` is scratch again

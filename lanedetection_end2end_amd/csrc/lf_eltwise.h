@@ -23,8 +23,9 @@ int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float
                      float* rows, long npix, int C, long pix_per_image, int s16, hipStream_t st);
 // partial rows -> c1 = sum/M, c2 = sumx/M (both 0 when the forward ran in eval mode: running statistics, no mean terms),
 // and the parameter gradients ggamma = sumx, gbeta = sum
-int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count, float* c1, float* c2, float* ggamma,
-                       float* gbeta, int training, hipStream_t st);
+// rows = [sum g, sum g * t] (RAW, t = the pre-BatchNorm tensor; asc / ash = rstd, -mean * rstd turn them into sum g * xhat in fp64)
+int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count, const float* asc, const float* ash, float* c1,
+                       float* c2, float* ggamma, float* gbeta, int training, hipStream_t st);
 // g_t = gamma*rstd*(gm - c1 - xhat*c2); optionally g_z = g*[y>0]
 int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* gamma,
                     const float* c1, const float* c2, const float* dm, float* g_t, float* g_z, long npix, int C,

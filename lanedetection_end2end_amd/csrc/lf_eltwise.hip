@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int C = Q * 4, ppi = 256 / Q;
     const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
     const int c = cq * 4;
-    const f32x4 a_sc = ld4(asc + c), a_sh = ld4(ash + c);
+    (void)asc; (void)ash;
     f32x4 a1 = z4(), a2 = z4();
     const long per_block = ((npix + gridDim.x - 1) / gridDim.x + ppi - 1) / ppi * ppi;
     const long p0 = (long)blockIdx.x * per_block;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         if (y) gm = pos4(gm, lf_ldv(y + off));
         if (dm) gm *= ld4(dm + (p / pix_per_image) * C + c);
         a1 += gm;
-        a2 += gm * (lf_ldv(t + off) * a_sc + a_sh);
+        a2 += gm * lf_ldv(t + off);          // RAW: bn_bwd_finalize_kernel applies the normalisation in fp64
     }
     __shared__ float sm[256][8];
     block_reduce_quads(a1, a2, Q, sm);
@@ -158,9 +158,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // terms of the data gradient vanish (c1 = c2 = 0); the parameter gradients are the same sums.
 // (mean_scale = 1 / count in training mode, 0 in eval mode -- decided on the host: a run-time `training ? :` in here made hipcc
 // unroll the final sum into 128 registers + 564 bytes of scratch, 19 us per launch instead of 6)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int C, double mean_scale, float* __restrict__ c1,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int C, double mean_scale, const float* __restrict__ asc,
+                                                            const float* __restrict__ ash, float* __restrict__ c1,
                                                             float* __restrict__ c2, float* __restrict__ ggamma,
                                                             float* __restrict__ gbeta) {
+    // rows: [sum g, sum g * t] with t the PRE-BatchNorm tensor (raw: the producing epilogues carry no per-channel vectors);
+    // sum g * x^ = rstd * sum g t - mean rstd * sum g, formed here in fp64 from the fp64 column sums
     const int c0 = blockIdx.x * 4;
     double s1[4], s2[4];
     stat_rows_sum4(sp, c0, s1, s2);
@@ -170,6 +173,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int 
         if (threadIdx.x == 1) { t1 = s1[1]; t2 = s2[1]; }
         if (threadIdx.x == 2) { t1 = s1[2]; t2 = s2[2]; }
         if (threadIdx.x == 3) { t1 = s1[3]; t2 = s2[3]; }
+        const double rstd = (double)asc[c], mr = (double)ash[c];       // mr = -mean * rstd
+        t2 = rstd * t2 + mr * t1;
         c1[c] = (float)(t1 * mean_scale);
         c2[c] = (float)(t2 * mean_scale);
         ggamma[c] = (float)t2;
@@ -578,15 +583,15 @@ int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float
     return 0;
 }
 
-int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count, float* c1, float* c2, float* ggamma,
-                       float* gbeta, int training, hipStream_t st) {
+int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count, const float* asc, const float* ash, float* c1,
+                       float* c2, float* ggamma, float* gbeta, int training, hipStream_t st) {
     LF_REQUIRE(nparts >= 1 && nparts <= 2, "bn_bwd_finalize: 1..2 partial sources");
     StatParts sp;
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
     for (int i = 0; i < nparts; ++i) LF_REQUIRE(parts[i].C % 4 == 0 && parts[i].ch_off % 4 == 0, "bn_bwd_finalize: channel ranges must be multiples of 4");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 4)), dim3(256), 0, st, sp, C, training ? 1.0 / count : 0.0, c1, c2,
-                       ggamma, gbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 4)), dim3(256), 0, st, sp, C, training ? 1.0 / count : 0.0, asc, ash,
+                       c1, c2, ggamma, gbeta);
     LF_CHECK_LAUNCH("bn_bwd_finalize");
     return 0;
 }

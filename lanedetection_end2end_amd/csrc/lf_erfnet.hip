@@ -527,7 +527,8 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
 int bn_bwd_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int nparts, double count) {
     // parameter gradients go straight to bn.weight.grad / bn.bias.grad; c1/c2 stay in the workspace
     if (!c.grads[b.p_g] || !c.grads[b.p_b]) return lf_fail("erfnet backward: BatchNorm weight/bias must both require grad");
-    return lf_bn_bwd_finalize(parts, nparts, b.C, count, c.at(b.c1), c.at(b.c2), c.grads[b.p_g], c.grads[b.p_b], c.training, c.st);
+    return lf_bn_bwd_finalize(parts, nparts, b.C, count, c.at(b.asc), c.at(b.ash), c.at(b.c1), c.at(b.c2), c.grads[b.p_g],
+                              c.grads[b.p_b], c.training, c.st);
 }
 
 // What the LAST data-gradient launch of layer L can do on behalf of layer L-1 (whose output it differentiates):
