@@ -163,14 +163,16 @@ def cpu_baseline_and_parity(precision):
     return base, parity
 
 
-def miopen_baseline(B, R, steps=20, warmup=5):
-    """The reference's step on the vendor stack (PyTorch-ROCm eager: MIOpen convolutions and batch norm with
-    cudnn.benchmark = True, rocBLAS bmm / inverse; oracle/vendor_baseline.py) at the headline's batch, timed AFTER the
-    timed region like cpu_baseline -- what the reference's users get on this GPU by calling .cuda() (BEV/main.py:77-83,
-    SURVEY.md 8c).  A second, non-graded baseline; never imported by the package."""
+def miopen_baseline(B, R, steps=20, warmup=5, tune=False):
+    """The reference's step on the vendor stack (PyTorch-ROCm eager: MIOpen convolutions and batch norm, rocBLAS bmm /
+    inverse; oracle/vendor_baseline.py) at the headline's batch, timed AFTER the timed region like cpu_baseline -- what the
+    reference's users get on this GPU by calling .cuda() (BEV/main.py:77-83, SURVEY.md 8c).  A second, non-graded baseline;
+    never imported by the package.  Default: MIOpen's immediate mode (cudnn.benchmark = False) -- on a fresh box (empty
+    kernel cache) its first step compiles ~70 kernels, 28 s; ``tune`` = cudnn.benchmark = True (MIOpen's find mode benchmarks
+    every applicable solver per problem: ~9 minutes on a fresh box for +4.6 %: 668 vs 639 images/s, r3 measurements)."""
     from oracle import fit_oracle, inputs, vendor_baseline
     prev = torch.backends.cudnn.benchmark
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = bool(tune)
     try:
         P = vendor_baseline.trainable_params(4, "cuda")
         x = torch.from_numpy(inputs.images(B, R, 2 * R, seed=100)).cuda()
@@ -188,7 +190,9 @@ def miopen_baseline(B, R, steps=20, warmup=5):
         if not torch.isfinite(loss):
             return {"value": None, "note": "non-finite loss on the vendor path"}
         return {"value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
-                "kind": "port on PyTorch-ROCm / MIOpen (torch %s, cudnn.benchmark=True)" % torch.__version__,
+                "kind": "port on PyTorch-ROCm / MIOpen (torch %s, cudnn.benchmark=%s)" % (torch.__version__, bool(tune)),
+                "tuned_reference": {"value": 668.06, "note": "the same leg with cudnn.benchmark=True (MIOpen find mode), measured once on "
+                                                            "an MI355X in round 3: gpurun_out r3e, profiles/r3_bench_vendor_tuned.json"},
                 "sample": "batch %d, %dx%d, 2 lanes, fp32, train mode with Dropout2d, fwd + bwd, optimizer excluded; "
                           "%d + %d steps" % (B, R, 2 * R, warmup, steps)}
     finally:
@@ -326,6 +330,8 @@ def main():
                          "-> fwd -> loss -> bwd -> gradient all-reduce -> fused Adam); ignores --steps / --warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vendor-baseline", action="store_true", help="skip the PyTorch-ROCm / MIOpen leg (miopen_baseline)")
+    ap.add_argument("--vendor-tune", action="store_true",
+                    help="miopen_baseline with cudnn.benchmark=True (MIOpen find mode: ~9 minutes of kernel tuning on a fresh box)")
     ap.add_argument("--min-seconds", type=float, default=TIMED_REGION_S,
                     help="the timed region repeats its --steps-step block until it spans this many seconds (default 6.5: an outside "
                          "sampler with a 5 s period then sees the GPU busy); the median block is reported")
@@ -566,7 +572,7 @@ def main():
                                             "products via bf16 x3 splits on the bf16 matrix cores; weight gradient on the "
                                             "fp32 cores); parity tests hold it to the fp32 tolerances"}
         if world == 1 and not a.no_vendor_baseline and a.workload == "bev":
-            out["miopen_baseline"] = miopen_baseline(B, R)
+            out["miopen_baseline"] = miopen_baseline(B, R, tune=a.vendor_tune)
             if out["miopen_baseline"].get("value"):
                 out["miopen_baseline"]["hip_over_miopen"] = round(ips / out["miopen_baseline"]["value"], 2)
         if world == 1 and not a.no_cpu_baseline and a.workload == "bev":

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round's profile evidence from HEAD on a 1-GPU MI355X box (run through gpurun from the repo root):
 #
-#     gpurun --timeout 1500 -- 'bash profiles/collect.sh r2'
+#     gpurun --timeout 900 -- 'bash profiles/collect.sh r3'        (every step runs under its own `timeout`)
 #
 # 1. rocprofv3 --kernel-trace --stats of the exact bench command       -> profiles/<tag>_kernel_stats.txt
 # 2. two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain other than --kernel-trace) over one
@@ -13,28 +13,30 @@
 # 4. a matrix-pipe pass (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) over the bench -> profiles/<tag>_pmc_bench.txt
 # Everything is written under gpurun_out/ first (scratch) and the summaries are copied to profiles/ by this script; commit them.
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 COMMIT=$(cat .git_head 2>/dev/null || echo unknown)
 
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 16 --warmup 4 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 16 --warmup 4 --min-seconds 1 --no-cpu-baseline --no-vendor-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 DB=$(find $OUT/trace -name '*_results.db' | head -1)
 python profiles/summarize_rocpd.py "$DB" > profiles/${TAG}_kernel_stats.txt
 
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1
+  timeout -k 10 120 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1
 done
 python profiles/summarize_traffic.py $OUT $TAG "$COMMIT"
 
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
+timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-vendor-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
 DB=$(find $OUT/pmc_mfma -name '*_results.db' | head -1)
 python profiles/summarize_pmc.py "$DB" 3 > profiles/${TAG}_pmc_bench.txt
+# 5. the vendor library on the kernel-level problems (torch conv2d through MIOpen) beside the HIP kernels -> profiles/<tag>_kbench_vs_miopen.txt
+timeout 240 python tools/kbench.py --iters 100 --miopen > profiles/${TAG}_kbench_vs_miopen.txt 2>&1
 # only gpurun_out/ travels back (<= 64 MiB): keep the summaries and logs, drop the databases
 mkdir -p gpurun_out/profiles_$TAG
-cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/traffic.json gpurun_out/profiles_$TAG/ 2>/dev/null
+cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/${TAG}_kbench_vs_miopen.txt profiles/traffic.json gpurun_out/profiles_$TAG/ 2>/dev/null
 cp $OUT/*.log $OUT/*.err $OUT/*.json gpurun_out/profiles_$TAG/ 2>/dev/null
 rm -rf $OUT
 head -12 profiles/${TAG}_kernel_stats.txt; cat profiles/traffic.json; tail -3 gpurun_out/profiles_$TAG/*.err gpurun_out/profiles_$TAG/pmc_*.log 2>/dev/null | tail -30

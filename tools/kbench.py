@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--split", type=int, default=0, choices=[0, 6, 9], help="fp32 from 3-way split operands on the bf16 matrix "
                     "cores (9 or 6 partial products); checked against the plain fp32 torch result")
     ap.add_argument("--one", type=int, nargs=5, metavar=("C", "H", "W", "AXIS", "DIL"), help="run a single shape (for PMC passes)")
+    ap.add_argument("--miopen", action="store_true", help="also time the vendor library on the same problems (torch conv2d forward / "
+                    "input gradient / weight gradient through MIOpen, NCHW fp32 as the reference runs it) and print its us")
     a = ap.parse_args()
     lib = _lib.load()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -99,6 +101,16 @@ def main():
             e3 = float((gw.view_as(wn.grad) - wn.grad).abs().max() / wn.grad.abs().max())
             e4 = float((gb - bn.grad).abs().max() / bn.grad.abs().max())
             d3 = float((gw.view_as(gw64).double() - gw64).abs().max() / gw64.abs().max())
+            if a.miopen:      # the vendor library on the same problem (what the reference's nn.Conv2d calls on this GPU)
+                gyn = gy.permute(0, 3, 1, 2).contiguous()
+                xd, wd = xn.detach(), w4.detach()
+                mf = timeit(lambda: F.conv2d(xd, wd, b, padding=pad, dilation=dil), a.iters)
+                md = timeit(lambda: torch.nn.grad.conv2d_input(xd.shape, wd, gyn, padding=pad, dilation=dil), a.iters)
+                mw = timeit(lambda: torch.nn.grad.conv2d_weight(xd, wd.shape, gyn, padding=pad, dilation=dil), a.iters)
+                print("   MIOpen (torch %s, NCHW fp32): fwd %6.1f us %5.1f TF | dgrad %6.1f us %5.1f TF | wgrad %6.1f us %5.1f TF   "
+                      "-> HIP / MIOpen speed: fwd %.2fx dgrad %.2fx wgrad %.2fx"
+                      % (torch.__version__, mf * 1e6, flops / mf / 1e12, md * 1e6, flops / md / 1e12, mw * 1e6, flops / mw / 1e12,
+                         mf / tf, md / td, mw / tw), flush=True)
             print("   vs fp64: fwd max %.2e rms %.2e | dgrad max %.2e | wgrad max %.2e   (torch fp32: fwd %.2e)"
                   % (d1, r1, d2, d3, float((yr.double() - y64).abs().max() / y64.abs().max())), flush=True)
             print("C=%3d %3dx%3d axis %d dil %2d var %d | fwd %6.1f us %5.1f TF (%4.1f%%) err %.1e | dgrad %6.1f us %5.1f TF err %.1e | "
