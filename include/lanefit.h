@@ -162,6 +162,10 @@ long lf_erfnet_dropmask_offset(const lf_erfnet_plan* plan, int i);      /* float
 int lf_erfnet_dropmask_channels(const lf_erfnet_plan* plan, int i);
 long lf_erfnet_encoder_offset(const lf_erfnet_plan* plan);             /* float offset of the encoder output (N,H/8,W/8,128) NHWC */
 long lf_erfnet_activation_offset(const lf_erfnet_plan* plan, int layer, int slot);
+/* float offset of a BatchNorm's folded per-channel fp32 vector in the workspace (parity tests: the values the forward pass decided
+ * its ReLU masks with).  bn: 0 / 1 within the layer (non_bottleneck_1d: bn1, bn2); which: 0 scale = gamma * rstd, 1 shift =
+ * beta - mean * scale, 2 rstd, 3 -mean * rstd.  Valid after lf_erfnet_forward; -1 when out of range. */
+long lf_erfnet_bn_vector_offset(const lf_erfnet_plan* plan, int layer, int bn, int which);
 /* head = 0 / 1 selects output_conv / output_conv2; head = -1 = ENCODER ONLY (Net.forward(only_encode=True),
  * BEV/Networks/ERFNet.py:151-153): the decoder does not run (its BatchNorm running statistics stay untouched, as in the
  * reference, where the decoder is never called on that branch), logits may be NULL; the matching backward takes

@@ -45,6 +45,7 @@ def _declare(lib):
         "lf_erfnet_dropmask_channels": (I, [P, I]),
         "lf_erfnet_encoder_offset": (L, [P]),
         "lf_erfnet_activation_offset": (L, [P, I, I]),
+        "lf_erfnet_bn_vector_offset": (L, [P, I, I, I]),
         "lf_erfnet_forward": (I, [P, P, P, P, P, P, I, I, P, P, c_size_t, P]),
         "lf_erfnet_backward": (I, [P, P, P, P, P, P, P, I, I, P, c_size_t, P]),
         "lf_convchain_plan_create": (P, [I, I, I, I, P, P]),

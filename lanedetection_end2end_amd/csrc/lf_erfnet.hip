@@ -345,6 +345,16 @@ long lf_erfnet_activation_offset(const lf_erfnet_plan* P, int layer, int slot) {
     if (layer < 0 || layer >= (int)P->layers.size() || slot < 0 || slot > 4) return -1;
     return P->layers[layer].b[slot];
 }
+// float offset of a BatchNorm's folded per-channel vector in the workspace (parity tests: the fp32 values the ReLU masks of the
+// forward pass were decided with).  bn = 0 / 1 within the layer (non_bottleneck_1d: bn1, bn2); which = 0 scale (gamma * rstd),
+// 1 shift (beta - mean * scale), 2 rstd, 3 -mean * rstd.  Valid after lf_erfnet_forward.  Returns -1 when out of range.
+long lf_erfnet_bn_vector_offset(const lf_erfnet_plan* P, int layer, int bn, int which) {
+    if (layer < 0 || layer >= (int)P->layers.size() || bn < 0 || bn > 1 || which < 0 || which > 3) return -1;
+    const Layer& L = P->layers[layer];
+    if (bn == 1 && L.kind != K_NB) return -1;
+    const BNRef& b = L.bn[bn];
+    return which == 0 ? b.sc : which == 1 ? b.sh : which == 2 ? b.asc : b.ash;
+}
 
 }  // extern "C"
 

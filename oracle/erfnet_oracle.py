@@ -129,6 +129,25 @@ def _tap(taps, override, key, t):
     return t
 
 
+def _relu(z, override, key, bn_input_key=None):
+    """ReLU.  In a straight-through evaluation (``override``) the DERIVATIVE mask is the one the other implementation's forward
+    pass used, not sign(z) of this evaluation: an element whose pre-activation lies inside fp32 rounding of zero may be
+    positive there and non-positive here, and that single element then carries its whole gradient into every parameter sum
+    below it (measured: 1e-4..6e-4 of a decoder tensor's maximum where the arithmetic difference is 2e-6).
+      * output saved under ``key`` (post-ReLU tensor): mask = saved > 0;
+      * ``relu(bn1(t2))`` of non_bottleneck_1d is never stored: override[key] = (scale, shift), the folded fp32 vectors of that
+        BatchNorm, and the mask is sign(fma(t2, scale, shift)) of the saved t2 = override[bn_input_key] -- exact in fp64 (the
+        product of two fp32 numbers is exact in fp64 and the sign of a two-term fp64 sum is exact)."""
+    if override is None or key not in override:
+        return F.relu(z)
+    if bn_input_key is None:
+        mask = override[key] > 0
+    else:
+        sc, sh = override[key]
+        mask = (override[bn_input_key].double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]) > 0
+    return z * mask.to(z.dtype)
+
+
 def _bn(x, P, prefix, training, stats_out):
     """nn.BatchNorm2d(eps=1e-3): batch stats in train mode, running stats in eval."""
     w, b = P[prefix + ".weight"], P[prefix + ".bias"]
@@ -155,25 +174,25 @@ def _down(x, P, p, training, stats_out, taps=None, override=None):
     y = torch.cat([F.conv2d(x, P[p + ".conv.weight"], P[p + ".conv.bias"], stride=2, padding=1),
                    F.max_pool2d(x, 2, stride=2)], 1)
     y = _tap(taps, override, p + "#0", y)
-    return F.relu(_bn(y, P, p + ".bn", training, stats_out))
+    return _relu(_bn(y, P, p + ".bn", training, stats_out), override, p)
 
 
 def _nb1d(x, P, p, d, training, stats_out, keep, taps=None, override=None):
     """non_bottleneck_1d.forward -- ERFNet.py:44-60.  ``keep`` = (N,C) scaled keep-mask or None."""
-    t1 = F.relu(F.conv2d(x, P[p + ".conv3x1_1.weight"], P[p + ".conv3x1_1.bias"], padding=(1, 0)))
+    t1 = _relu(F.conv2d(x, P[p + ".conv3x1_1.weight"], P[p + ".conv3x1_1.bias"], padding=(1, 0)), override, p + "#0")
     t1 = _tap(taps, override, p + "#0", t1)
     t2 = F.conv2d(t1, P[p + ".conv1x3_1.weight"], P[p + ".conv1x3_1.bias"], padding=(0, 1))
     t2 = _tap(taps, override, p + "#1", t2)
-    y = F.relu(_bn(t2, P, p + ".bn1", training, stats_out))
-    t3 = F.relu(F.conv2d(y, P[p + ".conv3x1_2.weight"], P[p + ".conv3x1_2.bias"],
-                         padding=(d, 0), dilation=(d, 1)))
+    y = _relu(_bn(t2, P, p + ".bn1", training, stats_out), override, p + "#bn1", p + "#1")
+    t3 = _relu(F.conv2d(y, P[p + ".conv3x1_2.weight"], P[p + ".conv3x1_2.bias"],
+                        padding=(d, 0), dilation=(d, 1)), override, p + "#2")
     t3 = _tap(taps, override, p + "#2", t3)
     t4 = F.conv2d(t3, P[p + ".conv1x3_2.weight"], P[p + ".conv1x3_2.bias"], padding=(0, d), dilation=(1, d))
     t4 = _tap(taps, override, p + "#3", t4)
     y = _bn(t4, P, p + ".bn2", training, stats_out)
     if keep is not None:
         y = y * keep[:, :, None, None].to(y.dtype)
-    return F.relu(y + x)
+    return _relu(y + x, override, p)
 
 
 def _up(x, P, p, training, stats_out, taps=None, override=None):
@@ -181,7 +200,7 @@ def _up(x, P, p, training, stats_out, taps=None, override=None):
     y = F.conv_transpose2d(x, P[p + ".conv.weight"], P[p + ".conv.bias"], stride=2, padding=1,
                            output_padding=1)
     y = _tap(taps, override, p + "#0", y)
-    return F.relu(_bn(y, P, p + ".bn", training, stats_out))
+    return _relu(_bn(y, P, p + ".bn", training, stats_out), override, p)
 
 
 def erfnet_forward(x, P, training=True, keep_masks=None, head="output_conv", stats_out=None,
@@ -193,7 +212,8 @@ def erfnet_forward(x, P, training=True, keep_masks=None, head="output_conv", sta
     ``head``: 'output_conv' or 'output_conv2' (Decoder.forward flag, :134-141).
     ``taps``: optional dict filled with every block output (key = prefix) and the tensors inside the
     block (key = prefix#slot: down/up pre-BN = #0; nb1d t1..t4 = #0..#3) for per-layer parity tests.
-    ``override``: dict with the same keys -> values substituted straight-through (see ``_tap``).
+    ``override``: dict with the same keys -> values substituted straight-through (see ``_tap``), the ReLU derivative masks taken
+    from the same state (see ``_relu``; optional key prefix#bn1 -> (scale, shift) of a non_bottleneck_1d's first BatchNorm).
     """
     enc = None
     y = x

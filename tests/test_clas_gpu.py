@@ -65,13 +65,14 @@ def test_classification_head(golden_clas, golden_clas_bev, tree, class_type):
     e_gx = relerr(xt.grad.cpu(), gxo)
     print("%s: out %.2e gx %.2e (golden f32-vs-f64 out %.2e)" % (
         class_type, e_out, e_gx, relerr(golden_clas["%s_f32_train_out" % class_type], golden_clas[pre + "train_out"])))
-    # the input gradient passes four ReLU layers of 0.5-1M pre-activations each: one fp32 / fp64 tie flip moves a 7x7 patch
+    # the input gradient passes four ReLU layers of 0.5-1M pre-activations each: one fp32 / fp64 tie flip in the last block moves
+    # a 7 x 7 patch of all 128 input channels = 1.2 % of the elements (measured r3: 1.07e-2, relative L2 8.5e-4, horizon head)
     frac, l2 = tie_tolerant_err(xt.grad.cpu(), gxo, 1e-4)
     print("   gx: %.2e of the elements beyond 1e-4, relative L2 %.2e" % (frac, l2))
-    assert e_out < 1e-4 and (e_gx < 1e-4 or (frac < 2e-4 and l2 < 5e-3))
+    assert e_out < 1e-4 and (e_gx < 1e-4 or (frac < 4e-2 and l2 < 3e-3))
     assert relerr(y.detach().cpu(), golden_clas[pre + "train_out"]) < 1e-4
     fr_g, l2_g = tie_tolerant_err(xt.grad.cpu().numpy()[:, ::8, ::4, ::4], golden_clas[pre + "gx_sample"], 1e-4)
-    assert fr_g < 2e-3 and l2_g < 5e-3
+    assert fr_g < 4e-2 and l2_g < 3e-3
     sd = m.state_dict()
     for k in ("conv1_bn.running_mean", "conv4_bn.running_var"):
         assert relerr(sd[k].cpu(), golden_clas[pre + k]) < 1e-5
@@ -282,7 +283,7 @@ def test_encoder_output_gradient_injection():
         ref = grads[torch.float64][k]
         floor = relerr(grads[torch.float32][k], ref)
         e = relerr(p.grad.cpu(), ref)
-        assert e < max(4 * floor, 1e-4), (k, e, floor)
+        assert e < max(2.5 * floor, 1e-4), (k, e, floor)
         if e > worst[0]:
             worst = (e, k, floor)
     print("encoder-gradient injection: worst %.2e at %s (fp32 reference floor %.2e)" % worst)

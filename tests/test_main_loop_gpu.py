@@ -51,7 +51,7 @@ def test_bev_main_loop_body(bev_tree_on_path, clas):
     Loss_crit = importlib.import_module("Loss_crit")                      # BEV/main.py:23
     define_loss_crit, polynomial = Loss_crit.define_loss_crit, Loss_crit.polynomial
     from lanedetection_end2end_amd.optim import define_optim             # same signature as Networks.utils.define_optim
-    N, R = 2, 64
+    N, R = 2, (256 if clas else 64)      # the --clas heads are built for the 32 x 64 encoder output of resize 256 (LSQ_layer.py:270-277)
     args = Namespace(batch_size=N, nclasses=2, resize=R, end_to_end=True, mod="erfnet", layers=18, channels_in=3, pretrained=False,
                      pool=True, activation_layer="square", no_cuda=False, order=2, reg_ls=0.0, use_cholesky=False,
                      mask_percentage=0.3, clas=clas, loss_policy="area", weight_funct="none", weight_seg=30, optimizer="adam",

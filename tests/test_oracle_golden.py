@@ -244,3 +244,41 @@ def test_mse_loss_vs_reference_golden(tree, D):
     assert abs(L - float(G["%s_d%d_f64_loss" % (tree, D)])) < 1e-14
     assert np.abs(grad - G["%s_d%d_f64_grad" % (tree, D)]).max() < 1e-15
     assert abs(L - float(G["%s_d%d_f32_loss" % (tree, D)])) < 1e-6 * L
+
+
+def test_straight_through_masks_of_the_other_state():
+    """erfnet_oracle's straight-through mode takes the ReLU DERIVATIVE masks from the state it is evaluated at (_relu): with its
+    own taps (and its own folded bn1 vectors) as that state the gradients are those of the plain run; with one post-ReLU
+    element of the state flipped to zero the gradients change -- the mask really comes from the state, not from sign(z)."""
+    N, H, W = 1, 32, 64
+    P = erfnet_oracle.make_params(seed=3, out_channels=2)
+    x = torch.from_numpy(inputs.images(N, H, W, seed=5)).double()
+    gy = torch.from_numpy(np.random.default_rng(6).standard_normal((N, 2, H, W)))
+
+    def grads(override):
+        Pd = erfnet_oracle.cast_params(P, torch.float64)
+        keys = [k for k, v in Pd.items() if v.is_floating_point() and "running" not in k]
+        for k in keys:
+            Pd[k].requires_grad_(True)
+        taps = {}
+        _, dec = erfnet_oracle.erfnet_forward(x, Pd, training=True, taps=taps, override=override)
+        (dec * gy).sum().backward()
+        return {k: Pd[k].grad for k in keys if Pd[k].grad is not None}, taps, Pd
+
+    g0, taps, Pd = grads(None)
+    state = {k: v.detach() for k, v in taps.items()}
+    for prefix, kind, _, _, _, _ in erfnet_oracle.layer_table():
+        if kind == "nb1d":
+            t2 = state[prefix + "#1"]
+            mean, var = t2.mean(dim=(0, 2, 3)), t2.var(dim=(0, 2, 3), unbiased=False)
+            sc = Pd[prefix + ".bn1.weight"].detach() * torch.rsqrt(var + erfnet_oracle.BN_EPS)
+            state[prefix + "#bn1"] = (sc, Pd[prefix + ".bn1.bias"].detach() - mean * sc)
+    g1, _, _ = grads(state)
+    assert max(relerr(g1[k], g0[k]) for k in g0) < 1e-12
+    flipped = dict(state)
+    t3 = state["decoder.layers.1#2"].clone()
+    idx = torch.nonzero(t3 > 0)[0]
+    t3[tuple(idx)] = 0.0                                   # one element of one saved post-ReLU tensor
+    flipped["decoder.layers.1#2"] = t3
+    g2, _, _ = grads(flipped)
+    assert relerr(g2["decoder.layers.1.conv3x1_2.bias"], g0["decoder.layers.1.conv3x1_2.bias"]) > 1e-9
