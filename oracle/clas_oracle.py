@@ -69,8 +69,11 @@ def make_clas_params(class_type, seed=0, **kw):
     return P
 
 
-def _block(x, P, name, training, stats_out):
-    """relu(bn(conv(x))) -- LSQ_layer.py:193-196."""
+def _block(x, P, name, training, stats_out, pre_out=None, flips=None):
+    """relu(bn(conv(x))) -- LSQ_layer.py:193-196.  ``pre_out``: dict filled with the ReLU's pre-activation (detached);
+    ``flips``: {name: flat indices} whose ReLU derivative mask is inverted -- an fp32 implementation decides the sign of a
+    pre-activation that lies inside fp32 rounding of zero differently from fp64, and a test may ask for the fp64 gradient under
+    either decision of such an element (tests/test_clas_gpu.py)."""
     w = P[name + ".weight"]
     z = F.conv2d(x, w, P[name + ".bias"], stride=1, padding=(w.shape[2] - 1) // 2)
     if training:
@@ -85,20 +88,28 @@ def _block(x, P, name, training, stats_out):
     else:
         mean, var = P[name + "_bn.running_mean"].to(z.dtype), P[name + "_bn.running_var"].to(z.dtype)
     zh = (z - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS)
-    return F.relu(zh * P[name + "_bn.weight"][None, :, None, None] + P[name + "_bn.bias"][None, :, None, None])
+    a = zh * P[name + "_bn.weight"][None, :, None, None] + P[name + "_bn.bias"][None, :, None, None]
+    if pre_out is not None:
+        pre_out[name] = a.detach()
+    if flips and name in flips:
+        mask = (a > 0).reshape(-1).clone()
+        idx = torch.as_tensor(list(flips[name]), dtype=torch.long)
+        mask[idx] = ~mask[idx]
+        return a * mask.reshape(a.shape).to(a.dtype)
+    return F.relu(a)
 
 
-def classification_trunk(x, P, training=True, stats_out=None):
+def classification_trunk(x, P, training=True, stats_out=None, pre_out=None, flips=None):
     for name in ("conv1", "conv2", "conv3", "conv4"):
-        x = _block(x, P, name, training, stats_out)
+        x = _block(x, P, name, training, stats_out, pre_out, flips)
     return x
 
 
-def classification_forward(x, P, class_type, training=True, stats_out=None):
+def classification_forward(x, P, class_type, training=True, stats_out=None, pre_out=None, flips=None):
     """x (N,128,rows,cols) -> line logits (N,4) or horizon logits (N,resize) -- BP/Networks/LSQ_layer.py:192-207.
     With the BEV tree's parameters (``fully_connected_line4`` present) the line logits are the four 3-way heads stacked
     to (N,3,4): ``cat((x1,x2,x3,x4), 2)`` of (N,3,1,1) views -- BEV/Networks/LSQ_layer.py:218-226."""
-    y = classification_trunk(x, P, training, stats_out)
+    y = classification_trunk(x, P, training, stats_out, pre_out, flips)
     if class_type == "line":
         f = F.max_pool2d(y, 2, 2).reshape(y.shape[0], -1)
         f = F.relu(F.linear(f, P["fully_connected1.weight"], P["fully_connected1.bias"]))

@@ -70,23 +70,19 @@ def _engine_state(model, logits, N, H, W):
     return fetch_all(model.net, model.net._plan(N, H, W), logits.grad_fn.ws, N, H, W)
 
 
-def _check_grads_straight_through(model, P, x, state, dlogits, tol=2e-4):
-    """Every parameter gradient at the configuration's OWN size, sharply: the oracle is evaluated straight-through at the
-    engine's forward state -- saved tensors, pool arg-maxes AND the ReLU derivative masks the engine's forward pass decided
-    (erfnet_oracle._relu: saved post-ReLU tensors, and sign(fma(t2, scale, shift)) with the engine's folded bn1 vectors for the
-    one ReLU per block whose output is never stored) -- and driven by the engine's own d loss / d logits, so the difference is
-    backward arithmetic only: no 2 % noise floor of a chaotic train-mode network in the way (round 2 held the gradient NORMS to
-    max(2 x floor, 2e-2), which would pass a wrong scale factor on a small tensor), and no single flipped ReLU tie carrying its
-    whole gradient into a decoder tensor's sum (round 3, before the masks came from the state: 1e-4..6e-4 of the maximum on
-    decoder tensors whose arithmetic floor is 2e-6).
-
-    Two oracle legs, fp64 (the truth) and fp32 (the reference arithmetic's own accuracy on the same sums): a weight gradient
-    at batch 32 is a sum of 2.6e5 products of either sign whose total is ~500x smaller than their absolute mass, so ANY fp32
-    accumulation lands up to ~1e-2 of the tensor's maximum away from fp64 (measured at C2: hip worst 1.0e-2, the CPU's fp32 leg
-    5e-3 on the same tensors; at 2 x 64 x 128 both are ~3e-6).  Per tensor: |hip - cpu64| <= max(8 |cpu32 - cpu64|, tol) and <= 5e-2
-    -- a wrong scale factor or a missed tap is an O(1) error.  The ratio r = |hip - cpu64| / |cpu32 - cpu64| (max norms of two
-    independent noise fields: an extreme-value statistic) is held as a DISTRIBUTION over the tensors whose fp32 floor is itself
-    above tol / 2: median <= 1.5, 90th percentile <= 4.  tol is relative to each tensor's maximum."""
+def _check_grads_straight_through(model, P, x, state, dlogits, tol=3e-5):
+    """Every parameter gradient at the configuration's OWN size, sharply: |hip - cpu64| <= tol = 3e-5 of the tensor's maximum.
+    The oracle is evaluated straight-through at the engine's forward state -- saved tensors, pool arg-maxes AND the ReLU
+    derivative masks the engine's forward pass decided (erfnet_oracle._relu: the saved post-ReLU tensors, and
+    sign(fma(t2, scale, shift)) with the engine's folded bn1 vectors for the one ReLU per block whose output is never stored) --
+    and driven by the engine's own d loss / d logits, so the difference is backward arithmetic only.  Round 2 held the gradient
+    NORMS to max(2 x floor, 2e-2) through the chaotic end-to-end chain, which would pass a wrong scale factor on a small tensor.
+    Round 3, first version: same state but the oracle's OWN masks -- errors of 1e-4 (decoder) to 1e-2 (encoder) of the tensor's
+    maximum, on the fp32 CPU leg as well, which looked like the accuracy limit of fp32 sums over 2.6e5 terms and was NOT: they
+    were single ReLU ties (a pre-activation inside fp32 rounding of zero) decided differently by the two evaluations, each
+    carrying its element's whole gradient into every parameter sum below it.  With the masks taken from the state, measured at
+    full size: C2 (32 x 256 x 512) worst 6.1e-6 on the fp32 cores and 1.5e-5 in mode fp32x9, C3 4.0e-6, C5 4.9e-6; the CPU's own
+    fp32 evaluation of the same sums sits at 0.5-1.2e-6 (it accumulates BatchNorm sums in fp64), printed beside each tensor."""
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     legs = {}
     for dt in (torch.float64, torch.float32):
@@ -113,16 +109,14 @@ def _check_grads_straight_through(model, P, x, state, dlogits, tol=2e-4):
         fl = float((P32[k].grad.double() - g64).abs().max()) / scale
         rows.append((e / max(fl, 1e-30), e, fl, k))
     rows.sort(reverse=True)
-    ratios = np.array([r[0] for r in rows if r[2] > tol / 2])
+    ratios = np.array([r[0] for r in rows])
     print("parameter gradients vs the straight-through oracle (|hip-cpu64|, |cpu32-cpu64|, relative to each tensor's max):")
     for r, e, fl, k in rows[:6]:
         print("    ratio %5.2f   hip %.2e   cpu32 %.2e   %s" % (r, e, fl, k))
-    print("    worst hip error %.2e; ratio median %.2f max %.2f over %d tensors above the absolute floor"
-          % (max(r[1] for r in rows), float(np.median(ratios)) if len(ratios) else 0.0, float(ratios.max()) if len(ratios) else 0.0, len(ratios)))
+    print("    worst hip error %.2e (tol %.0e); |hip-cpu64| / |cpu32-cpu64| median %.2f max %.2f over %d tensors"
+          % (max(r[1] for r in rows), tol, float(np.median(ratios)), float(ratios.max()), len(ratios)))
     for r, e, fl, k in rows:
-        assert e <= max(8.0 * fl, tol) and e <= 5e-2, (k, e, fl)
-    if len(ratios) >= 8:
-        assert np.median(ratios) <= 1.5 and np.percentile(ratios, 90) <= 4.0, (float(np.median(ratios)), float(np.percentile(ratios, 90)))
+        assert e <= tol, (k, e, fl)
 
 
 _ORACLE_CACHE = {}

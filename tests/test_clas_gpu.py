@@ -24,16 +24,54 @@ def _sample(g):
     return g if g.size <= 20000 else g.reshape(-1)[::97]
 
 
-def _oracle_head(class_type, x, g, P32, training=True):
+def _oracle_head(class_type, x, g, P32, training=True, flips=None, pre_out=None):
     P = clas_oracle.cast_params(P32, torch.float64)
     for k, v in P.items():
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_(True)
     xt = torch.from_numpy(x).double().requires_grad_(True)
     stats = {}
-    y = clas_oracle.classification_forward(xt, P, class_type, training, stats)
+    y = clas_oracle.classification_forward(xt, P, class_type, training, stats, pre_out, flips)
     (y * torch.from_numpy(g).double()).sum().backward()
     return y.detach(), xt.grad, P, stats
+
+
+_BIAS_BEFORE_BN = ("conv1.bias", "conv2.bias", "conv3.bias", "conv4.bias")
+
+
+def _head_grad_errors(m, xt, gxo, Po):
+    """(input-gradient error, worst parameter-gradient error) of module ``m`` against one oracle evaluation."""
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if k not in _BIAS_BEFORE_BN:
+            worst = max(worst, relerr(p.grad.cpu(), Po[k].grad))
+    return relerr(xt.grad.cpu(), gxo), worst
+
+
+def _resolve_relu_ties(class_type, x, g, P32, m, xt, pre, max_ties=3):
+    """The trunk has ~2.6M ReLU pre-activations; the few that lie inside fp32 rounding of zero (|a| < 1e-5 of their layer's RMS)
+    may be decided either way by a correct fp32 forward pass, and each decision moves the gradient of a whole receptive field.
+    Returns the smallest (input-gradient, parameter-gradient) errors over the sign choices of the ``max_ties`` most ambiguous
+    elements, and the choice that achieved them: the gradients must be the fp64 gradients of ONE consistent forward pass."""
+    import itertools
+    cand = []
+    for name, a in pre.items():
+        flat = a.reshape(-1).abs()
+        rms = float(a.pow(2).mean().sqrt())
+        for i in torch.nonzero(flat < 1e-5 * rms).reshape(-1).tolist():
+            cand.append((float(flat[i]) / rms, name, i))
+    cand = sorted(cand)[:max_ties]
+    best = (float("inf"), float("inf"), None)
+    for r in range(1, len(cand) + 1):
+        for sub in itertools.combinations(cand, r):
+            flips = {}
+            for _, name, i in sub:
+                flips.setdefault(name, []).append(i)
+            _, gxo, Po, _ = _oracle_head(class_type, x, g, P32, flips=flips)
+            e = _head_grad_errors(m, xt, gxo, Po)
+            if max(e) < max(best[:2]):
+                best = (e[0], e[1], [(n, i, "%.1e" % a) for a, n, i in sub])
+    return best, cand
 
 
 @pytest.fixture(scope="module")
@@ -59,20 +97,32 @@ def test_classification_head(golden_clas, golden_clas_bev, tree, class_type):
     y = m(xt)
     assert tree != "bev" or y.shape == (x.shape[0], 3, 4)
     (y * torch.from_numpy(g).cuda()).sum().backward()
-    yo, gxo, Po, stats = _oracle_head(class_type, x, g, P32)
+    preact = {}
+    yo, gxo, Po, stats = _oracle_head(class_type, x, g, P32, pre_out=preact)
     pre = "%s_f64_" % class_type
     e_out = relerr(y.detach().cpu(), yo)
-    e_gx = relerr(xt.grad.cpu(), gxo)
-    print("%s: out %.2e gx %.2e (golden f32-vs-f64 out %.2e)" % (
-        class_type, e_out, e_gx, relerr(golden_clas["%s_f32_train_out" % class_type], golden_clas[pre + "train_out"])))
-    # the input gradient passes four ReLU layers of 0.5-1M pre-activations each: one fp32 / fp64 tie flip in the last block moves
-    # a 7 x 7 patch of all 128 input channels = 1.2 % of the elements (measured r3: 1.07e-2, relative L2 8.5e-4, horizon head)
-    frac, l2 = tie_tolerant_err(xt.grad.cpu(), gxo, 1e-4)
-    print("   gx: %.2e of the elements beyond 1e-4, relative L2 %.2e" % (frac, l2))
-    assert e_out < 1e-4 and (e_gx < 1e-4 or (frac < 4e-2 and l2 < 3e-3))
+    e_gx, e_par = _head_grad_errors(m, xt, gxo, Po)
+    tie = None
+    if max(e_gx, e_par) >= 1e-4:
+        # one pre-activation inside fp32 rounding of zero, decided the other way than in fp64, moves the gradient of a whole
+        # receptive field (round 3, horizon head: 1.07 % of the input-gradient elements, conv1.weight 9.5e-4): the gradients are
+        # then held, at the SAME tolerance, to the fp64 gradients under the other decision of that element
+        (e_gx, e_par, tie), cand = _resolve_relu_ties(class_type, x, g, P32, m, xt, preact)
+        print("   ReLU ties (|pre-activation| / layer RMS, layer, element): %s -> inverted %s" % (
+            [("%.1e" % a, n, i) for a, n, i in cand], tie))
+        assert tie is not None
+        flips = {}
+        for n, i, _ in tie:
+            flips.setdefault(n, []).append(i)
+        _, gxo, Po, _ = _oracle_head(class_type, x, g, P32, flips=flips)
+    print("%s: out %.2e gx %.2e params %.2e (golden f32-vs-f64 out %.2e)" % (
+        class_type, e_out, e_gx, e_par, relerr(golden_clas["%s_f32_train_out" % class_type], golden_clas[pre + "train_out"])))
+    assert e_out < 1e-4 and e_gx < 1e-4
     assert relerr(y.detach().cpu(), golden_clas[pre + "train_out"]) < 1e-4
+    # the committed golden holds the fp64 gradient under fp64's own decisions: tie-tolerant (fraction of elements, relative L2)
     fr_g, l2_g = tie_tolerant_err(xt.grad.cpu().numpy()[:, ::8, ::4, ::4], golden_clas[pre + "gx_sample"], 1e-4)
-    assert fr_g < 4e-2 and l2_g < 3e-3
+    print("   gx vs the golden sample: %.2e of the elements beyond 1e-4, relative L2 %.2e" % (fr_g, l2_g))
+    assert (fr_g == 0.0 or tie is not None) and fr_g < 4e-2 and l2_g < 3e-3
     sd = m.state_dict()
     for k in ("conv1_bn.running_mean", "conv4_bn.running_var"):
         assert relerr(sd[k].cpu(), golden_clas[pre + k]) < 1e-5
@@ -86,7 +136,7 @@ def test_classification_head(golden_clas, golden_clas_bev, tree, class_type):
         e = relerr(p.grad.cpu(), ref)
         worst = max(worst, e)
         assert e < 2e-4, (k, e)
-        assert relerr(_sample(p.grad), golden_clas[pre + "grad_" + k]) < 2e-4, k
+        assert relerr(_sample(p.grad), golden_clas[pre + "grad_" + k]) < (2e-4 if tie is None else 5e-3), k
     print("worst parameter-gradient error %.2e" % worst)
     # eval mode: running statistics
     m.eval()
@@ -249,8 +299,12 @@ def test_bp_net_with_clas_heads():
 
 def test_encoder_output_gradient_injection():
     """d loss / d (encoder output) enters the backbone's backward at the encoder/decoder boundary: with
-    loss = <enc, G> + <dec, Gd> the parameter gradients are held to the fp32 reference's own distance from fp64."""
+    loss = <enc, G> + <dec, Gd> EVERY parameter gradient equals the fp64 oracle's, evaluated straight-through at the engine's own
+    forward state (saved tensors and ReLU masks: erfnet_oracle._relu), to 5e-5 of the tensor's maximum.  (Round 2 compared two
+    independent forward passes and had to allow 4x the fp32 reference's own 2.7e-2 distance from fp64 -- ReLU ties decided
+    differently by each evaluation -- on the blocks next to the injection point only.)"""
     from lanedetection_end2end_amd.bev.Networks import define_model
+    from test_backbone_gpu import fetch_all
     N, H, W = 2, 64, 128
     net = define_model('erfnet', layers=18, in_channels=3, out_channels=2, pretrained=False, pool=True)
     P = erfnet_oracle.make_params(seed=3, out_channels=2)
@@ -264,29 +318,30 @@ def test_encoder_output_gradient_injection():
     G = torch.from_numpy(rng.standard_normal((N, 128, H // 8, W // 8)))
     Gd = torch.from_numpy(rng.standard_normal((N, 2, H, W)))
     enc, dec = net(x.cuda(), True)
+    state = fetch_all(net, net._plan(N, H, W), dec.grad_fn.ws, N, H, W)
     ((enc * G.float().cuda()).sum() + (dec * Gd.float().cuda()).sum()).backward()
-    grads = {}
-    for dtype in (torch.float32, torch.float64):
-        Pd = erfnet_oracle.cast_params(P, dtype)
-        keys = [k for k, v in Pd.items() if v.is_floating_point() and "running" not in k]
-        for k in keys:
-            Pd[k].requires_grad_(True)
-        eo, do = erfnet_oracle.erfnet_forward(x.to(dtype), Pd, training=True, keep_masks=None)
-        ((eo * G.to(dtype)).sum() + (do * Gd.to(dtype)).sum()).backward()
-        grads[dtype] = {k: Pd[k].grad for k in keys if Pd[k].grad is not None}
-    worst = (0.0, None, 0.0)
+    Pd = erfnet_oracle.cast_params(P, torch.float64)
+    keys = [k for k, v in Pd.items() if v.is_floating_point() and "running" not in k]
+    for k in keys:
+        Pd[k].requires_grad_(True)
+    eo, do = erfnet_oracle.erfnet_forward(x.double(), Pd, training=True, keep_masks=None, override=state)
+    ((eo * G).sum() + (do * Gd).sum()).backward()
+    grads = {torch.float64: {k: Pd[k].grad for k in keys if Pd[k].grad is not None}}
+    gmax = max(float(v.abs().max()) for v in grads[torch.float64].values())
+    worst = (0.0, None)
     for k, p in net.named_parameters():
-        if k not in grads[torch.float64] or k.split(".")[-2] in ("conv", "conv1x3_1", "conv1x3_2") and k.endswith(".bias"):
+        if k not in grads[torch.float64]:
+            assert p.grad is None, k
             continue
-        if not k.startswith("encoder.layers.1"):
-            continue                                   # blocks 10-14 (and 1): close to the injection point
         ref = grads[torch.float64][k]
-        floor = relerr(grads[torch.float32][k], ref)
+        if float(ref.abs().max()) < 1e-6 * gmax:        # conv biases in front of a train-mode BatchNorm: analytically zero
+            assert float(p.grad.abs().max()) < 1e-4 * gmax, k
+            continue
         e = relerr(p.grad.cpu(), ref)
-        assert e < max(2.5 * floor, 1e-4), (k, e, floor)
+        assert e < 5e-5, (k, e)
         if e > worst[0]:
-            worst = (e, k, floor)
-    print("encoder-gradient injection: worst %.2e at %s (fp32 reference floor %.2e)" % worst)
+            worst = (e, k)
+    print("encoder-gradient injection: worst parameter-gradient error %.2e at %s" % worst)
     # without the encoder term the same parameter's gradient is different: the injected term matters
     net.zero_grad(set_to_none=True)
     enc, dec = net(x.cuda(), True)
