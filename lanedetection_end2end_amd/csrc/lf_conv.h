@@ -61,6 +61,9 @@ void lf_tapgemm_set_split_any_size(int v);
 int lf_tapgemm_stat_rows(const LfTapGeom& g);                          // upper bound over the kernels (buffer sizing)
 int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a);  // rows the launch with these arguments writes
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);
+// the same launch WITHOUT the in-order barrier on its dispatch packet (hipExtAnyOrderLaunch; fp32 tap-GEMM kernels only, the other
+// kernels launch in order): it may overlap the previous launch of the stream, which the caller guarantees to be independent of it
+int lf_tapgemm_launch_unordered(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);
 
 struct LfWgradArgs {
     const float* x;         // source-side tensor (gathered by taps), geometry = source fields of LfTapGeom

@@ -26,6 +26,8 @@
 #include <map>
 #include <utility>
 
+#include <hip/hip_ext.h>
+
 #include "lf_conv.h"
 #include "lf_types.h"
 
@@ -1013,13 +1015,25 @@ int resident_workgroups(K kernel, size_t lds) {
 }
 // tapgemm_kernel walks its pixel tiles with stride gridDim.x: launch no more workgroups than are resident at once (a multiple
 // of 8 per XCD dealing), so that the tiles beyond the first round are spread one per CU by construction
+// hipExtAnyOrderLaunch for the next launch_tapgemm (set by lf_tapgemm_launch_unordered): the dispatch packet carries no barrier
+// bit, so the kernel may start while the PREVIOUS packet of the stream is still running -- its workgroups fill the slots the
+// previous kernel's last workgroups leave (the caller guarantees the two are independent).
+thread_local unsigned g_launch_flags = 0;
 template <typename K>
 void launch_tapgemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
     const unsigned res = (unsigned)resident_workgroups(kernel, lds) / grid.y;
     if (grid.x > res && res >= 8) grid.x = res & ~7u;
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, g, a, pro, epi);
+    if (g_launch_flags) hipExtLaunchKernelGGL(kernel, grid, dim3(256), (unsigned)lds, st, nullptr, nullptr, g_launch_flags, g, a, pro, epi);
+    else hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, g, a, pro, epi);
 }
 }  // namespace
+
+int lf_tapgemm_launch_unordered(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st) {
+    g_launch_flags = hipExtAnyOrderLaunch;
+    const int rc = lf_tapgemm_launch(g, a, pro, epi, st);
+    g_launch_flags = 0;
+    return rc;
+}
 
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st) {
     LF_REQUIRE(g.Cs % 16 == 0 && g.Cd % 16 == 0, "tapgemm: channels must be multiples of 16 (Cs=%d Cd=%d)", g.Cs, g.Cd);

@@ -375,6 +375,7 @@ struct Ctx {
     mutable std::vector<LfReduceJob> reduce_jobs;
     mutable long wpart_used = 0, bpart_used = 0;
     mutable int last_rows = 0;           // BatchNorm partial rows the last run_gemm wrote (depends on the kernel it selected)
+    mutable bool wgrad_launched = false; // the last run_wgrad put a weight-gradient kernel on the stream (not skipped: frozen weight)
     float* at(long off) const { return ws + off; }
     const float* packed(int pack) const { return ws + P->off_packed + P->packs[pack].dst_off; }
 };
@@ -397,8 +398,11 @@ struct ProfScope {   // records a HIP event pair on the launch stream around one
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c.P->prof[idx].b, pst); }
 };
 
+// beside_wgrad: this data gradient directly follows the weight gradient of the same convolution.  The two read the same gradient
+// tensor and write disjoint buffers, so the data gradient is launched without the in-order barrier: its workgroups start in the
+// slots the weight gradient's last workgroups leave instead of after its tail (the NEXT launch is in order again and waits for both).
 int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const float* bias, int pro, int epi,
-             LfTapArgs extra) {
+             LfTapArgs extra, bool beside_wgrad = false) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
     extra.s16 = c.s16;
     if (c.P->precision == 1 || c.P->precision == 2)
@@ -409,6 +413,7 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
     }
     c.last_rows = lf_tapgemm_stat_rows_for(op.geom, extra);
     ProfScope ps(c, 0, op.geom, epi | (pro << 8), c.st);
+    if (beside_wgrad && c.wgrad_launched && !c.P->prof_on) return lf_tapgemm_launch_unordered(op.geom, extra, pro, epi, c.st);
     return lf_tapgemm_launch(op.geom, extra, pro, epi, c.st);
 }
 
@@ -498,6 +503,7 @@ int forward_layers(const Ctx& c, const float* img, int nlayers) {
 int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x, const float* g, const float* pro_sc,
               const float* pro_sh, int bias_accumulate, bool batch_off = false) {
     const lf_erfnet_plan* P = c.P;
+    c.wgrad_launched = false;
     if (!c.grads[cv.p_w]) return 0;
     hipStream_t ws = c.st;
     LfWgradArgs a;
@@ -515,6 +521,7 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
         ProfScope ps(c, 1, op.geom, 0, ws);
         LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, ws));
     }
+    c.wgrad_launched = true;
     const LfPackEntry& e = P->packs[op.pack];
     const int nsplit = lf_tapwgrad_splits_for(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE);   // rows this launch wrote
     if (batched) {
@@ -623,13 +630,13 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             LF_TRY(run_wgrad(c, L.cv[3].fwd, L.cv[3], t3, X, nullptr, nullptr, 0));
             LfTapArgs a = lf_no_args();
             a.mask_src = t3;
-            LF_TRY(run_gemm(c, L.cv[3].dg[0], X, F, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
+            LF_TRY(run_gemm(c, L.cv[3].dg[0], X, F, nullptr, LF_PRO_NONE, LF_EPI_MASK, a, true));
             // conv3x1_2: input relu(bn1(t2)) recomputed on the fly; g_y1 -> X with the bn1-backward sums
             LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, F, c.at(b1.sc), c.at(b1.sh), 0));
             a = lf_no_args();
             a.aux = t2; a.msc = c.at(b1.sc); a.msh = c.at(b1.sh); a.asc = c.at(b1.asc); a.ash = c.at(b1.ash);
             a.stats = stat0;
-            LF_TRY(run_gemm(c, L.cv[2].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, a));
+            LF_TRY(run_gemm(c, L.cv[2].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, a, true));
             LfStatPart sp = {stat0, c.last_rows, L.Cout, 0};
             LF_TRY(bn_bwd_finalize(c, b1, &sp, 1, (double)npo));
             LF_TRY(lf_bn_bwd_apply(X, nullptr, t2, c.at(b1.asc), c.at(b1.ash), c.params[b1.p_g], c.at(b1.c1), c.at(b1.c2),
@@ -638,14 +645,14 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             LF_TRY(run_wgrad(c, L.cv[1].fwd, L.cv[1], t1, F, nullptr, nullptr, 0));
             a = lf_no_args();
             a.mask_src = t1;
-            LF_TRY(run_gemm(c, L.cv[1].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASK, a));
+            LF_TRY(run_gemm(c, L.cv[1].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASK, a, true));
             // conv3x1_1 (+ residual branch gradient g_z) -> F, optionally prepared for the previous layer
             LF_TRY(run_wgrad(c, L.cv[0].fwd, L.cv[0], x, X, nullptr, nullptr, 0));
             a = lf_no_args();
             a.add_src = gz;
             int epi = LF_EPI_ADD;
             add_prep(a, epi);
-            LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a));
+            LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a, true));
             out = F;
             if (can_prep) { prepped = true; prep_rows = c.last_rows; }
         } else if (L.kind == K_UP) {
