@@ -136,3 +136,29 @@ def ptr(t):
 
 def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeferredRead:
+    """A few device scalars read back WITHOUT stalling the stream: the copy to pinned host memory and an event are enqueued
+    right behind the kernel / collective that produced them; ``get()`` waits for THAT event only.  (``t.tolist()`` / ``float(t)``
+    at a later point enqueue their copy behind everything launched since -- e.g. the whole next forward + backward -- and block
+    the host until that finishes: the hidden per-step sync VERDICT round 3 found in the reducer and the cross-entropy check.)
+    Host tensors are cloned (the gloo / CPU tests)."""
+
+    def __init__(self, t):
+        if t.is_cuda:
+            self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self.host.copy_(t, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host = t.detach().clone()
+            self.event = None
+
+    def ready(self):
+        return self.event is None or self.event.query()
+
+    def get(self):
+        if self.event is not None:
+            self.event.synchronize()
+        return self.host

@@ -35,6 +35,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef LF_FLUSH_PAIRS
+#define LF_FLUSH_PAIRS 1              // tapgemm_kernel: pairs of K-steps per accumulation segment (1 = 32 products per chain)
+#endif
 constexpr int MT = 4;                 // 16-pixel tiles per wave
 constexpr int WG_WAVES = 4;
 constexpr int PIX_PER_WG = WG_WAVES * MT * 16;
@@ -225,8 +228,10 @@ constexpr size_t LF_TAP_LDS_PER_TAP = (size_t)WG_WAVES * 64 * (sizeof(uint4) + s
 // ROW1 (Wl % 64 == 0): a wave's 64 pixels lie in one image row, so (image, row, first column) are wave-uniform and live in
 // scalar registers: two divisions instead of eight in the prologue and ~10 vector registers less.
 // DBG: per-wave phase stamps (tools/kbench.py --phases); compiled only into the instantiation lf_debug_conv1d_fwd_phases launches
+// (the run-time-flag forms -- cold paths: the --clas trunk, kernel-level tests -- hold the union of all epilogue state beside the
+// two accumulator sets and are given the whole register file, one wave per SIMD, instead of spilling 14-21 registers)
 template <int NT, int PROC, int EPIC = -1, bool ROW1 = false, bool DBG = false>
-__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
+__global__ __launch_bounds__(256, (EPIC >= 0 || NT < 4) ? 2 : 1) void tapgemm_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
     constexpr bool S16 = false, HOISTV = EPIC >= 0;  // compiled-in flags: the per-channel vectors are loaded once, after the loop
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
@@ -281,11 +286,18 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         }
     }
 
-    f32x4 acc[NT][MT];
+    // Two accumulator sets (round 4): `acc` holds the running chain of ONE pair of K-steps (32 products per element), `accl`
+    // the sum of the finished pairs.  One fp32 fma chain over the whole contraction (K = 192 at 64 channels, 384 at 128) left
+    // the logits ~1.25x further from fp64 than oneDNN's fp32 convolution; tools/accum_study.py reproduces that on the CPU with
+    // the kernel's summation order emulated (1.31x) and shows where it comes from (the 64-channel layers' K = 192 chain; the
+    // folded BatchNorm and the fp32 statistics partials do not matter) and what removes it: 32-term segments summed into a
+    // second accumulator -> 0.90x.  The flush is a VALU add per accumulator register and pair, issued between the MFMAs that
+    // restart the chain from a zero C operand; the 64 extra registers put every variant at two waves per SIMD.
+    f32x4 acc[NT][MT], accl[NT][MT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+        for (int m = 0; m < MT; ++m) { acc[n][m] = zero4(); accl[n][m] = zero4(); }
 
     const int ncg = g.Cs >> 4;
     const int nsteps = g.ntaps * ncg;
@@ -368,6 +380,23 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
                 for (int m = 0; m < MT; ++m)
                     acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][s], S.x[m][s], acc[n][m], 0, 0, 0);
         };
+        // first quarter of a pair: every accumulator is flushed into the long-term set and its chain restarted (C = 0).  The
+        // add of tile (n, m) reads what the LAST quarter of the previous pair wrote 16 MFMAs ago -- no dependency stall -- and
+        // issues in the shadow of the neighbouring MFMAs.
+        auto mma_restart = [&](const Step& S) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    accl[n][m] += acc[n][m];
+                    // (pinned: without the empty asm the IR passes sink all 64 adds behind the next loads, and the restarted
+                    // chains then live in a THIRD register set beside the old one -- 256 registers, 13-65 of them spilled)
+                    asm volatile("" : "+v"(accl[n][m]));
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.w[n][0], S.x[m][0], zero4(), 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // 2 VALU (v_pk_add_f32 x 2) ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // ... then this tile's MFMA
+                }
+        };
         static_assert(MT == 4, "tab_off packs 4 pixel tiles");
         if constexpr (DBG) tstamp[1] = __builtin_amdgcn_s_memrealtime();
         Step A, B;
@@ -382,7 +411,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         // issue in the shadow of MFMAs instead of in front of them.  (Where the loads sit inside the step does not matter at
         // three waves per SIMD: r3 sweep over six positions.)
         for (int pr = 0; pr < npairs; ++pr) {
-            mma(A, 0);
+#if LF_FLUSH_PAIRS == 1
+            mma_restart(A);
+#else
+            if ((pr & (LF_FLUSH_PAIRS - 1)) == 0) mma_restart(A); else mma(A, 0);      // A/B builds only (64-term segments)
+#endif
             __builtin_amdgcn_sched_barrier(0);
             issue(B);                                   // (behind the first quarter: its eight dead operand registers are reused)
             __builtin_amdgcn_sched_barrier(0);
@@ -403,6 +436,10 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const LfTapGeom g, cons
         }
     }
 
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] += accl[n][m];
     if constexpr (DBG) {   // make the stamp wait for the last MFMA: touch one accumulator
         asm volatile("" ::"v"(acc[0][0][0]));
         tstamp[2] = __builtin_amdgcn_s_memrealtime();
@@ -878,6 +915,11 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+    f32x4 seg[NT][MT];                 // running chain of the general path (see below)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) seg[n][m] = zero4();
     const int ncg = g.Cs >> 4;
     const float* wp = a.wp + (long)(kq * g.Cd + cob + pl) * 4;
     // x: num_records = the tensor, so that LF_OOB reads as 0.0f (padding without masks when there is no prologue)
@@ -916,13 +958,20 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
                     x3[t][m] = v;
                 }
             }
+            // one fma chain per TAP (16 products), the three summed afterwards: the summation-error rule of tapgemm_kernel
+            // (segments of <= 32 products), here for the layers next to the logits
+            f32x4 part[NT][MT];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[t][n][s4], x3[t][m][s4], acc[n][m], 0, 0, 0);
+                        part[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[t][n][s4], x3[t][m][s4], s4 ? part[n][m] : zero4(), 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = t ? acc[n][m] + part[n][m] : part[n][m];
         }
     } else
     for (int t = 0; t < g.ntaps; ++t) {
@@ -953,14 +1002,27 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
                 x[m].x = in[m] ? x[m].x : 0.f; x[m].y = in[m] ? x[m].y : 0.f;
                 x[m].z = in[m] ? x[m].z : 0.f; x[m].w = in[m] ? x[m].w : 0.f;
             }
+            // (a chain restarts every two channel groups = 32 products and is added into acc: tapgemm_kernel's rule)
+            if ((cg & 1) == 0) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) { acc[n][m] += seg[n][m]; seg[n][m] = zero4(); }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][s], x[m][s], acc[n][m], 0, 0, 0);
+                        seg[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][s], x[m][s], seg[n][m], 0, 0, 0);
         }
+    }
+    if (!(g.Cs == 16 && g.ntaps == 3)) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] += seg[n][m];
     }
     LF_TAPGEMM_EPILOGUE
 }

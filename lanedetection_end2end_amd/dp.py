@@ -25,6 +25,22 @@ def broadcast_parameters(module, src=0, group=None):
 
 
 TAIL = 8          # trailing fp32 slots of the flat bucket reserved for the reducer (signature of the active parameter set)
+HASH_MODS = (31, 61, 64)      # small moduli: h and h^2 (<= 3969) and their means stay exact to ~1e-3 in fp32 under any rounding
+
+
+def signature_disagrees(tail, world):
+    """True when the reduced signature ``tail`` ([1, h1, h1^2, h2, h2^2, h3, h3^2, 0] averaged -- or summed -- over ``world``
+    ranks) says the ranks held different hash values: Var(h) = mean(h^2) - mean(h)^2 is 0 iff all ranks agree and at least
+    (world - 1) / world^2 when ONE rank differs by the smallest possible amount (integers); the threshold is half of that.
+    Robust to how the collective rounds: RCCL's ``ReduceOp.AVG`` multiplies every rank's value by fp32(1 / world) BEFORE the
+    sum, which is inexact for world = 3, 5, 6, 7, ...; with h <= 63 the absolute error of both means is below 1e-3 (the first
+    version hashed modulo 1021: h^2 ~ 1e6, one fp32 ulp 0.06 against a tolerance of 0.01 -- a spurious failure on 16-49 % of
+    the hash values at those world sizes)."""
+    v = [float(x) for x in tail]
+    scale = 1.0 if abs(v[0] - 1.0) < 1e-3 else float(world)       # AVG leaves the leading 1 at 1, SUM at world
+    m = [x / scale for x in v]
+    thr = 0.5 * (world - 1) / float(world * world)
+    return any(abs(m[k + 1] - m[k] * m[k]) > thr for k in (1, 3, 5))
 
 
 class FlatGradAllReduce:
@@ -35,14 +51,20 @@ class FlatGradAllReduce:
     keeps ``grad = None``.  The set of parameters WITH a gradient may change between steps -- the reference's pretrained
     schedule flips ``end_to_end`` mid-run (BEV/main.py get_flags): ``decoder.output_conv2`` stops and ``decoder.output_conv``
     starts receiving gradients -- but it must change identically on every rank.  That is verified, not assumed, and WITHOUT a
-    second collective or a host sync in the step: two small hashes (h, h^2 pairs) of the local set ride in the tail of the same
-    all-reduce -- the ranks agree iff mean(h^2) == mean(h)^2 -- and the reduced tail is inspected at the START OF THE NEXT
-    call (or by ``check()``), when the collective that produced it has long completed: the host runs a full step ahead.
+    second collective or a host sync in the step: three small hashes (h, h^2 pairs) of the local set ride in the tail of the
+    same all-reduce (``signature_disagrees``).  The reduced tail is copied to pinned host memory right behind the collective
+    with an event (``_lib.DeferredRead``) and inspected at the START OF THE NEXT call (or by ``check()``), waiting for that
+    event only -- the collective of a step ago -- so the host keeps running a full step ahead of the GPU.
     Because the bucket size never depends on the active set, a disagreement cannot produce a size-mismatched collective.
     On RCCL the reduction is ``ReduceOp.AVG`` (no separate divide pass); gloo (CPU tests) sums and divides.
+
+    Detection is therefore ONE STEP LATE by default: the optimizer has already applied the partially averaged gradients of the
+    offending step when the error is raised.  Call ``check()`` before ``optimizer.step()`` (one host sync per step), or
+    construct with ``strict=True`` (the same, inside the call), where that matters; otherwise call ``check()`` at the end of
+    an epoch and before a checkpoint so that the last step is inspected too.
     """
 
-    def __init__(self, params, group=None, flat_provider=None):
+    def __init__(self, params, group=None, flat_provider=None, strict=False):
         """``flat_provider``: optional callable returning one contiguous fp32 tensor of ``sum(p.numel()) + TAIL`` elements in
         which every non-None ``p.grad`` is a view at the parameter's running offset (``erfnet.Net.flat_grad``): the
         all-reduce then runs in place on it, without flatten / unflatten copies."""
@@ -50,12 +72,13 @@ class FlatGradAllReduce:
         self.group = group
         self.active = None
         self.flat_provider = flat_provider
+        self.strict = strict
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)
             off += p.numel()
         self.total = off
-        self._pending = None          # reduced tail of the previous call, not yet inspected
+        self._pending = None          # reduced tail of the previous call (DeferredRead), not yet inspected
         self._sig_cache = (None, None)
         self.last_flat = None         # the bucket of the last call (tests: ranks must hold identical bits after the reduce)
 
@@ -63,12 +86,12 @@ class FlatGradAllReduce:
     def _hashes(active):
         h1 = h2 = 0
         for i in active:
-            h1 = (h1 * 31 + i + 1) % 1021
-            h2 = (h2 * 37 + i + 7) % 1019
-        return float(h1), float(h2), float(len(active) % 1024)
+            h1 = (h1 * 7 + i + 1) % HASH_MODS[0]
+            h2 = (h2 * 11 + i + 7) % HASH_MODS[1]
+        return float(h1), float(h2), float(len(active) % HASH_MODS[2])
 
     def _signature(self, active, device):
-        """Device tensor [1, h1, h1^2, h2, h2^2, n, n^2, 0] for this active set (cached: the set rarely changes)."""
+        """Device tensor [1, h1, h1^2, h2, h2^2, h3, h3^2, 0] for this active set (cached: the set rarely changes)."""
         key = (tuple(active), device)
         if self._sig_cache[0] != key:
             h1, h2, n = self._hashes(active)
@@ -76,19 +99,15 @@ class FlatGradAllReduce:
         return self._sig_cache[1]
 
     def check(self):
-        """Inspect the signature the PREVIOUS all-reduce carried (one small D2H read of a long-finished result).  Raises on
-        every rank when the ranks reduced different parameter sets."""
+        """Inspect the signature the PREVIOUS all-reduce carried (waits for the event recorded behind that collective, nothing
+        launched since).  Raises on every rank when the ranks reduced different parameter sets."""
         if self._pending is None:
             return
-        t, world = self._pending
+        pend, world = self._pending
         self._pending = None
-        v = [float(x) for x in t.tolist()]
-        scale = 1.0 if abs(v[0] - 1.0) < 1e-3 else float(world)       # AVG leaves the leading 1 at 1, SUM at world
-        m = [x / scale for x in v]
-        for k in (1, 3, 5):
-            if abs(m[k + 1] - m[k] * m[k]) > 0.01:
-                raise RuntimeError("data-parallel ranks disagree on the set of parameters with gradients (%d tensors here)"
-                                   % len(self.active or []))
+        if signature_disagrees(pend.get().tolist(), world):
+            raise RuntimeError("data-parallel ranks disagree on the set of parameters with gradients (%d tensors here)"
+                               % len(self.active or []))
 
     def _in_place_flat(self, grads, active):
         flat = self.flat_provider() if self.flat_provider is not None else None
@@ -100,12 +119,27 @@ class FlatGradAllReduce:
                 return None
         return flat
 
-    def __call__(self):
+    def _reduce(self, flat, active, world):
+        """Signature into the tail, the collective, the deferred read of the reduced tail."""
+        from ._lib import DeferredRead
+        flat[self.total:].copy_(self._signature(active, flat.device))
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)        # RCCL: sum and scale in the collective
+        else:
+            dist.all_reduce(flat, group=self.group)
+            flat.div_(world)
+        self._pending = (DeferredRead(flat[self.total:]), world)
+        self.last_flat = flat
+        if self.strict:
+            self.check()
+
+    def __call__(self, force=False):
+        """``force``: run the bucket path for a single-rank group too (tests of the stream behaviour on one GPU)."""
         world = dist.get_world_size(self.group)
         self.check()                          # last step's signature (its collective finished a step ago)
         active = [i for i, p in enumerate(self.params) if p.grad is not None]
         self.active = active
-        if world == 1 or not self.params:
+        if (world == 1 and not force) or not self.params:
             return 0
         grads = [self.params[i].grad for i in active]
         flat = self._in_place_flat(grads, active) if active else None
@@ -115,14 +149,7 @@ class FlatGradAllReduce:
             flat = torch.zeros(self.total + TAIL, dtype=torch.float32, device=dev)
             for g, i in zip(grads, active):
                 flat[self.offsets[i]: self.offsets[i] + g.numel()].copy_(g.reshape(-1))
-        flat[self.total:].copy_(self._signature(active, flat.device))
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)        # RCCL: sum and scale in the collective
-        else:
-            dist.all_reduce(flat, group=self.group)
-            flat.div_(world)
-        self._pending = (flat[self.total:].clone(), world)
-        self.last_flat = flat
+        self._reduce(flat, active, world)
         if not in_place:
             for g, i in zip(grads, active):
                 g.copy_(flat[self.offsets[i]: self.offsets[i] + g.numel()].view_as(g))

@@ -82,17 +82,26 @@ class CrossEntropyLoss2d(nn.Module):
         w = [1.0] + [float(weight)] * nclasses if seg else [1.0] * (nclasses + 1)
         self.register_buffer("weights", torch.tensor(w, dtype=torch.float32), persistent=False)
         # A label outside [0, C) raises like nn.NLLLoss's device assert does -- and, like it, not inside the offending call:
-        # the kernel counts such labels (they carry weight 0), the count of call k is read at the START of call k + 1 (or by
-        # flush()), when it has long been computed, so the loss adds no host sync to the step.  "always": read it in the call
-        # itself (one D2H sync per step); False: never (the count stays in ops.CrossEntropy2dFn.last_acc[2]).
+        # the kernel counts such labels (they carry weight 0); the count of call k is copied to pinned host memory right behind
+        # the kernel (``_lib.DeferredRead``) and read at the START of call k + 1 (or by flush()), waiting for that copy's event
+        # only -- the loss adds no host sync to the step.  "always": read it in the call itself (one sync per step);
+        # False: never (the count stays in ops.CrossEntropy2dFn.last_acc[2]).
+        # The LAST call of a loop is inspected by flush(): the mirrors' loops call it after the last batch; train() / eval()
+        # on the criterion flush too.
         self.check_targets = True
         self._pending = None
 
     def flush(self):
         """Raise now if the previous call saw a label outside [0, C)."""
         pend, self._pending = self._pending, None
-        if pend is not None and float(pend[0][2]) != 0.0:
-            raise RuntimeError("cross entropy: %d target value(s) outside [0, %d)" % (int(pend[0][2]), pend[1]))
+        if pend is not None:
+            acc = pend[0].get()
+            if float(acc[2]) != 0.0:
+                raise RuntimeError("cross entropy: %d target value(s) outside [0, %d)" % (int(acc[2]), pend[1]))
+
+    def train(self, mode=True):
+        self.flush()
+        return super().train(mode)
 
     def forward(self, inputs, targets):
         if targets.dim() == 4:
@@ -101,7 +110,7 @@ class CrossEntropyLoss2d(nn.Module):
             self.flush()
         loss = ops.CrossEntropy2dFn.apply(inputs, targets.long(), self.weights, self.check_targets == "always")
         if self.check_targets:
-            self._pending = (ops.CrossEntropy2dFn.last_acc, inputs.shape[1])
+            self._pending = (_lib.DeferredRead(ops.CrossEntropy2dFn.last_acc), inputs.shape[1])
         return loss
 
 

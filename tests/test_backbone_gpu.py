@@ -319,9 +319,20 @@ def test_eval_mode_backward_is_the_affine_batchnorm():
     x = torch.from_numpy(inputs.images(N, H, W, seed=51))
     gy = torch.from_numpy(np.random.default_rng(9).standard_normal((N, 2, H, W)).astype(np.float32))
     enc, dec = net(x.cuda(), True)
+    state = fetch_all(net, net._plan(N, H, W), dec.grad_fn.ws, N, H, W)
     (dec * gy.cuda()).sum().backward()
-    _, dec64, _, _, Pd = run_oracle(x, P2, torch.float64, gy=gy, training=False)
+    _, dec64, _, _, _ = run_oracle(x, P2, torch.float64, training=False)
     assert relerr(dec.detach().cpu(), dec64.detach()) < 2e-5
+    # backward at the engine's own forward state (ReLU masks included), like the train-mode test: without that, ONE
+    # pre-activation inside fp32 rounding of zero decided differently by the fp64 oracle puts its whole gradient into every
+    # sum below it -- round 4's change of the convolutions' summation order moved such a tie and the stem's weight gradient
+    # read 2.1e-3 off where the backward arithmetic differs by 1e-6
+    Pd = erfnet_oracle.cast_params(P2, torch.float64)
+    for k, v in Pd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    _, dec_st = erfnet_oracle.erfnet_forward(x.double(), Pd, training=False, override=state)
+    (dec_st * gy.double()).sum().backward()
     worst = 0.0
     for k, p in net.named_parameters():
         ref = Pd[k].grad
@@ -330,8 +341,8 @@ def test_eval_mode_backward_is_the_affine_batchnorm():
             continue
         e = relerr(p.grad.cpu(), ref)
         worst = max(worst, e)
-        assert e < 2e-4, (k, e)          # no batch statistics: not chaotic, only fp32 roundoff through 70 layers
-    print("eval-mode backward: worst parameter-gradient error vs fp64 %.2e" % worst)
+        assert e < 2e-5, (k, e)          # no batch statistics: fp32 roundoff of the backward pass only
+    print("eval-mode backward: worst parameter-gradient error vs the straight-through fp64 oracle %.2e" % worst)
     assert float((net.state_dict()["encoder.initial_block.bn.running_mean"].cpu() - P2["encoder.initial_block.bn.running_mean"]).abs().max()) == 0.0
 
 
@@ -422,9 +433,11 @@ def test_e2e_bev_vs_golden(golden_e2e):
     print("loss  hip %.8e  ref64 %.8e  ref32 %.8e" % (float(loss), l64, l32))
     assert e64 < max(2 * floor, 1e-5)
     # train-mode BN + ReLU make the random-weight net chaotic: logits carry ~1e-4 fp32 noise on either
-    # implementation (test_forward_layer_by_layer); the loss is held to 1e-4 relative here, and to 1e-6
-    # on identical logits in test_fit_gpu.py
-    assert abs(float(loss) - l64) < max(2 * abs(l32 - l64), 1e-2 * abs(l64))
+    # implementation (test_forward_layer_by_layer); the loss is held to twice the reference arithmetic's own fp32-vs-fp64
+    # distance, with a floor of 2e-4 relative for the case that the fp32 leg happens to land on the fp64 one (measured on
+    # MI355X: 2.4e-5; round 3 had let this floor slip to 1e-2 -- ADVICE round 3), and to 1e-6 on identical logits in
+    # test_fit_gpu.py
+    assert abs(float(loss) - l64) < max(2 * abs(l32 - l64), 2e-4 * abs(l64))
     s64 = golden_e2e["e2e_bev_logits_sample_f64"]
     sfl = relerr(golden_e2e["e2e_bev_logits_sample_f32"], s64)
     assert relerr(output.detach().cpu().numpy()[:, :, ::16, ::16], s64) < max(2 * sfl, 2e-5)

@@ -1,23 +1,35 @@
-"""The BASELINE.json configurations AT THEIR OWN SIZES against the CPU oracle (fp32 and fp64 backbone legs of
-oracle/e2e_oracle.py, whose composition is pinned to the real reference's end-to-end runs by
-tests/test_oracle_golden.py::test_e2e_oracle_matches_reference_goldens):
+"""The BASELINE.json configurations against the CPU oracle (fp32 and fp64 backbone legs of oracle/e2e_oracle.py, whose
+composition is pinned to the real reference's end-to-end runs by
+tests/test_oracle_golden.py::test_e2e_oracle_matches_reference_goldens).
 
-  C2  BEV, 2 lanes, 32 x 3 x 256 x 512, train mode (batch statistics over all 32 images), fp32 matrix cores -- and the same
-      step in precision mode fp32x9 with the SHIPPED kernel-selection rule (no test-size override);
-  C3  Backprojection tree, 4 lanes, 320 x 640 (batch 4; masked-row pole of the homography sanitised in the oracle only);
-  C5  segmentation branch, Cout = 3, 512 x 1024 (batch 2), class-weighted cross entropy.
+DIRECT oracle comparisons (a CPU fp64 run of the whole step beside the HIP one):
+  C2  BEV, 2 lanes, 32 x 3 x 256 x 512 -- ITS OWN SIZE -- train mode (batch statistics over all 32 images), fp32 matrix cores,
+      and the same step in precision mode fp32x9 with the SHIPPED kernel-selection rule (no test-size override);
+  C3  Backprojection tree, 4 lanes, 320 x 640 at batch 4 (masked-row pole of the homography sanitised in the oracle only);
+  C5  segmentation branch, Cout = 3, 512 x 1024 at batch 2, class-weighted cross entropy.
+TRANSITIVE checks at C3's and C5's OWN batch sizes (64, fp32 and bf16; 16) -- a CPU fp64 step at those sizes does not fit the
+suite's time cap (Missing #2):
+  eval mode   image i of the full-batch HIP run == the same image in a batch-4 (batch-2) HIP run, logits and lane coefficients
+              (the small-batch run is oracle-checked right here, eval mode, both CPU legs); parameter gradients of a linear
+              functional of the logits == the sum over the chunks' gradients;
+  train mode  every BatchNorm mean / variance the engine folded at the full batch == an fp64 reduction of the engine's own
+              pre-BN tensor, and the running statistics it wrote == the momentum update from those.
+Together with the per-kernel parity tests (tests/test_backbone_gpu.py: every addressing path at ragged sizes) this leaves no
+batch-size-dependent arithmetic unchecked: everything else in the network is per-image.
 
 Reference call sites: BEV/main.py:213-223,264-265; BP/main.py:256-263,286-305.
 
-Criterion (lane coefficients / back-projected x, loss, logits, d loss / d logits): |hip - cpu64| <= 2 * |cpu32 - cpu64| -- the HIP path may be no further from the fp64 truth than twice the distance of
-the reference arithmetic's own fp32 run -- with a small absolute floor where the fp32 leg happens to land on the fp64 one.
+Criterion (lane coefficients / back-projected x, loss, logits, d loss / d logits): |hip - cpu64| <= 1.5 * |cpu32 - cpu64| (round 4;
+2x before the convolutions' two-accumulator summation) -- the HIP path may be no further from the fp64 truth than 1.5x the
+distance of the reference arithmetic's own fp32 run -- with a small absolute floor where the fp32 leg happens to land on the
+fp64 one.
 The norm is the RMS for the tensors (the statistic that is stable when two independent roundoff-noise fields are compared:
 both legs are draws of the same noise process through a chaotic train-mode network) and the maximum for the scalars and the
-lane coefficients; the maximum over the 1e7..3e7 elements of a tensor is printed too and held to 4x (one extreme sample of
+lane coefficients; the maximum over the 1e7..3e7 elements of a tensor is printed too and held to 2x (one extreme sample of
 one draw against one extreme sample of another).  All three numbers are printed.  Dropout is off (p = 0): the draw of torch's generator cannot be shared with the oracle at
 this size; the masked path is covered in tests/test_backbone_gpu.py.
 Parameter gradients (round 3): every tensor against the fp64 oracle evaluated STRAIGHT-THROUGH at the engine's own forward state
-and driven by the engine's own d loss / d logits -- backward arithmetic only, held to 5e-5 of each tensor's maximum at these sizes.
+and driven by the engine's own d loss / d logits -- backward arithmetic only, held to 3e-5 of each tensor's maximum at these sizes.
 """
 import os
 from argparse import Namespace
@@ -48,6 +60,11 @@ def _prepare(model, P, precision):
     return model.train()
 
 
+# scalars and lane coefficients (a maximum over <= 200 numbers of one noise draw against another): measured over six seeds in round 4
+# 0.87 - 1.71, so a single draw is held to 2x; the RMS statistics of the 1e7-element tensors to 1.5x (measured 0.83 - 0.91)
+MAXNORM_BAND = 2.0
+
+
 def _check(name, hip, r32, r64, abs_floor, rel=True, rms=False):
     hip, r32, r64 = (np.asarray(v, dtype=np.float64) for v in (hip, r32, r64))
     scale = max(np.abs(r64).max(), 1e-300) if rel else 1.0
@@ -57,10 +74,10 @@ def _check(name, hip, r32, r64, abs_floor, rel=True, rms=False):
         q = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2))) / scale
         r64e, r32e, rfl = q(hip, r64), q(hip, r32), q(r32, r64)
         print("%-28s rms: |hip-cpu64| %.3e   |hip-cpu32| %.3e   |cpu32-cpu64| %.3e" % ("", r64e, r32e, rfl))
-        assert r64e <= max(2.0 * rfl, abs_floor), (name, "rms", r64e, rfl)
-        assert e64 <= max(2.5 * floor, abs_floor), (name, "max", e64, floor)       # max norms: extreme-value statistic (measured <= 1.9)
+        assert r64e <= max(1.5 * rfl, abs_floor), (name, "rms", r64e, rfl)
+        assert e64 <= max(2.0 * floor, abs_floor), (name, "max", e64, floor)       # max norms: extreme-value statistic
     else:
-        assert e64 <= max(2.0 * floor, abs_floor), (name, e64, floor)
+        assert e64 <= max(MAXNORM_BAND * floor, abs_floor), (name, e64, floor)
     return e64, floor
 
 
@@ -166,11 +183,15 @@ def test_bev_distance_ratio_over_seeds():
     chaotic train-mode network against one fp64 run), so ONE seed says little.  Six seeds at 8 x 3 x 256 x 512 (the headline's
     geometry and statistics path, a quarter of its batch so that the twelve CPU legs stay within a couple of minutes): the
     distribution of the ratio is printed for the lane coefficients (max norm over 6 numbers per image pair: the noisiest), the
-    logits and d loss / d logits (RMS).  Measured in round 3: logits 1.21-1.30 (median 1.24), d loss / d logits 1.20-1.35 (1.22),
-    coefficients 1.17-2.05 (1.34): the HIP path is SYSTEMATICALLY ~1.25x further from fp64 than oneDNN's fp32 -- a K = 384 fma
-    chain in one accumulator against blocked partial sums; two accumulator sets per output tile would halve the chain but cost 64
-    registers (two waves per SIMD instead of three).  Held to: RMS ratios median <= 1.3, max <= 1.5; coefficients median <= 1.5,
-    max <= 2.5."""
+    logits and d loss / d logits (RMS).
+    Round 3 measured logits 1.21-1.30 (median 1.24), d loss / d logits 1.20-1.35 (1.22), coefficients 1.17-2.05 (1.34): the HIP
+    path was SYSTEMATICALLY ~1.25x further from fp64 than oneDNN's fp32.  Round 4 found the cause on the CPU
+    (tools/accum_study.py: the fp32 oracle with the kernel's summation order emulated reproduces 1.31x; it is the ONE fma chain
+    per output element over K = 192 / 384 products, chiefly in the 64-channel layers -- not the folded BatchNorm, not the fp32
+    statistics partials) and removed it: the tap-GEMM sums segments of 32 products into a second accumulator set (emulated
+    0.90x).  Measured on MI355X with the same six seeds and CPU legs, round-3 library vs round-4 library on one box:
+    logits 1.24 -> 0.85 (0.83-0.88), d loss / d logits 1.22 -> 0.86 (0.79-0.91), coefficients 1.34 -> 1.23 (0.87-1.71).
+    Held to: RMS ratios median <= 1.0, max <= 1.1; coefficients median <= 1.3, max <= 2.0."""
     from lanedetection_end2end_amd.bev.Loss_crit import Area_Loss
     from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Net
     N, R = 8, 256
@@ -201,7 +222,7 @@ def test_bev_distance_ratio_over_seeds():
         v = np.array(v)
         print("|hip - cpu64| / |cpu32 - cpu64|  %-8s  per seed %s   median %.2f  max %.2f" % (k, np.round(v, 2), np.median(v), v.max()))
     for k, v in ratios.items():
-        lim = (1.5, 2.5) if k == "beta" else (1.3, 1.5)
+        lim = (1.3, 2.0) if k == "beta" else (1.0, 1.1)
         assert np.median(v) <= lim[0] and max(v) <= lim[1], (k, v)
 
 
@@ -304,3 +325,181 @@ def test_c3_bf16_training_tracks_fp32():
     for m in ("bf16_mfma", "bf16"):
         assert abs(curves[m][0] - ref[0]) <= 0.02 * abs(ref[0]), (m, curves[m][0], ref[0])
         assert abs(curves[m][-10:].mean() - ref[-10:].mean()) <= 0.05 * ref[-10:].mean(), (m, curves[m][-10:].mean(), ref[-10:].mean())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# C3 and C5 AT THEIR OWN BATCH SIZES (64 in fp32 and bf16; 16): transitive checks (module docstring)
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def _bn_sites():
+    """(layer index, slot of the pre-BN tensor, bn index within the layer, state_dict prefix of the BatchNorm, channels)."""
+    out = []
+    for li, (prefix, kind, cin, cout, _, _) in enumerate(erfnet_oracle.layer_table()):
+        if kind == "nb1d":
+            out += [(li, 1, 0, prefix + ".bn1", cout), (li, 3, 1, prefix + ".bn2", cout)]
+        else:
+            out.append((li, 0, 0, prefix + ".bn", cout))
+    return out
+
+
+def _layer_hw(H, W):
+    hw, h, w = [], H, W
+    for prefix, kind, *_ in erfnet_oracle.layer_table():
+        if kind == "down":
+            h, w = h // 2, w // 2
+        elif kind == "up":
+            h, w = h * 2, w * 2
+        hw.append((h, w))
+    return hw
+
+
+def _check_bn_statistics_at_full_batch(net, x, precision):
+    """Train-mode forward at the configuration's own batch; every BatchNorm's folded statistics and running-statistics update
+    against an fp64 reduction (on the GPU, torch) of the engine's own pre-BN tensor as stored (bf16 tensors in mode "bf16")."""
+    from lanedetection_end2end_amd import _lib
+    lib = _lib.load()
+    N, _, H, W = x.shape
+    net.precision = precision
+    net.train()
+    fresh = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+    _, dec = net(x, True)[:2]
+    plan, ws = net._plan(N, H, W), dec.grad_fn.ws
+    hw = _layer_hw(H, W)
+    sd = net.state_dict()
+    worst = dict(mean=0.0, rstd=0.0, rmean=0.0, rvar=0.0)
+    for li, slot, bn, prefix, C in _bn_sites():
+        h, w = hw[li]
+        off = lib.lf_erfnet_activation_offset(plan.handle, li, slot)
+        n = N * h * w * C
+        if precision == "bf16":
+            t = ws.view(torch.bfloat16)[2 * off: 2 * off + n]
+        else:
+            t = ws.view(torch.float32)[off: off + n]
+        t = t.view(-1, C).double()
+        mean, var = t.mean(0), t.var(0, unbiased=False)
+        cnt = t.shape[0]
+        del t
+        vec = [ws.view(torch.float32)[o: o + C].double() for o in
+               (lib.lf_erfnet_bn_vector_offset(plan.handle, li, bn, 2), lib.lf_erfnet_bn_vector_offset(plan.handle, li, bn, 3))]
+        rstd_e, mean_e = vec[0], -vec[1] / vec[0]
+        rstd = torch.rsqrt(var + erfnet_oracle.BN_EPS)
+        std = torch.sqrt(var + erfnet_oracle.BN_EPS)
+        e_rstd = float(((rstd_e - rstd).abs() / rstd).max())
+        e_mean = float(((mean_e - mean).abs() / (mean.abs() + std)).max())
+        rm = 0.9 * fresh[prefix + ".running_mean"].double() + 0.1 * mean
+        rv = 0.9 * fresh[prefix + ".running_var"].double() + 0.1 * var * cnt / (cnt - 1)
+        e_rm = float(((sd[prefix + ".running_mean"].double() - rm).abs() / (rm.abs() + 0.1 * std)).max())
+        e_rv = float(((sd[prefix + ".running_var"].double() - rv).abs() / rv).max())
+        for k, v in zip(("mean", "rstd", "rmean", "rvar"), (e_mean, e_rstd, e_rm, e_rv)):
+            worst[k] = max(worst[k], v)
+        # fp32 partial sums of y and y^2 per 256-pixel tile, combined in fp64: var = E[y^2] - mean^2 keeps ~1e-7 * (1 + mean^2 / var)
+        assert e_rstd < 1e-5 and e_mean < 1e-5 and e_rm < 1e-5 and e_rv < 2e-5, (prefix, e_mean, e_rstd, e_rm, e_rv)
+    print("BatchNorm statistics at batch %d (%s), %d BatchNorms, worst relative error: batch mean %.1e, rstd %.1e, running mean "
+          "%.1e, running var %.1e" % (N, precision, len(_bn_sites()), worst["mean"], worst["rstd"], worst["rmean"], worst["rvar"]))
+    assert torch.isfinite(dec).all()
+
+
+def _eval_chunks_equal_full_batch(model, call, x, chunk, precision, P, oracle_check):
+    """Eval mode (running statistics): the full-batch run == the per-chunk runs, image by image (logits, lane coefficients), and
+    the parameter gradients of sum(logits * gy) at the full batch == the sum of the chunks' gradients.  The first chunk's logits
+    are checked against the CPU oracle in the same mode (fp32 cores: both legs; bf16: bf16-level agreement with fp64)."""
+    N = x.shape[0]
+    net = model.net
+    net.precision = precision
+    model.eval()
+    gy = torch.from_numpy(np.random.default_rng(77).standard_normal(tuple(call(x[:chunk])[1].shape[1:])).astype(np.float32)).cuda()
+    for p in model.parameters():
+        p.grad = None
+    betas_f, logits_f = call(x)
+    (logits_f * gy).sum().backward()
+    g_full = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    lmax = float(logits_f.detach().abs().max())
+    g_sum = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in g_full.items()}
+    worst_l = worst_b = 0.0
+    first = None
+    for c in range(0, N, chunk):
+        for p in model.parameters():
+            p.grad = None
+        betas_c, logits_c = call(x[c: c + chunk])
+        if first is None:
+            first = logits_c.detach()
+        (logits_c * gy).sum().backward()
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                g_sum[k] += p.grad.double()
+        worst_l = max(worst_l, float((logits_c.detach() - logits_f.detach()[c: c + chunk]).abs().max()) / lmax)
+        for bf, bc in zip(betas_f, betas_c):
+            if bf is not None:
+                worst_b = max(worst_b, float((bc.detach() - bf.detach()[c: c + chunk]).abs().max() / bf.detach().abs().max()))
+    worst_g = 0.0
+    for k, v in g_full.items():
+        scale = float(g_sum[k].abs().max())
+        if scale == 0.0:
+            continue
+        worst_g = max(worst_g, float((v.double() - g_sum[k]).abs().max()) / scale)
+    print("batch %d vs %d chunks of %d (%s, eval): logits %.1e of max, lane coefficients %.1e, parameter gradients vs the chunk sum %.1e"
+          % (N, N // chunk, chunk, precision, worst_l, worst_b, worst_g))
+    assert worst_l <= 1e-6 and worst_b <= 1e-6
+    assert worst_g <= (2e-5 if precision == "fp32" else 2e-2)     # summation order of the split-K weight gradient differs with the batch
+    if oracle_check:
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        legs = {}
+        for dt in (torch.float32, torch.float64):
+            Pd = erfnet_oracle.cast_params(sd, dt)
+            with torch.no_grad():
+                legs[dt] = erfnet_oracle.erfnet_forward(x[:chunk].cpu().to(dt), Pd, training=False)[1].double().numpy()
+        got = first.cpu().double().numpy()
+        rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)))
+        e64, fl = rms(got, legs[torch.float64]), rms(legs[torch.float32], legs[torch.float64])
+        scale = float(np.abs(legs[torch.float64]).max())
+        print("first chunk vs the CPU oracle (eval): rms |hip-cpu64| %.2e  |cpu32-cpu64| %.2e (of max |logits|)" % (e64 / scale, fl / scale))
+        if precision == "fp32":
+            assert e64 <= max(1.5 * fl, 2e-6 * scale), (e64, fl)
+        else:
+            assert e64 <= 3e-2 * scale, (e64, scale)            # bf16 products, fp32 accumulation, 70 layers
+
+
+def _warm_running_stats(model, call, x_small):
+    """Non-trivial running statistics for the eval-mode runs: one train-mode forward on a small batch."""
+    model.train()
+    with torch.no_grad():
+        call(x_small)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_c3_bp_batch64_transitive(precision):
+    """BASELINE config 3 at its own size and dtype: 64 x 3 x 320 x 640, 4 lanes, fp32 and bf16."""
+    from lanedetection_end2end_amd.bp.Networks.LSQ_layer import Net
+    N, R, K = 64, 320, 4
+    P = erfnet_oracle.make_params(seed=5, out_channels=K)
+    x = torch.from_numpy(inputs.images(N, R, 2 * R, seed=171)).cuda()
+    model = _prepare(Net(_args(N, R, K, "bp")), P, "fp32")
+    gl = torch.zeros(4, K)
+
+    def call(xb):
+        out = model(xb, gl, True)
+        return out[:4], out[5]
+    _check_bn_statistics_at_full_batch(model.net, x, precision)
+    model.net.load_state_dict(P)                                   # fresh running statistics again
+    model.net.precision = "fp32"
+    _warm_running_stats(model, call, x[:4])
+    _eval_chunks_equal_full_batch(model, call, x, 4, precision, P, oracle_check=True)
+    model.net.precision = "fp32"
+
+
+def test_c5_seg_batch16_transitive():
+    """BASELINE config 5's per-GPU shard at its own size: 16 x 3 x 512 x 1024, Cout = 3 (segmentation branch, early_return)."""
+    from lanedetection_end2end_amd.bp.Networks.LSQ_layer import Net
+    N, R, K = 16, 512, 2
+    P = erfnet_oracle.make_params(seed=6, out_channels=K + 1)
+    x = torch.from_numpy(inputs.images(N, R, 2 * R, seed=181)).cuda()
+    model = _prepare(Net(_args(N, R, K, "bp", end_to_end=False)), P, "fp32")
+    gl = torch.zeros(2, K)
+
+    def call(xb):
+        return (None,), model(xb, gl, False, early_return=True)
+    _check_bn_statistics_at_full_batch(model.net, x, "fp32")
+    model.net.load_state_dict(P)
+    _warm_running_stats(model, call, x[:2])
+    _eval_chunks_equal_full_batch(model, call, x, 2, "fp32", P, oracle_check=True)

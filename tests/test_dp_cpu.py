@@ -120,3 +120,40 @@ def test_epoch_batches_config4_sharding():
     assert len(one) == 113 and all(len(b) == 32 for b in one)        # 1 GPU: 113 steps, 10 frames dropped
     assert not np.array_equal(one[0], next(dp.epoch_batches(3626, 32, seed=5, epoch=1)))    # reshuffled per epoch
     assert np.array_equal(np.concatenate(list(dp.epoch_batches(64, 32, shuffle=False))), np.arange(64))
+
+
+def _premul_avg(per_rank_values, world):
+    """What RCCL's ReduceOp.AVG computes for fp32: every rank's value times fp32(1 / world), then an fp32 sum (rank order)."""
+    import numpy as np
+    inv = np.float32(1.0) / np.float32(world)
+    acc = np.zeros(per_rank_values.shape[1], dtype=np.float32)
+    for r in range(world):
+        acc = (acc + per_rank_values[r].astype(np.float32) * inv).astype(np.float32)
+    return acc
+
+
+def test_signature_survives_premul_avg_rounding():
+    """with ReduceOp.AVG at a world size whose reciprocal is inexact in fp32 (3, 5, 6, 7, 12) the
+    rank-agreement signature must neither fire on identical sets (every hash value) nor miss a single deviating rank."""
+    import numpy as np
+    from lanedetection_end2end_amd import dp
+    sig = lambda h1, h2, h3: np.array([1.0, h1, h1 * h1, h2, h2 * h2, h3, h3 * h3, 0.0], dtype=np.float32)
+    rng = np.random.default_rng(0)
+    for world in (2, 3, 5, 6, 7, 8, 12, 64):
+        for h1 in range(dp.HASH_MODS[0]):                      # identical on every rank: all values of every hash
+            for h2, h3 in ((h1 * 2 % dp.HASH_MODS[1], h1 * 2 % dp.HASH_MODS[2]), (dp.HASH_MODS[1] - 1, dp.HASH_MODS[2] - 1)):
+                same = np.stack([sig(h1, h2, h3)] * world)
+                assert not dp.signature_disagrees(_premul_avg(same, world), world), (world, h1, h2, h3)
+                assert not dp.signature_disagrees(same.sum(0), world)                      # gloo: SUM, divided by check
+        for _ in range(200):                                   # ONE rank differs by one in ONE hash: must be seen
+            h = [int(rng.integers(1, m - 1)) for m in dp.HASH_MODS]
+            rows = [sig(*h)] * world
+            k = int(rng.integers(0, 3))
+            h2 = list(h)
+            h2[k] += 1 if rng.random() < 0.5 else -1
+            rows[int(rng.integers(0, world))] = sig(*h2)
+            assert dp.signature_disagrees(_premul_avg(np.stack(rows), world), world), (world, h, h2)
+    # the real hashes of real active sets: the reference's head switch changes every hash
+    a = dp.FlatGradAllReduce._hashes(list(range(226)))
+    b = dp.FlatGradAllReduce._hashes(list(range(224)) + [226, 227])
+    assert a != b and max(a) < 64

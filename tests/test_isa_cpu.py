@@ -48,10 +48,18 @@ def test_no_vgpr_spills_in_network_kernels(conv_kernels):
 
 def test_register_budgets(conv_kernels):
     by = {k["name"]: k for k in conv_kernels}
-    # three waves per SIMD (<= 168 registers) for the most frequent launches of the step
-    for name in ("tapgemm_kernel<4, 0, 8, true, false>", "tapgemm_kernel<4, 0, 1, true, false>", "tapgemm_kernel<4, 0, 2, true, false>",
-                 "tapgemm_kernel<4, 1, 1, true, false>", "tapgemm_kernel<4, 0, 0, true, false>"):
-        assert by[name]["vgpr"] <= 168, (name, by[name]["vgpr"])
+    # round 4: two accumulator sets (128 registers) + two operand sets (64) -- two waves per SIMD (<= 256 registers) for every
+    # compiled-in variant the step launches, both row forms (round 3: one accumulator set, three waves per SIMD at <= 168)
+    hot = [k for k in conv_kernels if k["name"].startswith("tapgemm_kernel<4, ") and ", -1, " not in k["name"]]
+    assert len(hot) >= 18
+    for k in hot:
+        assert k["vgpr"] + k["agpr"] <= 256, (k["name"], k["vgpr"], k["agpr"])
+    # the run-time-flag forms (cold paths) take the whole register file instead of spilling: one wave per SIMD
+    for name in ("tapgemm_kernel<4, 0, -1, true, false>", "tapgemm_kernel<4, 1, -1, false, false>"):
+        assert by[name]["vgpr_spill"] == 0 and by[name]["vgpr"] + by[name]["agpr"] <= 512, (name, by[name])
+    # the 16-channel kernel keeps four workgroups per CU (<= 128 registers)
+    for k in _select(conv_kernels, "tapgemm_lean_kernel<"):
+        assert k["vgpr"] <= 128, (k["name"], k["vgpr"])
     # the phase-stamp code exists only in the DBG instantiations
     dbg = [k["name"] for k in conv_kernels if k["name"].endswith(", true>") and k["name"].startswith(("tapgemm_kernel<", "tapwgrad_kernel<"))
            and k["name"].count("true>")]

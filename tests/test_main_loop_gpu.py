@@ -1,11 +1,13 @@
-"""The reference's training-loop body executed on the mirror (Missing #5).
+"""The reference's training-loop bodies executed on the mirror (Missing #5; round 3, Missing #4: the BP tree).
 
 The reference itself is absent on the GPU box, so its main.py cannot run here; this is a replica of the statement sequence of
 BEV/main.py:200-266 -- same import names through the path arrangement of tools/run_reference_main.py (the mirrored tree first
 on sys.path: ``from Networks.LSQ_layer import Net``, ``from Loss_crit import define_loss_crit, polynomial``), a stub loader
 yielding the loader's 6-tuples, ``model(input, end_to_end)`` -> per-lane ``criterion`` -> ``loss.item()`` -> ``zero_grad /
 backward / step``, the ``except RuntimeError: continue`` skip of a singular batch, the --clas branch, and the exact-area metric
-on ``.cpu()`` copies."""
+on ``.cpu()`` copies.  ``test_bp_main_loop_body`` does the same for BP/main.py:232-337: the ``skip`` branch (``early_return=True`` ->
+``criterion_seg``, :256-263), ``model(input, gt_line, end_to_end, gt=gt)`` -> ``criterion(beta_k, gt_k, valid_points[:, k])`` per lane
+-> ``/ nclasses`` (:286-305), the segmentation-mode branch with its ``no_grad`` metric (:306-318), and the --clas losses (:321-326)."""
 import importlib
 import os
 import sys
@@ -22,9 +24,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture()
-def bev_tree_on_path():
-    tree = os.path.join(ROOT, "lanedetection_end2end_amd", "bev")
+def _tree_on_path(name):
+    tree = os.path.join(ROOT, "lanedetection_end2end_amd", name)
     saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "Networks" or k.startswith("Networks.") or k == "Loss_crit"}
     sys.path.insert(0, tree)
     try:
@@ -34,6 +35,16 @@ def bev_tree_on_path():
         for k in [k for k in sys.modules if k == "Networks" or k.startswith("Networks.") or k == "Loss_crit"]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+@pytest.fixture()
+def bev_tree_on_path():
+    yield from _tree_on_path("bev")
+
+
+@pytest.fixture()
+def bp_tree_on_path():
+    yield from _tree_on_path("bp")
 
 
 class AverageMeter:          # BEV/Networks/utils.py AverageMeter, the four lines the loop uses
@@ -118,5 +129,105 @@ def test_bev_main_loop_body(bev_tree_on_path, clas):
             exact_area.update(((trap_left + trap_right) / 2).mean().item(), input.size(0))
     assert skipped == 1 and stepped == 3 and losses.count == 3 * N
     assert np.isfinite(losses.sum) and np.isfinite(exact_area.sum) and exact_area.sum > 0
+    assert not torch.equal(model.net.encoder.initial_block.conv.weight.detach(), w0)       # the optimizer moved the weights
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("clas,nclasses", [(False, 4), (False, 2), (True, 4)])
+def test_bp_main_loop_body(bp_tree_on_path, clas, nclasses):
+    Net = importlib.import_module("Networks.LSQ_layer").Net              # BP/main.py:25
+    Loss_crit = importlib.import_module("Loss_crit")                      # BP/main.py:24
+    define_loss_crit = Loss_crit.define_loss_crit
+    from lanedetection_end2end_amd.optim import define_optim             # same signature as Networks.utils.define_optim
+    N, R = 2, (256 if clas else 64)      # the --clas heads are built for the 32 x 64 encoder output of resize 256
+    # --pretrained True: the decoder carries output_conv2 (nclasses + 1 logits) for the segmentation pretraining epochs and
+    # output_conv for the end-to-end ones; get_flags (main.py:32-44) flips args.end_to_end between them
+    args = Namespace(batch_size=N, nclasses=nclasses, resize=R, end_to_end=True, mod="erfnet", layers=18, channels_in=3,
+                     pretrained=True, pool=True, activation_layer="square", no_cuda=False, order=2, reg_ls=0.0,
+                     use_cholesky=False, mask_percentage=0.2, clas=clas, no_mapping=False, loss_policy="backproject",
+                     weight_funct="none", weight_seg=30, optimizer="adam", learning_rate=1e-4, weight_decay=0.0,
+                     clip_grad_norm=0, weight_fit=1.0, weight_class=1.0)
+    torch.manual_seed(5)
+    model = Net(args)                                                      # main.py:94
+    if not args.no_cuda:
+        model = model.cuda()                                               # main.py:97-100
+    optimizer = define_optim(args.optimizer, model.parameters(), args.learning_rate, args.weight_decay)   # main.py:102-103
+    criterion, criterion_seg = define_loss_crit(args)                      # main.py:108
+    criterion_horizon = nn.BCEWithLogitsLoss().cuda()                      # main.py:109
+    criterion_line_class = nn.BCEWithLogitsLoss().cuda()                   # main.py:110
+    rng = np.random.default_rng(13)
+
+    def loader(nbatches):                                                  # the 7-tuple of BP Load_Data_new.__getitem__ batches
+        for i in range(nbatches):
+            lanes, valid = inputs.bp_targets(N, 4, R, seed=700 + i)
+            yield (torch.from_numpy(inputs.images(N, R, 2 * R, seed=300 + i)),
+                   torch.from_numpy(inputs.seg_targets(N, R, 2 * R, nclasses + 1, seed=500 + i)).unsqueeze(1),
+                   torch.from_numpy(lanes), torch.arange(N) + i * N, torch.zeros(N, 4),
+                   torch.from_numpy((rng.uniform(0, 1, (N, R)) > 0.5).astype(np.float32)), torch.from_numpy(valid))
+
+    losses, rmse_metric, losses_skip = AverageMeter(), AverageMeter(), AverageMeter()
+    model.train()                                                          # main.py:226
+    w0 = model.net.encoder.initial_block.conv.weight.detach().clone()
+    # get_flags over the epochs of a pretrained run: skip (epoch < skip_epochs), segmentation mode (epoch < pretrain_epochs), end to end
+    schedule = [(True, False), (False, False), (False, True), (False, True)]
+    for i, (input, gt, lanes, idx, gt_line, gt_horizon, valid_points) in enumerate(loader(len(schedule))):
+        skip, args.end_to_end = schedule[i]
+        if not args.no_cuda:                                               # main.py:245-248
+            input, lanes = input.cuda(), lanes.cuda()
+            valid_points = valid_points.cuda()
+            gt = gt.cuda().squeeze(1)
+        assert lanes.size(1) == 4
+        gt0, gt1, gt2, gt3 = lanes[:, 0, :], lanes[:, 1, :], lanes[:, 2, :], lanes[:, 3, :]
+        if skip:                                                           # main.py:254-262
+            output_net = model(input, gt_line, args.end_to_end, early_return=True)
+            assert tuple(output_net.shape) == (N, nclasses + 1, R, 2 * R)          # decoder.output_conv2
+            loss = criterion_seg(output_net, gt)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            losses_skip.update(loss.item(), input.size(0))
+            continue
+        beta0, beta1, beta2, beta3, weightmap_zeros, output_net, outputs_line, outputs_horizon, output_seg = \
+            model(input, gt_line, args.end_to_end, gt=gt)                  # main.py:287-289
+        assert output_net.shape[1] == nclasses + int(not args.end_to_end)
+        if args.end_to_end:                                                # main.py:296-305
+            loss_left, x_cal0 = criterion(beta0, gt0, valid_points[:, 0])
+            loss_right, x_cal1 = criterion(beta1, gt1, valid_points[:, 1])
+            if args.nclasses > 3:
+                loss_left1, x_cal2 = criterion(beta2, gt2, valid_points[:, 2])
+                loss_right1, x_cal3 = criterion(beta3, gt3, valid_points[:, 3])
+                loss_left += loss_left1
+                loss_right += loss_right1
+            else:
+                assert beta2 is None and beta3 is None
+            loss = (loss_left + loss_right) / args.nclasses
+            assert x_cal0.shape == (N, 56) and beta0.dtype == torch.float64
+        else:                                                              # main.py:306-318
+            loss = criterion_seg(output_net, gt)
+            with torch.no_grad():
+                loss_left, x_cal0 = criterion(beta0, gt0, valid_points[:, 0])
+                loss_right, x_cal1 = criterion(beta1, gt1, valid_points[:, 1])
+                if args.nclasses > 3:
+                    loss_left1, x_cal2 = criterion(beta2, gt2, valid_points[:, 2])
+                    loss_right1, x_cal3 = criterion(beta3, gt3, valid_points[:, 3])
+                    loss_left += loss_left1
+                    loss_right += loss_right1
+                loss_metric = (loss_left + loss_right) / args.nclasses
+                rmse_metric.update(loss_metric.item(), input.size(0))
+        if args.clas and args.end_to_end:                                  # main.py:321-326 (the heads run with end_to_end only)
+            gt_horizon, gt_line = gt_horizon.cuda(), gt_line.cuda()
+            loss_horizon = criterion_horizon(outputs_horizon, gt_horizon).double()
+            loss_line = criterion_line_class(outputs_line, gt_line).double()
+            loss = loss * args.weight_fit + (loss_line + loss_horizon) * args.weight_class
+            assert tuple(outputs_line.shape) == (N, 4) and tuple(outputs_horizon.shape) == (N, R)
+        losses.update(loss.item(), input.size(0))                          # main.py:331
+        optimizer.zero_grad()                                              # main.py:338-340
+        loss.backward()
+        optimizer.step()
+    criterion_seg.flush()                  # (the deferred target-range check of the last batch: losses.CrossEntropyLoss2d)
+    assert losses_skip.count == N and losses.count == 3 * N and rmse_metric.count == N
+    # the head switch of the schedule: both heads were trained at some point, each only in its own phase
+    assert model.net.decoder.output_conv.weight.grad is not None
+    assert np.isfinite(losses.sum) and np.isfinite(losses_skip.sum) and np.isfinite(rmse_metric.sum)
     assert not torch.equal(model.net.encoder.initial_block.conv.weight.detach(), w0)       # the optimizer moved the weights
     assert all(torch.isfinite(p).all() for p in model.parameters())
