@@ -191,6 +191,22 @@ int lf_pointwise_fwd(const float* x, const float* w, const float* b, float* y, i
 long lf_pointwise_scratch_floats(int N, int h, int w_, int C, int K);
 int lf_pointwise_bwd(const float* x, const float* gy, const float* w, float* gx, float* gw, float* gb, int N, int h, int w_,
                      int C, int K, float* scratch, void* stream);
+/* ------------------------------------------------------------------------------------
+ * Cold-path arithmetic natively (round 4): the nn.Linear tails of the --clas heads and the segmentation-mode fit input.
+ *
+ * lf_linear_fwd: y (N,O) = act(x (N,K) @ w (O,K)^T + b (O) or NULL), act = identity or ReLU (relu = 1).  Replaces
+ *   F.relu(self.fully_connected1(x)), self.fully_connected_line1(x), self.fully_connected_horizon(x)
+ *   (BP/Networks/LSQ_layer.py:186-189,199-207; BEV/Networks/LSQ_layer.py:198-205,218-226).  fp32, fixed summation order.
+ * lf_linear_bwd: gy (N,O) [+ y, the forward's output, when relu] -> gx (N,K), gw (O,K), gb (O); NULL outputs are skipped
+ *   (gb needs gw).  Written, not accumulated.
+ * lf_seg_maps: logits (N,C,H,W) -> maps (N,L,H,W): per-lane maps valued k where the arg-max over the C class logits is k
+ *   (first maximum, like torch.max), rows < zero_rows zeroed (index_fill), lanes flagged in gt_line (N,L fp32, or NULL) set to
+ *   map [0,0] -- Net.forward(end_to_end=False): BEV/Networks/LSQ_layer.py:302-308,316; BP/Networks/LSQ_layer.py:279-293,298,308-311. */
+int lf_linear_fwd(const float* x, const float* w, const float* b, float* y, int N, int K, int O, int relu, void* stream);
+int lf_linear_bwd(const float* x, const float* w, const float* y, const float* gy, float* gx, float* gw, float* gb, int N, int K,
+                  int O, int relu, void* stream);
+int lf_seg_maps(const float* logits, const float* gt_line, float* maps, int N, int C, int L, int H, int W, int zero_rows,
+                void* stream);
 /* Roofline instrumentation (bench.py): HIP event pairs around every matrix-core launch of the engine.
  * out6 = {ms, algorithmic FLOPs, launches} for family 0 (tap-GEMM forward + data gradient) and
  * family 1 (weight gradient), accumulated since the last read. */

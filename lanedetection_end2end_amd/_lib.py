@@ -78,6 +78,9 @@ def _declare(lib):
         "lf_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_weight": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+        "lf_linear_fwd": (I, [P, P, P, P, I, I, I, I, P]),
+        "lf_linear_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+        "lf_seg_maps": (I, [P, P, P, I, I, I, I, I, I, P]),
         "lf_erfnet_set_precision": (I, [P, I]),
         "lf_erfnet_profile": (I, [P, I]),
         "lf_erfnet_profile_read": (I, [P, P, c_char_p]),

@@ -16,9 +16,8 @@ import ctypes
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from . import _lib, geometry
+from . import _lib, geometry, ops
 
 
 def _ptr_array(tensors):
@@ -144,7 +143,7 @@ class Classification(nn.Module):
         self.fully_connected_line1 = nn.Linear(128, 4)
 
     def _line_logits(self, f):
-        return self.fully_connected_line1(f)
+        return ops.linear(f, self.fully_connected_line1.weight, self.fully_connected_line1.bias)
 
     def _batchnorms(self):
         return [self.conv1_bn, self.conv2_bn, self.conv3_bn, self.conv4_bn]
@@ -183,10 +182,10 @@ class Classification(nn.Module):
         y = self.trunk(x)
         if self.class_type == 'line':
             f = _PoolFlatFn.apply(y, 0)
-            f = F.relu(self.fully_connected1(f))
+            f = ops.linear(f, self.fully_connected1.weight, self.fully_connected1.bias, relu=True)      # F.relu(fc1(f)), one launch
             return self._line_logits(f)
         f = _PoolFlatFn.apply(y, 1)
-        return self.fully_connected_horizon(f)
+        return ops.linear(f, self.fully_connected_horizon.weight, self.fully_connected_horizon.bias)
 
 
 class ClassificationBEV(Classification):
@@ -201,8 +200,8 @@ class ClassificationBEV(Classification):
 
     def _line_logits(self, f):
         heads = [getattr(self, "fully_connected_line%d" % i) for i in range(1, 5)]
-        y = F.linear(f, torch.cat([h.weight for h in heads], 0), torch.cat([h.bias for h in heads], 0))    # (N, 12), head-major
-        return y.view(f.size(0), 4, 3).transpose(1, 2)                                                       # (N, 3, 4)
+        y = torch.stack([ops.linear(f, h.weight, h.bias) for h in heads], 2)      # four (N, 3) GEMVs (lf_linear_fwd) -> (N, 3, 4)
+        return y
 
 
 def resize_coordinates(array):

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import erfnet, fit, geometry
+from . import erfnet, fit, geometry, ops
 from .clas import Classification, ClassificationBEV
 
 
@@ -79,12 +79,12 @@ class _LaneFitNet(nn.Module):
             return self.line_classification(shared_encoder), self.horizon_estimation(shared_encoder)
         return None, None
 
-    def _seg_maps(self, output):
-        """Non-end-to-end path: arg-max of the segmentation logits -> per-lane maps valued k at class k
-        (LSQ_layer.py:302-308; BP :279-293), detached."""
-        act = output.detach().argmax(1).float()
-        ks = range(1, (2 if self.nclasses < 3 else 4) + 1)
-        return torch.stack([act * (act == k).float() for k in ks], 1)
+    def _seg_maps(self, output, gt_line=None):
+        """Non-end-to-end path: arg-max of the segmentation logits -> per-lane maps valued k at class k (LSQ_layer.py:302-308;
+        BP :279-293), the masked rows zeroed (``index_fill``) and, in the BP tree, "Prevent singular matrix" (BP :308-311): lanes
+        flagged in ``gt_line`` borrow map [0, 0].  One launch (``lf_seg_maps``), detached, no host read of ``gt_line.sum()``."""
+        lanes = 2 if self.nclasses < 3 else 4
+        return ops.seg_maps(output, gt_line, self.zero_rows, lanes)
 
     def _fit(self, output, end_to_end, gt_line=None):
         grid = self.grid_on(output.device)
@@ -94,13 +94,10 @@ class _LaneFitNet(nn.Module):
                                                  self.activation_name, self.use_cholesky, self.return_masked,
                                                  self.check_singular)
         else:
-            maps = self._seg_maps(output)
-            maps[:, :, : self.zero_rows] = 0
-            if gt_line is not None and gt_line.sum() != 0:
-                # "Prevent singular matrix" (BP/Networks/LSQ_layer.py:308-311): absent lanes borrow map [0,0]
-                sel = gt_line.bool()
-                maps[sel] = maps[0, 0].clone()
-            beta, _, status = fit.fit_lanes(maps, grid, 0, self.order, reg, self.y_offset, "none",
+            maps = self._seg_maps(output, gt_line)
+            # (the masked rows are zeros already; handing zero_rows to the fit keeps its kernels from reading them at all --
+            # at 320 x 640 the BP grid has a pole on a masked row, and 0 * inf is NaN)
+            beta, _, status = fit.fit_lanes(maps, grid, self.zero_rows, self.order, reg, self.y_offset, "none",
                                             self.use_cholesky, False, self.check_singular)
             masked = maps
         self.last_status = status

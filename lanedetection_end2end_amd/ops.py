@@ -185,3 +185,64 @@ class CrossEntropy2dFn(torch.autograd.Function):
         _lib.check(lib.lf_ce2d_bwd(_lib.ptr(logits), _lib.ptr(target), _lib.ptr(weights), N, C, H, W,
                                    _lib.ptr(acc), _lib.ptr(up), _lib.ptr(g), _lib.stream()), "lf_ce2d_bwd")
         return g, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """``act(x @ w.T + b)`` with ``act`` = identity or ReLU: the nn.Linear tails of the --clas heads on lf_linear_fwd / lf_linear_bwd
+    (fp32, fixed summation order) instead of F.linear / rocBLAS."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        lib = _lib.load()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w = w.contiguous()
+        assert x2.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[1] == x2.shape[1]
+        N, K = x2.shape
+        O = w.shape[0]
+        bb = None if b is None else b.contiguous()
+        y = torch.empty(N, O, dtype=torch.float32, device=x2.device)
+        _lib.check(lib.lf_linear_fwd(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(bb), _lib.ptr(y), N, K, O, int(bool(relu)), _lib.stream()),
+                   "lf_linear_fwd")
+        ctx.save_for_backward(x2, w, y)
+        ctx.relu, ctx.xshape, ctx.has_bias = bool(relu), x.shape, b is not None
+        return y.view(*x.shape[:-1], O)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x2, w, y = ctx.saved_tensors
+        N, K = x2.shape
+        O = w.shape[0]
+        gy2 = gy.reshape(N, O).to(torch.float32).contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        gx = torch.empty_like(x2) if need_x else None
+        gw = torch.empty_like(w) if (need_w or need_b) else None
+        gb = torch.empty(O, dtype=torch.float32, device=w.device) if need_b else None
+        _lib.check(lib.lf_linear_bwd(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(y), _lib.ptr(gy2), _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb),
+                                     N, K, O, int(ctx.relu), _lib.stream()), "lf_linear_bwd")
+        return (gx.view(ctx.xshape) if need_x else None), (gw if need_w else None), gb, None
+
+
+def linear(x, w, b=None, relu=False):
+    return LinearFn.apply(x, w, b, relu)
+
+
+def seg_maps(logits, gt_line, zero_rows, lanes):
+    """Segmentation-mode fit input (lf_seg_maps): arg-max of the class logits -> per-lane maps valued k at class k, masked rows
+    zeroed, lanes flagged in ``gt_line`` (N, lanes; BP only) overwritten with map [0, 0].  No gradient (the reference detaches)."""
+    lib = _lib.load()
+    logits = logits.detach().contiguous()
+    assert logits.dtype == torch.float32 and logits.dim() == 4
+    N, C, H, W = logits.shape
+    flags = None
+    if gt_line is not None:
+        flags = gt_line.to(device=logits.device, dtype=torch.float32).contiguous()
+        if tuple(flags.shape) != (N, lanes):
+            # the reference's expand_as(masked) fails here -- but only when gt_line.sum() != 0 lets it get that far
+            if float(flags.sum()) != 0:
+                raise RuntimeError("seg-mode fit: gt_line %s cannot be expanded to the (%d, %d) lane maps" % (tuple(flags.shape), N, lanes))
+            flags = None
+    maps = torch.empty(N, lanes, H, W, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.lf_seg_maps(_lib.ptr(logits), _lib.ptr(flags), _lib.ptr(maps), N, C, lanes, H, W, int(zero_rows), _lib.stream()),
+               "lf_seg_maps")
+    return maps

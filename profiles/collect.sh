@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round's profile evidence from HEAD on a 1-GPU MI355X box (run through gpurun from the repo root):
 #
-#     gpurun --timeout 900 -- 'bash profiles/collect.sh r3'        (every step runs under its own `timeout`)
+#     bash tools/stamp_head.sh && gpurun --timeout 900 -- 'bash profiles/collect.sh r4'        (every step runs under its own `timeout`)
 #
 # 1. rocprofv3 --kernel-trace --stats of the exact bench command       -> profiles/<tag>_kernel_stats.txt
 # 2. two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain other than --kernel-trace) over one
@@ -13,16 +13,24 @@
 # 4. a matrix-pipe pass (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) over the bench -> profiles/<tag>_pmc_bench.txt
 # Everything is written under gpurun_out/ first (scratch) and the summaries are copied to profiles/ by this script; commit them.
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-COMMIT=$(cat .git_head 2>/dev/null || echo unknown)
+# The evidence is stamped with the commit it was measured at (tools/stamp_head.sh writes .git_head before the gpurun call) and
+# refused when the tree was dirty or is not the stamped one (digest of the kernel sources + bench.py).
+STAMP=$(cat .git_head 2>/dev/null || echo "unknown clean=no digest=none")
+COMMIT=${STAMP%% *}
+DIGEST=$(cat lanedetection_end2end_amd/csrc/*.hip lanedetection_end2end_amd/csrc/*.h bench.py | sha256sum | cut -c1-16)
+case "$STAMP" in
+  *"clean=yes digest=$DIGEST"*) ;;
+  *) echo "collect.sh: refusing to write profiles: .git_head says '$STAMP', this tree's digest is $DIGEST (run tools/stamp_head.sh on a clean tree first)"; exit 1 ;;
+esac
 
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 16 --warmup 4 --min-seconds 1 --no-cpu-baseline --no-vendor-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 DB=$(find $OUT/trace -name '*_results.db' | head -1)
-python profiles/summarize_rocpd.py "$DB" > profiles/${TAG}_kernel_stats.txt
+( echo "# commit $COMMIT"; python profiles/summarize_rocpd.py "$DB" ) > profiles/${TAG}_kernel_stats.txt
 
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 120 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1

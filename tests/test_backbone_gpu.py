@@ -755,9 +755,12 @@ def test_fp32_kernel_parity_every_addressing_path():
 
 def test_split_mode_kernel_parity():
     """Precision modes "fp32x9" / "fp32x6": fp32 tensors, fp32 accumulation, every product formed on the bf16 matrix
-    cores from exact 3-way splits of both operands (9 = all partial products, 6 = those above 2^-24).  Contract: as close
-    to the exact (fp64) convolution as the fp32 matrix cores are -- checked per kernel against the SAME launch in mode 0,
-    on inputs with a wide dynamic range, with the ReLU / mask epilogues."""
+    cores from exact 3-way splits of both operands (9 = all partial products, 6 = those above 2^-24).  Contract: fp32-level
+    distance from the exact (fp64) convolution -- checked per kernel beside the SAME launch in mode 0, on inputs with a wide
+    dynamic range, with the ReLU / mask epilogues.  Round 4: the fp32 cores now sum 32-product segments into a second
+    accumulator set and sit at ~1.7e-7 (round 3: 2.3-5.9e-7); the split kernels keep one chain of exact 32-product MFMA steps
+    (their 512-thread workgroups have no registers for a second set) at 3-5e-7: held to 6e-7 absolute -- the fp32 cores' own
+    round-3 level -- and 3.5x the fp32 cores' launch, instead of round 3's 1.25x."""
     import torch.nn.functional as F
     from lanedetection_end2end_amd import _lib
     lib = _lib.load()
@@ -789,8 +792,8 @@ def test_split_mode_kernel_parity():
             print("split C=%d axis %d dil %d: fwd/dgrad error vs fp64  fp32 cores %.1e %.1e | x9 %.1e %.1e | x6 %.1e %.1e"
                   % (C, axis, d, err[0][0], err[0][1], err[9][0], err[9][1], err[6][0], err[6][1]))
             for mode in (9, 6):
-                assert err[mode][0] < 1.25 * err[0][0] + 1e-7 and err[mode][1] < 1.25 * err[0][1] + 1e-7
-                assert err[mode][0] < 2e-6 and err[mode][1] < 2e-6
+                assert err[mode][0] < 3.5 * err[0][0] + 1e-7 and err[mode][1] < 3.5 * err[0][1] + 1e-7
+                assert err[mode][0] < 6e-7 and err[mode][1] < 6e-7
             assert not torch.equal(err[9][2], err[0][2])          # the split kernel really ran (different rounding order)
     finally:
         lib.lf_debug_set_ops_precision(0)

@@ -393,7 +393,10 @@ def _check_bn_statistics_at_full_batch(net, x, precision):
         for k, v in zip(("mean", "rstd", "rmean", "rvar"), (e_mean, e_rstd, e_rm, e_rv)):
             worst[k] = max(worst[k], v)
         # fp32 partial sums of y and y^2 per 256-pixel tile, combined in fp64: var = E[y^2] - mean^2 keeps ~1e-7 * (1 + mean^2 / var)
-        assert e_rstd < 1e-5 and e_mean < 1e-5 and e_rm < 1e-5 and e_rv < 2e-5, (prefix, e_mean, e_rstd, e_rm, e_rv)
+        # (mode "bf16": the stem and the pooled channels take their statistics from the fp32 values BEFORE the bf16 store, the
+        # tap-GEMM epilogues from the values as stored: the stored tensor's own statistics differ by its rounding noise, 2^-9)
+        tol = 1e-5 if precision == "fp32" else 3e-4
+        assert e_rstd < tol and e_mean < tol and e_rm < tol and e_rv < 2 * tol, (prefix, e_mean, e_rstd, e_rm, e_rv)
     print("BatchNorm statistics at batch %d (%s), %d BatchNorms, worst relative error: batch mean %.1e, rstd %.1e, running mean "
           "%.1e, running var %.1e" % (N, precision, len(_bn_sites()), worst["mean"], worst["rstd"], worst["rmean"], worst["rvar"]))
     assert torch.isfinite(dec).all()
