@@ -175,6 +175,53 @@ def test_backbone_vs_golden_and_grads(golden_backbone, out_channels, precision):
     assert worst < 2e-5         # measured 3.5e-6 (fp32 matrix cores), the split modes are held to the same bound
 
 
+def test_bn_backward_large_channel_offset():
+    """the BatchNorm-backward second sum is accumulated RAW (sum g * t in fp32 per 256-pixel partial) and centred
+    afterwards in fp64 (rstd * sum(g t) - mean * rstd * sum(g)); for a channel whose |mean| is much larger than its std that
+    cancels digits the fp32 partials have already lost.  Here the convolutions in front of four BatchNorms get a bias of ~50
+    standard deviations of their output (train-mode BatchNorm removes it again, so the forward state is unchanged up to
+    rounding) and every parameter gradient is checked against the straight-through fp64 oracle: the expected loss is
+    |mean| / std * 2^-24 ~ 3e-6 of a sum's terms -- measured, printed, held to 1e-4."""
+    N, H, W = 2, 64, 128
+    net, P = build()
+    x = torch.from_numpy(inputs.images(N, H, W, seed=51))
+    _, _, taps, _, _ = run_oracle(x, P, torch.float64)
+    P2 = dict(P)
+    for conv, tap in (("encoder.layers.3.conv1x3_1", "encoder.layers.3#1"), ("encoder.layers.3.conv1x3_2", "encoder.layers.3#3"),
+                      ("encoder.layers.9.conv1x3_2", "encoder.layers.9#3"), ("decoder.layers.1.conv1x3_1", "decoder.layers.1#1")):
+        std = taps[tap].detach().std(dim=(0, 2, 3)).float()
+        P2[conv + ".bias"] = P[conv + ".bias"] + 50.0 * std
+    net.load_state_dict(P2)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0
+    net.train()
+    gy = torch.from_numpy(np.random.default_rng(52).standard_normal((N, 2, H, W))).float()
+    enc, dec = net(x.cuda(), True)
+    state = fetch_all(net, net._plan(N, H, W), dec.grad_fn.ws, N, H, W)
+    (dec * gy.cuda()).sum().backward()
+    Pd = erfnet_oracle.cast_params(P2, torch.float64)
+    for k, v in Pd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    _, dec_st = erfnet_oracle.erfnet_forward(x.double(), Pd, training=True, override=state)
+    (dec_st * gy.double()).sum().backward()
+    gmax = max(float(v.grad.abs().max()) for k, v in Pd.items() if v.grad is not None)
+    worst, worst_k = 0.0, None
+    for k, p in net.named_parameters():
+        if k.startswith("encoder.output_conv"):
+            continue
+        g64 = Pd[k].grad
+        scale = float(g64.abs().max())
+        if scale < 1e-6 * gmax:
+            continue
+        e = float((p.grad.cpu().double() - g64).abs().max()) / scale
+        if e > worst:
+            worst, worst_k = e, k
+    print("BatchNorm backward with 50-sigma channel offsets: worst parameter-gradient error %.2e (%s)" % (worst, worst_k))
+    assert worst < 1e-4
+
+
 def test_eval_mode_and_no_grad(golden_backbone):
     N, H, W = 2, 64, 128
     net, P = build()

@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as TF
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from oracle import erfnet_oracle, inputs  # noqa: E402
+from oracle import erfnet_oracle, fit_oracle, inputs  # noqa: E402
 
 RULE = None
 SEG = 0
@@ -157,7 +157,12 @@ def main():
     erfnet_oracle._bn = bn_emul
     erfnet_oracle.F = FShim
     rms = lambda u, v: float(np.sqrt(np.mean((u - v) ** 2)))
-    variants = ["plain", "stats"] + (["chain", "chain2", "seg32", "seg64", "seg96"] if a.chain else [])
+    Mh, _ = fit_oracle.bev_homography()
+    grid = fit_oracle.projective_grid(a.r, 2 * a.r, Mh.astype(np.float32), True, np.float32)
+    zr = fit_oracle.zero_rows_of(a.r, 0.3)
+    beta_of = lambda lg: fit_oracle.wls_forward(lg.astype(np.float32), grid, zr, 2, 0.0, 1.0, "square")["beta"]
+    brows = {}
+    variants = ["plain", "fold", "stats", "fold+stats"] + (["chain", "seg32", "seg32+fold", "seg32+stats", "seg32+fold+stats"] if a.chain else [])
     rows = {v: [] for v in variants}
     for seed in range(a.seeds):
         P = erfnet_oracle.make_params(seed=40 + seed, out_channels=2)
@@ -169,16 +174,20 @@ def main():
         for v in variants:
             global RULE, SEG
             RULE = RULES.get(v)
-            SEG = int(v[3:]) if v.startswith("seg") else 0
+            SEG = int(v.split("+")[0][3:]) if v.startswith("seg") else 0
             for k in MODE:
                 MODE[k] = k in v.split("+")
-            d = rms(run(x, P, torch.float32), r64)
+            lg = run(x, P, torch.float32)
+            d = rms(lg, r64)
+            bd = np.abs(beta_of(lg) - beta_of(r64)).max()
             if v == "plain":
-                base = d
+                base, bbase = d, bd
             rows[v].append(d / base)
+            brows.setdefault(v, []).append(bd / bbase)
         print("seed %d  plain rms %.3e  " % (seed, base) + "  ".join("%s %.2f" % (v, rows[v][-1]) for v in variants[1:]), flush=True)
     for v in variants:
-        print("%-18s ratio to the plain fp32 leg: median %.2f  (min %.2f max %.2f)" % (v, np.median(rows[v]), min(rows[v]), max(rows[v])))
+        print("%-18s ratio to the plain fp32 leg: logits rms median %.2f  (min %.2f max %.2f)   lane coefficients (max norm) median %.2f (min %.2f max %.2f)"
+              % (v, np.median(rows[v]), min(rows[v]), max(rows[v]), np.median(brows[v]), min(brows[v]), max(brows[v])))
 
 
 if __name__ == "__main__":

@@ -50,7 +50,7 @@ def main():
                      use_cholesky=False, mask_percentage=0.3, clas=False, no_mapping=False, loss_policy="area", weight_seg=30,
                      weight_funct="none")
     model = None
-    ratios = {"beta": [], "logits": [], "dlogits": []}
+    ratios = {"beta": [], "beta_rms": [], "logits": [], "dlogits": []}
     rms = lambda u, v: float(np.sqrt(np.mean((np.asarray(u, dtype=np.float64) - v) ** 2)))
     for seed in range(a.seeds):
         P, x, gt = case(seed)
@@ -74,6 +74,7 @@ def main():
         (crit(b0, gtc[:, 0]) + crit(b1, gtc[:, 1])).backward()
         beta = torch.stack([b0, b1], 1)[..., 0].detach().cpu().numpy()
         ratios["beta"].append(np.abs(beta - o["b64"]).max() / max(np.abs(o["b32"] - o["b64"]).max(), 1e-30))
+        ratios["beta_rms"].append(rms(beta, o["b64"]) / max(rms(o["b32"], o["b64"]), 1e-30))
         ratios["logits"].append(rms(output.detach().cpu().numpy(), o["l64"]) / rms(o["l32"], o["l64"]))
         ratios["dlogits"].append(rms(output.grad.cpu().numpy(), o["d64"]) / rms(o["d32"], o["d64"]))
     for k, v in ratios.items():
