@@ -183,6 +183,27 @@ int lf_erfnet_backward(const lf_erfnet_plan* plan, const float* img, const float
                        const float* grad_encoder, const float* const* params_host, float* const* grads_host,
                        const float* dropmask, int training, int head, void* workspace, size_t workspace_bytes, void* stream);
 int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+
+/* Block-level surface (round 4): a contiguous range [first, last) of the plan's layers (module order: 0 =
+ * encoder.initial_block, 1..15 = encoder.layers[0..14], 16..21 = decoder.layers[0..5]) as one call, inside the plan of the
+ * whole network at the matching input size -- what makes the reference's sub-modules callable on their own:
+ *   DownsamplerBlock.forward(input)            BEV/Networks/ERFNet.py:19-22
+ *   non_bottleneck_1d.forward(input)           :44-60
+ *   UpsamplerBlock.forward(input)              :104-107
+ *   Encoder.forward(input, predict=False)      :86-95   (range 0..16; predict = lf_pointwise_fwd on top)
+ *   Decoder.forward(input, flag)               :129-142 (range 16..22 with head = 0 / 1)
+ * x / y / gy / gx are NCHW fp32 like the reference's tensors; head >= 0 (only with last = the layer count) appends
+ * output_conv (0) / output_conv2 (1) and makes y the logits.  Only the range's parameters are read / receive gradients
+ * (grads_host entries outside it are left untouched); BatchNorm running statistics of the range are updated in train mode.
+ * lf_erfnet_backward_range must follow lf_erfnet_forward_range on the same workspace.  fp32-tensor precision modes only. */
+int lf_erfnet_num_layers(const lf_erfnet_plan* plan);
+int lf_erfnet_layer_io(const lf_erfnet_plan* plan, int layer, int* out6_host);   /* Cin, Hin, Win, Cout, Hout, Wout */
+int lf_erfnet_forward_range(const lf_erfnet_plan* plan, int first, int last, int head, const float* x,
+                            const float* const* params_host, const float* const* params_dev, float* const* running_host,
+                            const float* dropmask, int training, float* y, void* workspace, size_t workspace_bytes, void* stream);
+int lf_erfnet_backward_range(const lf_erfnet_plan* plan, int first, int last, int head, const float* x, const float* gy,
+                             const float* const* params_host, float* const* grads_host, const float* dropmask, int training,
+                             float* gx, void* workspace, size_t workspace_bytes, void* stream);
 /* encoder.output_conv = nn.Conv2d(128, num_classes, 1): the `predict=True` branch of Encoder.forward that
  * Net.forward(input, flag, only_encode=True) returns (BEV/Networks/ERFNet.py:84,86-95,151-153).
  * x (N,h,w,C) NHWC fp32 (the encoder output, read in place), w (K,C) = the weight (K,C,1,1), b (K) or NULL -> y (N,K,h,w) NCHW.

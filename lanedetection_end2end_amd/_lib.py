@@ -78,6 +78,10 @@ def _declare(lib):
         "lf_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_weight": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+        "lf_erfnet_num_layers": (I, [P]),
+        "lf_erfnet_layer_io": (I, [P, I, P]),
+        "lf_erfnet_forward_range": (I, [P, I, I, I, P, P, P, P, P, I, P, P, c_size_t, P]),
+        "lf_erfnet_backward_range": (I, [P, I, I, I, P, P, P, P, P, I, P, P, c_size_t, P]),
         "lf_linear_fwd": (I, [P, P, P, P, I, I, I, I, P]),
         "lf_linear_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
         "lf_seg_maps": (I, [P, P, P, I, I, I, I, I, I, P]),

@@ -440,6 +440,25 @@ __global__ __launch_bounds__(256, (EPIC >= 0 || NT < 4) ? 2 : 1) void tapgemm_ke
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] += accl[n][m];
+    if constexpr (!ROW1) {
+        // per-lane pixel coordinates are RECOMPUTED for the epilogue (from a laundered thread index, so that the compiler cannot
+        // keep the prologue's copies): 16 registers that would otherwise live across the main loop, where two accumulator sets
+        // and two operand sets leave no room for them (24-32 registers spilled around the loop in the BatchNorm-backward-sum
+        // variants).  The ROW1 form holds them in scalar registers.
+        unsigned tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const unsigned tile0b = (bx * WG_WAVES + (tid2 >> 6)) * (MT * 16);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const unsigned p = tile0b + m * 16 + (tid2 & 15u);
+            pv[m] = p < npix;
+            const unsigned q = pv[m] ? p : 0u;
+            const unsigned r = q / (unsigned)g.Wl;
+            pj[m] = (int)(q - r * (unsigned)g.Wl);
+            pn[m] = (int)(r / (unsigned)g.Hl);
+            pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
+        }
+    }
     if constexpr (DBG) {   // make the stamp wait for the last MFMA: touch one accumulator
         asm volatile("" ::"v"(acc[0][0][0]));
         tstamp[2] = __builtin_amdgcn_s_memrealtime();

@@ -429,7 +429,8 @@ int encoder_layers(const lf_erfnet_plan* P) {     // layers [0, n) = the encoder
     return n;
 }
 
-int forward_layers(const Ctx& c, const float* img, int nlayers) {
+// layers [first, last) of the plan; with first > 0 the caller has put the range's input at P->layers[first].x
+int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
     const lf_erfnet_plan* P = c.P;
     const int N = P->N;
     float* stat0 = c.at(P->off_stat0);
@@ -437,6 +438,7 @@ int forward_layers(const Ctx& c, const float* img, int nlayers) {
     int layer_idx = 0;
     for (const Layer& L : P->layers) {
         if (layer_idx >= nlayers) break;
+        if (layer_idx < first) { ++layer_idx; continue; }
         P->prof_layer = layer_idx++;
         const long npo = (long)N * L.Hout * L.Wout;
         if (L.kind == K_DOWN) {
@@ -569,7 +571,9 @@ Prep prep_for(const Ctx& c, const Layer& Lp) {
     return p;
 }
 
-int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float* g2, int nlayers) {
+// layers [first, nlayers) in reverse; *gin (optional) receives the buffer holding d loss / d (input of layer `first`), NHWC
+int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float* g2, int nlayers, int first = 0,
+                    float** gin = nullptr) {
     // on entry g0 holds d loss / d (output of the last block), NHWC.  The three buffers rotate roles:
     // `in` = incoming gradient, X / Y = scratch; every layer leaves its result in one of them.
     const lf_erfnet_plan* P = c.P;
@@ -579,7 +583,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
     float* in = g0;
     bool prepped = false;        // `in` already masked by the layer's output ReLU, BN sums in stat0
     int prep_rows = 0;
-    for (int li = nlayers - 1; li >= 0; --li) {
+    for (int li = nlayers - 1; li >= first; --li) {
         const Layer& L = P->layers[li];
         P->prof_layer = 100 + li;
         const long npo = (long)N * L.Hout * L.Wout;
@@ -589,7 +593,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         float* Y = bufs[(iin + 2) % 3];
         // gradient preparation the final dgrad of THIS layer performs for the previous one
         Prep nx;
-        const bool can_prep = li > 0 && (L.kind == K_NB || L.kind == K_UP);
+        const bool can_prep = li > first && (L.kind == K_NB || L.kind == K_UP);
         if (can_prep) nx = prep_for(c, P->layers[li - 1]);
         auto add_prep = [&](LfTapArgs& a, int& epi) {
             if (!can_prep) return;
@@ -690,6 +694,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         }
         in = out;
     }
+    if (gin) *gin = in;
     return 0;
 }
 
@@ -832,3 +837,107 @@ extern "C" int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W
     LF_CHECK_LAUNCH("nhwc_to_nchw");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// Block-level surface (round 4): a contiguous RANGE of the plan's layers as one call, so that the reference's sub-modules are
+// callable on their own -- DownsamplerBlock / non_bottleneck_1d / UpsamplerBlock.forward(input), Encoder.forward(input,
+// predict), Decoder.forward(input, flag) (BEV/Networks/ERFNet.py:19-22,44-60,86-95,104-107,129-142).  The range runs inside
+// the plan of the whole network at the matching input size: same kernels, same workspace slots, same BatchNorm /
+// Dropout2d handling as the full pass; only the range's parameters are read and only their gradients written.
+// Tensors cross this boundary in the reference's NCHW fp32.  Precision modes with fp32 tensors only.
+// ---------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ s, float* __restrict__ d, int H, int W, int C,
+                                                          long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % C);
+        long r = i / C;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H);
+        const long n = r / H;
+        d[i] = s[((n * C + ch) * H + h) * W + w];
+    }
+}
+int nchw_to_nhwc(const float* src, float* dst, int N, int H, int W, int C, hipStream_t st) {
+    const long total = (long)N * H * W * C;
+    int grid = lf_cdiv(total, 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid), dim3(256), 0, st, src, dst, H, W, C, total);
+    LF_CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+long layer_out_offset(const Layer& L) { return L.kind == K_NB ? L.b[4] : L.b[1]; }
+int check_range(const lf_erfnet_plan* P, int first, int last, int head, const char* who) {
+    LF_REQUIRE(P && first >= 0 && last > first && last <= (int)P->layers.size(), "%s: bad layer range [%d, %d)", who, first, last);
+    LF_REQUIRE(head < 0 || (last == (int)P->layers.size() && head < P->n_heads), "%s: the head follows the last layer only", who);
+    LF_REQUIRE(P->precision != 2, "%s: block-level calls take fp32 tensors (precision mode bf16 stores bf16)", who);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int lf_erfnet_num_layers(const lf_erfnet_plan* P) { return (int)P->layers.size(); }
+// out6 = {Cin, Hin, Win, Cout, Hout, Wout} of a layer (module order: 0 = encoder.initial_block, 1.. = encoder.layers, then decoder.layers)
+int lf_erfnet_layer_io(const lf_erfnet_plan* P, int layer, int* out6) {
+    LF_REQUIRE(P && out6 && layer >= 0 && layer < (int)P->layers.size(), "lf_erfnet_layer_io: layer %d out of range", layer);
+    const Layer& L = P->layers[layer];
+    out6[0] = L.Cin; out6[1] = L.Hin; out6[2] = L.Win; out6[3] = L.Cout; out6[4] = L.Hout; out6[5] = L.Wout;
+    return 0;
+}
+
+// x: (N, Cin, Hin, Win) NCHW input of layer `first` (the image when first = 0); y: (N, Cout, Hout, Wout) NCHW output of layer
+// last - 1, or, with head >= 0 (last = the layer count), the logits (N, out_channels + head, H, W).
+int lf_erfnet_forward_range(const lf_erfnet_plan* P, int first, int last, int head, const float* x,
+                            const float* const* params_host, const float* const* params_dev, float* const* running_host,
+                            const float* dropmask, int training, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+    LF_TRY(check_range(P, first, last, head, "lf_erfnet_forward_range"));
+    LF_REQUIRE(x && y && params_host && params_dev && running_host && workspace, "lf_erfnet_forward_range: null pointer");
+    LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_forward_range: workspace too small");
+    Ctx c{P, (float*)workspace, params_host, nullptr, running_host, dropmask, training, (hipStream_t)stream};
+    LF_TRY(upload_and_pack(c, params_dev));
+    const Layer& Lf = P->layers[first];
+    if (first > 0) LF_TRY(nchw_to_nhwc(x, c.at(Lf.x), P->N, Lf.Hin, Lf.Win, Lf.Cin, c.st));
+    LF_TRY(forward_layers(c, x, last, first));
+    const Layer& Ll = P->layers[last - 1];
+    if (head >= 0)
+        return lf_head_fwd(c.at(P->head_in), params_host[P->p_head_w[head]], params_host[P->p_head_b[head]], y, P->N, P->H / 2,
+                           P->W / 2, P->Cout + head, 0, c.st);
+    return lf_nhwc_to_nchw(c.at(layer_out_offset(Ll)), y, P->N, Ll.Hout, Ll.Wout, Ll.Cout, stream);
+}
+
+// Backward of lf_erfnet_forward_range on the same workspace: gy = d loss / d y (NCHW, the forward's output shape); gx (NCHW,
+// the forward's input shape) or NULL (always NULL-able; ignored when first = 0: the image takes no gradient).
+// grads_host: n_params device pointers; only the range's (and the head's) entries are written, NULL entries skipped.
+int lf_erfnet_backward_range(const lf_erfnet_plan* P, int first, int last, int head, const float* x, const float* gy,
+                             const float* const* params_host, float* const* grads_host, const float* dropmask, int training,
+                             float* gx, void* workspace, size_t workspace_bytes, void* stream) {
+    LF_TRY(check_range(P, first, last, head, "lf_erfnet_backward_range"));
+    LF_REQUIRE(x && gy && params_host && grads_host && workspace, "lf_erfnet_backward_range: null pointer");
+    LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_backward_range: workspace too small");
+    Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, training, (hipStream_t)stream};
+    float *gA = c.at(P->off_gA), *gB = c.at(P->off_gB), *gC = c.at(P->off_gC);
+    const Layer& Ll = P->layers[last - 1];
+    if (head >= 0) {
+        const int h = P->H / 2, w = P->W / 2, K = P->Cout + head;
+        const int pw = P->p_head_w[head], pb = P->p_head_b[head];
+        if (grads_host[pw]) {
+            const int rows = lf_head_wgrad_rows(P->N, h, w);
+            LF_TRY(lf_head_wgrad(c.at(P->head_in), gy, c.at(P->off_wpart), c.at(P->off_bpart), P->N, h, w, K, 0, c.st));
+            LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, 16 * K * 4, grads_host[pw], 0, c.st));
+            if (grads_host[pb]) LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, K, grads_host[pb], 0, c.st));
+        }
+        LF_TRY(lf_head_bwd_data(gy, params_host[pw], gA, P->N, h, w, K, 0, c.st));
+    } else {
+        LF_TRY(nchw_to_nhwc(gy, gA, P->N, Ll.Hout, Ll.Wout, Ll.Cout, c.st));
+    }
+    float* gin = nullptr;
+    LF_TRY(backward_layers(c, x, gA, gB, gC, last, first, &gin));
+    if (!c.reduce_jobs.empty()) LF_TRY(lf_wgrad_reduce_batch_launch(c.reduce_jobs.data(), (int)c.reduce_jobs.size(), c.st));
+    const Layer& Lf = P->layers[first];
+    if (gx && first > 0) LF_TRY(lf_nhwc_to_nchw(gin, gx, P->N, Lf.Hin, Lf.Win, Lf.Cin, stream));
+    return 0;
+}
+
+}  // extern "C"

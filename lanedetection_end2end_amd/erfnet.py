@@ -18,11 +18,35 @@ from . import _lib
 _BN_EPS = 1e-3
 
 
-class _Holder(nn.Module):
-    """Parameter container; compute happens in the engine."""
+# cumulative down-sampling in front of every layer of the plan (module order: encoder.initial_block, encoder.layers[0..14],
+# decoder.layers[0..5]): input size of layer i = (H / s_i, W / s_i) of the network input
+_LAYER_IN_STRIDE = [1, 2] + [4] * 5 + [4] + [8] * 8 + [8, 4, 4, 4, 2, 2]
 
-    def forward(self, *a, **k):
-        raise RuntimeError("lanefit ERFNet blocks hold parameters only; call the top-level Net")
+
+class _Holder(nn.Module):
+    """A sub-module of the backbone.  It holds its parameters with the reference's names; ``forward`` runs the module's layer
+    range of the engine plan (``lf_erfnet_forward_range``) at the input's size -- the same kernels as the whole-network pass --
+    so ``model.net.encoder(x)``, ``model.net.decoder.layers[1](y)`` ... work like the reference's modules
+    (BEV/Networks/ERFNet.py:19-22,44-60,86-95,104-107,129-142).  Bound to its ``Net`` by ``Net._bind_blocks``."""
+    _lf_range = None
+
+    def _owner(self):
+        ref = self.__dict__.get("_lf_owner")
+        net = ref() if ref is not None else None
+        if net is None or self._lf_range is None:
+            raise RuntimeError("lanefit ERFNet block is not part of a Net (blocks run inside their network's engine plan)")
+        return net
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_lf_owner", None)            # weak reference: re-bound by Net.__setstate__
+        return st
+
+    def _run_range(self, x, head=-1):
+        return self._owner()._forward_range(x, self._lf_range[0], self._lf_range[1], head)
+
+    def forward(self, input):
+        return self._run_range(input)
 
 
 class DownsamplerBlock(_Holder):
@@ -71,6 +95,13 @@ class Encoder(_Holder):
         # only used by the reference's only_encode=True path; never trained (ERFNet.py:84,92-93)
         self.output_conv = nn.Conv2d(128, num_classes, 1, stride=1, padding=0, bias=True)
 
+    def forward(self, input, predict=False):
+        """ERFNet.py:86-95: initial_block, the 15 layers, and with ``predict`` the 1x1 ``output_conv``."""
+        output = self._run_range(input)
+        if predict:
+            output = _PointwiseFn.apply(output.permute(0, 2, 3, 1).contiguous(), self.output_conv.weight, self.output_conv.bias)
+        return output
+
 
 class Decoder(_Holder):
     def __init__(self, num_classes, pretrain):
@@ -83,6 +114,15 @@ class Decoder(_Holder):
         if pretrain:
             self.output_conv2 = nn.ConvTranspose2d(16, num_classes + 1, 2, stride=2, padding=0, output_padding=0,
                                                    bias=True)
+
+    def forward(self, input, flag):
+        """ERFNet.py:129-142: the six layers + ``output_conv`` (``output_conv2`` when pretrain and not flag).  The BP tree's
+        decoder returns ``(output, output_seg)`` with ``output_seg`` = its input (BP/Networks/ERFNet.py:143-163)."""
+        head = 1 if (self.pretrain and not flag) else 0
+        output = self._run_range(input, head)
+        if self._owner().three_outputs:
+            return output, input
+        return output
 
 
 class _Plan:
@@ -261,6 +301,52 @@ class _PointwiseFn(torch.autograd.Function):
         return gx, (None if gw is None else gw.view(ctx.wshape)), gb
 
 
+class _RangeFn(torch.autograd.Function):
+    """Layers [first, last) of the plan (+ optional head) on an NCHW tensor: lf_erfnet_forward_range / _backward_range."""
+
+    @staticmethod
+    def forward(ctx, net, plan, x, first, last, head, training, dropmask, *params):
+        lib = _lib.load()
+        N, H, W = plan.shape
+        io = (ctypes.c_int * 6)()
+        _lib.check(lib.lf_erfnet_layer_io(plan.handle, last - 1, io), "lf_erfnet_layer_io")
+        oshape = (N, net.out_channels + head, H, W) if head >= 0 else (N, io[3], io[4], io[5])
+        ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=x.device)
+        y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        params = [p.detach() for p in params]
+        host = net._ptrs.get("params", params)
+        devarr = net._device_ptr_table(params)
+        ctx.precision = _PRECISIONS[net.precision]
+        _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
+        running = net._ptrs.get("running", net._running_buffers())
+        _lib.check(lib.lf_erfnet_forward_range(plan.handle, first, last, head, _lib.ptr(x), host, _lib.ptr(devarr), running,
+                                               _lib.ptr(dropmask), int(training), _lib.ptr(y), _lib.ptr(ws), plan.ws_bytes,
+                                               _lib.stream()), "lf_erfnet_forward_range")
+        ctx.set_materialize_grads(False)
+        ctx.net, ctx.plan, ctx.cfg, ctx.ws, ctx.x, ctx.dropmask, ctx.params = net, plan, (first, last, head), ws, x, dropmask, params
+        ctx.training = int(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        first, last, head = ctx.cfg
+        if gy is None:
+            return (None,) * (8 + len(ctx.params))
+        gy = gy.contiguous().float()
+        used = ctx.net._range_param_mask(first, last, head)
+        needs = ctx.needs_input_grad[8:]
+        grads = [torch.empty_like(p) if (n and u) else None for p, n, u in zip(ctx.params, needs, used)]
+        gx = torch.empty_like(ctx.x) if (ctx.needs_input_grad[2] and first > 0) else None
+        _lib.check(lib.lf_erfnet_set_precision(ctx.plan.handle, ctx.precision), "lf_erfnet_set_precision")
+        _lib.check(lib.lf_erfnet_backward_range(ctx.plan.handle, first, last, head, _lib.ptr(ctx.x), _lib.ptr(gy),
+                                                _ptr_array(ctx.params), _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.training,
+                                                _lib.ptr(gx), _lib.ptr(ctx.ws), ctx.plan.ws_bytes, _lib.stream()),
+                   "lf_erfnet_backward_range")
+        ctx.ws = None
+        return (None, None, gx, None, None, None, None, None) + tuple(grads)
+
+
 class Net(nn.Module):
     """``Net(layers=18, in_channels=1, out_channels=1, pretrained=False, pool=False)`` and
     ``forward(input, flag, only_encode=False) -> (encoder_output, decoder_output)``
@@ -297,6 +383,57 @@ class Net(nn.Module):
         # encoder_output (N,128,H/8,W/8) is part of the return tuple (zero-copy view); wrappers that never read it
         # may switch it off
         self.export_encoder_output = True
+        self._bind_blocks()
+
+    def _blocks(self):
+        """The plan's layers in module order -> the modules that own them."""
+        return [self.encoder.initial_block] + list(self.encoder.layers) + list(self.decoder.layers)
+
+    def _bind_blocks(self):
+        import weakref
+        ref = weakref.ref(self)
+        blocks = self._blocks()
+        for i, b in enumerate(blocks):
+            b.__dict__["_lf_owner"], b._lf_range = ref, (i, i + 1)
+        ne = 1 + len(self.encoder.layers)
+        self.encoder.__dict__["_lf_owner"], self.encoder._lf_range = ref, (0, ne)
+        self.decoder.__dict__["_lf_owner"], self.decoder._lf_range = ref, (ne, len(blocks))
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._bind_blocks()
+
+    def _range_param_mask(self, first, last, head):
+        """Which parameters (module order) a layer range reads: its blocks', plus the chosen head's."""
+        own = set()
+        for b in self._blocks()[first:last]:
+            own.update(id(p) for p in b.parameters())
+        if head >= 0:
+            conv = self.decoder.output_conv2 if head == 1 else self.decoder.output_conv
+            own.update(id(p) for p in conv.parameters())
+        return [id(p) in own for p in self._ordered_params()]
+
+    def _forward_range(self, x, first, last, head=-1):
+        """Run layers [first, last) (+ head) on an NCHW tensor inside the plan of the whole network at the matching size."""
+        if not x.is_cuda:
+            raise _lib.LaneFitLibraryError("lanefit ERFNet needs its input on the MI355X; there is no CPU path")
+        if self.precision == "bf16":
+            raise NotImplementedError("block-level calls take fp32 tensors: use precision 'fp32', 'bf16_mfma', 'fp32x9' or 'fp32x6'")
+        x = x.contiguous().float()
+        N, C, h, w = x.shape
+        s = _LAYER_IN_STRIDE[first]
+        plan = self._plan(N, h * s, w * s)
+        io = (ctypes.c_int * 6)()
+        _lib.check(_lib.load().lf_erfnet_layer_io(plan.handle, first, io), "lf_erfnet_layer_io")
+        if (C, h, w) != (io[0], io[1], io[2]):
+            raise RuntimeError("ERFNet block expects an input of (N, %d, H, W), got %s" % (io[0], tuple(x.shape)))
+        training = self._blocks()[first].training
+        dropmask = self._make_dropmask(plan, x.device) if training else None
+        y = _RangeFn.apply(self, plan, x, first, last, head, training, dropmask, *self._ordered_params())
+        if training:
+            bns = [m for b in self._blocks()[first:last] for m in b.modules() if isinstance(m, nn.BatchNorm2d)]
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        return y
 
     # ---- bookkeeping -------------------------------------------------------------------
     def _ordered_params(self):

@@ -39,9 +39,14 @@ def test_no_vgpr_spills_in_network_kernels(conv_kernels):
     hot += _select(conv_kernels, "tapgemm_lean_kernel<")
     hot += _select(conv_kernels, "tapgemm_split_kernel<")
     hot += _select(conv_kernels, "tapgemm_bf16_kernel<")
+    hot += _select(conv_kernels, "tapgemm_bf16_lds_kernel<")
     hot += _select(conv_kernels, "tapwgrad_kernel<")
     hot += _select(conv_kernels, "tapwgrad16_kernel<")
     assert len(hot) > 100
+    # no scratch access inside any matrix loop ...
+    bad = [(k["name"], k["loop_scratch"]) for k in hot if k["loop_scratch"] != 0]
+    assert not bad, "kernels spilling inside the MFMA loop: %r" % bad
+    # ... and none anywhere else
     bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in hot if k["vgpr_spill"] != 0]
     assert not bad, "kernels spilling vector registers: %r" % bad
 
