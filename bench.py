@@ -79,6 +79,19 @@ def build_model(batch, seed, workload="bev"):
     return model.cuda().train(), Area_Loss(2, "none")
 
 
+def _sources_digest():
+    """sha256 (first 16 hex) of the kernel sources + this file, as tools/stamp_head.sh / profiles/collect.sh compute it: lets the
+    line say whether the committed PMC evidence (profiles/traffic.json) was measured on THESE sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "lanedetection_end2end_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))) + sorted(glob.glob(os.path.join(csrc, "*.h"))) + [os.path.abspath(__file__)]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _load_json(path):
     try:
         with open(path) as f:
@@ -554,6 +567,7 @@ def main():
                     "traffic": (traffic or {}).get(("tapgemm", "tapwgrad")[dom], {}).get("bytes_per_launch")
                     if (a.workload == "bev" and a.precision == "fp32" and B == 32) else None,
                     "traffic_source": None if traffic is None else {"file": "profiles/traffic.json", "commit": traffic.get("commit"),
+                                                                     "measured_on_these_sources": traffic.get("sources_digest") == _sources_digest(),
                                                                      "algorithmic_bytes_per_launch": traffic.get("algorithmic_bytes_per_launch")},
                     "avg_launch_us": round(1e3 * d["ms"] / max(d["launches"], 1), 2),
                     "launches_per_step": d["launches"] / psteps,

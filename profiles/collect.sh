@@ -30,16 +30,16 @@ esac
 
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 16 --warmup 4 --min-seconds 1 --no-cpu-baseline --no-vendor-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 DB=$(find $OUT/trace -name '*_results.db' | head -1)
-( echo "# commit $COMMIT"; python profiles/summarize_rocpd.py "$DB" ) > profiles/${TAG}_kernel_stats.txt
+( echo "# commit $COMMIT  sources digest $DIGEST (sha256 of csrc/*.hip csrc/*.h bench.py, first 16 hex)"; python profiles/summarize_rocpd.py "$DB" ) > profiles/${TAG}_kernel_stats.txt
 
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 120 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1
 done
-python profiles/summarize_traffic.py $OUT $TAG "$COMMIT"
+python profiles/summarize_traffic.py $OUT $TAG "$COMMIT" "$DIGEST"
 
 timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-vendor-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
 DB=$(find $OUT/pmc_mfma -name '*_results.db' | head -1)
-python profiles/summarize_pmc.py "$DB" 3 > profiles/${TAG}_pmc_bench.txt
+( echo "# commit $COMMIT  sources digest $DIGEST"; python profiles/summarize_pmc.py "$DB" 3 ) > profiles/${TAG}_pmc_bench.txt
 # 5. the vendor library on the kernel-level problems (torch conv2d through MIOpen) beside the HIP kernels -> profiles/<tag>_kbench_vs_miopen.txt
 timeout 240 python tools/kbench.py --iters 100 --miopen > profiles/${TAG}_kbench_vs_miopen.txt 2>&1
 # only gpurun_out/ travels back (<= 64 MiB): keep the summaries and logs, drop the databases

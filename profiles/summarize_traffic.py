@@ -27,7 +27,7 @@ def collect(db):
     return agg
 
 
-def main(out_dir, tag, commit):
+def main(out_dir, tag, commit, digest=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = ["# rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python tools/kbench.py --variants 2 --iters 3 --one 128 32 64 1 16",
              "# one 1x3 dil-16 conv, C=128, 32x64, batch 32: x, y, gx, gy are 33.5 MB each (NHWC fp32); values in KB as reported",
@@ -51,7 +51,7 @@ def main(out_dir, tag, commit):
         if not f or not w:
             return None
         return {"bytes_per_launch": 2 * max(f) * 1e3 + max(w) * 1e3, "fetch_kb_reported": max(f), "write_kb_reported": max(w)}
-    out = {"commit": commit, "source": "profiles/%s_pmc_hbm_conv128.txt" % tag,
+    out = {"commit": commit, "sources_digest": digest, "source": "profiles/%s_pmc_hbm_conv128.txt" % tag,
            "launch": "128-channel 3-tap conv, 32x64, batch 32 (tools/kbench.py --one 128 32 64 1 16)",
            "algorithmic_bytes_per_launch": 2 * 32 * 32 * 64 * 128 * 4,
            "tapgemm": bytes_of("tapgemm_kernel<"), "tapwgrad": bytes_of("tapwgrad_kernel<")}
@@ -59,4 +59,4 @@ def main(out_dir, tag, commit):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "unknown")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "unknown", sys.argv[4] if len(sys.argv) > 4 else None)
