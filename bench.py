@@ -175,9 +175,11 @@ def cpu_baseline_and_parity(precision):
               "loss_rel_err": dict(zip(keys, (float("%.3e" % v) for v in tl))),
               "logits_max_rel_err": dict(zip(keys, (float("%.3e" % v) for v in tg))),
               "fit_only_lane_coeff_max_rel_err": float("%.3e" % e2e_oracle.relerr(beta, c["beta"])),
-              "criterion": "hip_vs_cpu64 <= 2 * cpu32_vs_cpu64 (the distance of the reference arithmetic's own fp32 run from "
-                           "fp64); the fit on identical logits is held to 1e-5",
-              "ok": bool(tb[0] <= max(2 * tb[2], 1e-5) and tl[0] <= max(2 * tl[2], 1e-5) and
+              "hip_over_cpu32_distance_to_fp64": {"lane_coeff": round(tb[0] / max(tb[2], 1e-30), 3),
+                                                  "logits_max": round(tg[0] / max(tg[2], 1e-30), 3)},
+              "criterion": "hip_vs_cpu64 <= 1.5 * cpu32_vs_cpu64 (the distance of the reference arithmetic's own fp32 run from "
+                           "fp64; 2 x before round 4's two-accumulator convolutions); the fit on identical logits is held to 1e-5",
+              "ok": bool(tb[0] <= max(1.5 * tb[2], 1e-5) and tl[0] <= max(1.5 * tl[2], 1e-5) and
                          e2e_oracle.relerr(beta, c["beta"]) <= 1e-5)}
     return base, parity
 

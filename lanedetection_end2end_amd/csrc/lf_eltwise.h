@@ -21,7 +21,7 @@ int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm,
 // kernel centres it in fp64: sum gm * xhat = rstd * sum(gm t) - mean * rstd * sum(gm)).  Round 4 measured the centred form
 // (sum gm * (t - fl32(mean)), one extra vector and subtraction per element) against it with 50-sigma channel offsets: no
 // difference in any parameter gradient -- what degrades there is the FORWARD variance (E[y^2] - mean^2 from fp32 partials),
-// DESIGN.md section 7 -- so the raw form, which keeps the epilogues free of per-channel vectors, stays.
+// DESIGN.md section 2 -- so the raw form, which keeps the epilogues free of per-channel vectors, stays.
 int lf_bn_bwd_reduce_rows(long npix);
 int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* dm,
                      float* rows, long npix, int C, long pix_per_image, int s16, hipStream_t st);
