@@ -281,7 +281,7 @@ def run_epoch(a, rank, world, dist):
 
     def train_step(sel, flip):
         gt = torch.where(flip[:, None, None], gt_pool_flipped.index_select(0, sel), gt_pool.index_select(0, sel))
-        image, _, _ = pipe(frames.index_select(0, sel), None, flip)
+        image, _, _ = pipe(frames, None, flip, index=sel)          # the index batch is gathered inside the resize kernel
         b0, b1, _, _, _, _, _, _, _ = model(image, True)
         loss = crit(b0, gt[:, 0]) + crit(b1, gt[:, 1])
         for p in params:

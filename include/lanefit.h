@@ -327,6 +327,13 @@ int lf_pipeline_image(const lf_pipeline_plan* plan, const uint8_t* frames, int N
                       const uint8_t* flip, float* out, void* stream);
 int lf_pipeline_label(const lf_pipeline_plan* plan, const uint8_t* labels, int N, const void* tables_dev,
                       const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon, void* stream);
+/* The same two calls reading a RESIDENT POOL of decoded frames / label maps: batch element n is pool entry sel[n] (int64 on the
+ * device).  The index batch of a cached dataset (SubsetRandomSampler's draw, BEV/Dataloader/Load_Data_new.py:305-320) is gathered
+ * inside the kernels instead of by a copy of N frames first. */
+int lf_pipeline_image_indexed(const lf_pipeline_plan* plan, const uint8_t* pool, long pool_frames, const int64_t* sel, int N,
+                              const void* tables_dev, const uint8_t* flip, float* out, void* stream);
+int lf_pipeline_label_indexed(const lf_pipeline_plan* plan, const uint8_t* pool, const int64_t* sel, int N, const void* tables_dev,
+                              const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Kernel-level entry points: one factorised convolution of non_bottleneck_1d

@@ -64,6 +64,8 @@ def _declare(lib):
         "lf_pipeline_tables_host": (I, [P, P, P, P, P, P, P, P, P]),
         "lf_pipeline_image": (I, [P, P, I, P, P, P, P]),
         "lf_pipeline_label": (I, [P, P, I, P, P, I, P, P, P, P]),
+        "lf_pipeline_image_indexed": (I, [P, P, L, P, I, P, P, P, P]),
+        "lf_pipeline_label_indexed": (I, [P, P, P, I, P, P, I, P, P, P, P]),
         "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
         "lf_pointwise_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
         "lf_pointwise_scratch_floats": (L, [I, I, I, I, I]),

@@ -62,28 +62,46 @@ class InputPipeline:
             self._lut = (v * 255).long().to(device)
         return self._tables, self._lut
 
-    def __call__(self, frames_u8, labels_u8=None, flip=None):
+    def __call__(self, frames_u8, labels_u8=None, flip=None, index=None):
+        """``index`` (N,) int64 on the device: ``frames_u8`` / ``labels_u8`` are a resident POOL and batch element n is pool entry
+        ``index[n]`` -- gathered inside the kernels (``lf_pipeline_image_indexed``), no copy of the N selected frames first."""
         lib = _lib.load()
         if not frames_u8.is_cuda:
             raise _lib.LaneFitLibraryError("InputPipeline needs the decoded frames on the MI355X; there is no CPU path")
-        N, H, W, C = frames_u8.shape
+        pool, H, W, C = frames_u8.shape
         assert (H, W) == self.frame_hw and C == 3 and frames_u8.dtype == torch.uint8
         dev = frames_u8.device
         tables, lut = self._device_state(dev)
         R = self.resize
+        sel = None
+        N = pool
+        if index is not None:
+            sel = index.to(device=dev, dtype=torch.int64).contiguous()
+            N = sel.numel()
         fl = None if flip is None else flip.to(device=dev, dtype=torch.uint8).contiguous()
+        frames_u8 = frames_u8.contiguous()
         image = torch.empty(N, 3, R, 2 * R, dtype=torch.float32, device=dev)
-        _lib.check(lib.lf_pipeline_image(self.handle, _lib.ptr(frames_u8.contiguous()), N, _lib.ptr(tables), _lib.ptr(fl),
-                                         _lib.ptr(image), _lib.stream()), "lf_pipeline_image")
+        if sel is None:
+            _lib.check(lib.lf_pipeline_image(self.handle, _lib.ptr(frames_u8), N, _lib.ptr(tables), _lib.ptr(fl),
+                                             _lib.ptr(image), _lib.stream()), "lf_pipeline_image")
+        else:
+            _lib.check(lib.lf_pipeline_image_indexed(self.handle, _lib.ptr(frames_u8), pool, _lib.ptr(sel), N, _lib.ptr(tables),
+                                                     _lib.ptr(fl), _lib.ptr(image), _lib.stream()), "lf_pipeline_image_indexed")
         gt = horizon = None
         if labels_u8 is not None:
-            assert labels_u8.shape == (N, H, W) and labels_u8.dtype == torch.uint8
+            assert labels_u8.shape == (pool, H, W) and labels_u8.dtype == torch.uint8
+            labels_u8 = labels_u8.contiguous()
             gt = torch.empty(N, 1, R, 2 * R, dtype=torch.int64, device=dev)
             if self.tree == "bev":
                 horizon = torch.empty(N, R, dtype=torch.float32, device=dev)
-            _lib.check(lib.lf_pipeline_label(self.handle, _lib.ptr(labels_u8.contiguous()), N, _lib.ptr(tables), _lib.ptr(fl),
-                                             self.mode, _lib.ptr(lut), _lib.ptr(gt), _lib.ptr(horizon), _lib.stream()),
-                       "lf_pipeline_label")
+            if sel is None:
+                _lib.check(lib.lf_pipeline_label(self.handle, _lib.ptr(labels_u8), N, _lib.ptr(tables), _lib.ptr(fl),
+                                                 self.mode, _lib.ptr(lut), _lib.ptr(gt), _lib.ptr(horizon), _lib.stream()),
+                           "lf_pipeline_label")
+            else:
+                _lib.check(lib.lf_pipeline_label_indexed(self.handle, _lib.ptr(labels_u8), _lib.ptr(sel), N, _lib.ptr(tables),
+                                                         _lib.ptr(fl), self.mode, _lib.ptr(lut), _lib.ptr(gt), _lib.ptr(horizon),
+                                                         _lib.stream()), "lf_pipeline_label_indexed")
         return image, gt, horizon
 
 

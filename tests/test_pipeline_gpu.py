@@ -90,3 +90,22 @@ def test_pipeline_feeds_the_network():
     out = model(image, True)
     (out[0].sum() + out[1].sum()).backward()
     assert torch.isfinite(out[0]).all() and torch.isfinite(model.net.encoder.initial_block.conv.weight.grad).all()
+
+
+def test_pipeline_indexed_pool_equals_gather_then_pipeline(frames):
+    """``index``: the batch is gathered from a resident pool INSIDE the kernels (lf_pipeline_image_indexed /
+    lf_pipeline_label_indexed) -- bit-identical to gathering the frames first (what a cached dataset's SubsetRandomSampler batch
+    needs, BEV/Dataloader/Load_Data_new.py:305-320), repeated and out-of-order indices included."""
+    from lanedetection_end2end_amd.pipeline import InputPipeline
+    rng = np.random.default_rng(11)
+    pool_f = torch.from_numpy(np.stack([frames[0][0], frames[1][0]] + [rng.integers(0, 256, frames[0][0].shape, dtype=np.uint8) for _ in range(3)])).cuda()
+    pool_l = torch.from_numpy(np.stack([frames[0][1], frames[1][1]] + [rng.integers(0, 5, frames[0][1].shape, dtype=np.uint8) for _ in range(3)])).cuda()
+    sel = torch.tensor([4, 0, 0, 3, 1, 2], device="cuda")
+    flip = torch.tensor([True, False, True, False, False, True])
+    for tree, ncls, R in (("bev", 2, 64), ("bp", 4, 256)):
+        pipe = InputPipeline(R, tree=tree, nclasses=ncls)
+        a = pipe(pool_f, pool_l, flip, index=sel)
+        b = pipe(pool_f.index_select(0, sel), pool_l.index_select(0, sel), flip)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert (a[2] is None and b[2] is None) or torch.equal(a[2], b[2])
+        assert a[0].shape == (6, 3, R, 2 * R)
