@@ -15,11 +15,33 @@ import torch
 from . import _lib
 
 
+def _upload(host_array, device):
+    """A small host table to the device WITHOUT stalling the stream: pinned staging + non-blocking copy.  (The engine hands out
+    parameter gradients as views of a flat buffer that the caching allocator alternates between two addresses, so the record
+    table is rebuilt every step; a pageable `.to(device)` there is a synchronous copy queued behind the whole backward pass --
+    the host then waits for the GPU once per step and the next forward's launches start late: ~0.5 ms per step in
+    `bench.py --workload epoch`, round 4.)  Returns (device tensor, pinned tensor to keep alive with it)."""
+    pinned = torch.from_numpy(host_array).pin_memory()
+    return pinned.to(device, non_blocking=True), pinned
+
+
+def _work_list(numels, chunk, device, cache):
+    """(tensor, chunk) work items for tensors of these sizes: depends on the sizes only, cached."""
+    key = (tuple(numels), chunk, device)
+    hit = cache.get(key)
+    if hit is None:
+        work = np.array([(i, c) for i, n in enumerate(numels) for c in range((n + chunk - 1) // chunk)], dtype=np.int32).reshape(-1, 2)
+        dev, pin = _upload(work, device)
+        hit = cache[key] = (dev, pin, len(work))
+    return hit
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = float(grad_scale)
         self._tables = {}
+        self._works = {}
 
     def load_state_dict(self, state_dict):
         """A loaded state replaces ``exp_avg`` / ``exp_avg_sq`` / ``step``: the cached device tables hold the OLD buffers' addresses
@@ -43,14 +65,14 @@ class FusedAdam(torch.optim.Optimizer):
             return cached
         chunk = _lib.load().lf_adam_chunk()
         rec = np.zeros((len(plist), 7), dtype=np.int64)
-        work = []
         for i, p in enumerate(plist):
             st = self.state[p]
             n = int(st["step"])
             rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), n, n)
-            work += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
         dev = plist[0].device
-        cached = [key, torch.from_numpy(rec).to(dev), torch.tensor(work, dtype=torch.int32, device=dev), len(work), 0]
+        t_work, _, nwork = _work_list([p.numel() for p in plist], chunk, dev, self._works)
+        t_rec, pin = _upload(rec, dev)
+        cached = [key, t_rec, t_work, nwork, 0, pin]
         self._tables[gi] = cached
         return cached
 
@@ -76,7 +98,7 @@ class FusedAdam(torch.optim.Optimizer):
                 elif torch.is_tensor(st["step"]):              # a loaded torch.optim.Adam state
                     st["step"] = int(st["step"])
             tab = self._table(gi, plist)
-            _, t_rec, t_work, nblocks, parity = tab
+            _, t_rec, t_work, nblocks, parity = tab[:5]
             b1, b2 = group["betas"]
             _lib.check(lib.lf_adam_step(_lib.ptr(t_rec), _lib.ptr(t_work), nblocks, group["lr"], b1, b2, group["eps"],
                                         group["weight_decay"], parity, self.grad_scale, _lib.stream()), "lf_adam_step")
@@ -94,6 +116,7 @@ class _FusedMomentum(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.grad_scale = float(grad_scale)
         self._tables = {}
+        self._works = {}
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)      # new state buffers: the cached device tables point at the old ones
@@ -110,15 +133,15 @@ class _FusedMomentum(torch.optim.Optimizer):
             return cached
         chunk = _lib.load().lf_adam_chunk()
         rec = np.zeros((len(plist), 7), dtype=np.int64)
-        work = []
         for i, p in enumerate(plist):
             st = self.state[p]
             m = st["momentum_buffer"]
             v = st["square_avg"] if "square_avg" in st else m
             rec[i] = (p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, 0)
-            work += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
         dev = plist[0].device
-        cached = (key, torch.from_numpy(rec).to(dev), torch.tensor(work, dtype=torch.int32, device=dev), len(work))
+        t_work, _, nwork = _work_list([p.numel() for p in plist], chunk, dev, self._works)
+        t_rec, pin = _upload(rec, dev)
+        cached = (key, t_rec, t_work, nwork, pin)
         self._tables[gi] = cached
         return cached
 
@@ -143,7 +166,7 @@ class _FusedMomentum(torch.optim.Optimizer):
                     if st.get(name) is None:
                         st[name] = torch.zeros_like(p)
                 st["step"] = st.get("step", 0) + 1
-            _, t_rec, t_work, nblocks = self._table(gi, plist)
+            _, t_rec, t_work, nblocks = self._table(gi, plist)[:4]
             self._launch(group, t_rec, t_work, nblocks)
         return loss
 
