@@ -40,11 +40,16 @@ python profiles/summarize_traffic.py $OUT $TAG "$COMMIT" "$DIGEST"
 timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-vendor-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
 DB=$(find $OUT/pmc_mfma -name '*_results.db' | head -1)
 ( echo "# commit $COMMIT  sources digest $DIGEST"; python profiles/summarize_pmc.py "$DB" 3 ) > profiles/${TAG}_pmc_bench.txt
+# 4b. the bf16-tensor tap-GEMM, LDS-staged vs streaming (tools/bf16_ab.py runs both on the same launches): LDS vs vector-memory
+#     instruction counts and matrix-pipe busy cycles per launch -> profiles/<tag>_pmc_bf16_lds.txt
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_bf16 -o p -- python tools/bf16_ab.py --iters 3 > $OUT/pmc_bf16.log 2>&1
+DB=$(find $OUT/pmc_bf16 -name '*_results.db' | head -1)
+[ -n "$DB" ] && ( echo "# commit $COMMIT  sources digest $DIGEST"; python profiles/summarize_pmc.py "$DB" 3 ) > profiles/${TAG}_pmc_bf16_lds.txt
 # 5. the vendor library on the kernel-level problems (torch conv2d through MIOpen) beside the HIP kernels -> profiles/<tag>_kbench_vs_miopen.txt
 timeout 240 python tools/kbench.py --iters 100 --miopen > profiles/${TAG}_kbench_vs_miopen.txt 2>&1
 # only gpurun_out/ travels back (<= 64 MiB): keep the summaries and logs, drop the databases
 mkdir -p gpurun_out/profiles_$TAG
-cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/${TAG}_kbench_vs_miopen.txt profiles/traffic.json gpurun_out/profiles_$TAG/ 2>/dev/null
+cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/${TAG}_pmc_bf16_lds.txt profiles/${TAG}_kbench_vs_miopen.txt profiles/traffic.json gpurun_out/profiles_$TAG/ 2>/dev/null
 cp $OUT/*.log $OUT/*.err $OUT/*.json gpurun_out/profiles_$TAG/ 2>/dev/null
 rm -rf $OUT
 head -12 profiles/${TAG}_kernel_stats.txt; cat profiles/traffic.json; tail -3 gpurun_out/profiles_$TAG/*.err gpurun_out/profiles_$TAG/pmc_*.log 2>/dev/null | tail -30

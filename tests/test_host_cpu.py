@@ -174,3 +174,43 @@ def test_classification_module_and_chain_plan():
     assert b"multiples of 16" in lib.lf_last_error()
     with pytest.raises(_lib.LaneFitLibraryError):
         m(torch.zeros(1, 128, 32, 64))          # no CPU path
+
+
+def test_blocks_are_bound_to_their_layer_range():
+    """Block-level surface (round 4): every sub-module knows its layer range of the engine plan; the plan's layer geometry (a
+    host object) agrees with the modules' channel counts and the cumulative-stride table of erfnet.py; the binding survives
+    deepcopy and pickling (weak references are re-bound), and a block refuses host tensors like the whole network does."""
+    import copy
+    import ctypes
+    import io
+    from lanedetection_end2end_amd import _lib, erfnet
+    lib = _lib.load()
+    net = erfnet.Net(in_channels=3, out_channels=2, pretrained=True)
+    blocks = net._blocks()
+    assert len(blocks) == 22 and net.encoder._lf_range == (0, 16) and net.decoder._lf_range == (16, 22)
+    plan = erfnet._Plan(2, 64, 128, 3, 2, 2)
+    assert lib.lf_erfnet_num_layers(plan.handle) == 22
+    io6 = (ctypes.c_int * 6)()
+    for i, b in enumerate(blocks):
+        assert b._lf_range == (i, i + 1) and b._owner() is net
+        assert lib.lf_erfnet_layer_io(plan.handle, i, io6) == 0
+        s = erfnet._LAYER_IN_STRIDE[i]
+        assert (io6[1], io6[2]) == (64 // s, 128 // s), (i, list(io6))
+        conv = b.conv if hasattr(b, "conv") else b.conv3x1_1
+        cin = conv.in_channels
+        assert io6[0] == cin, (i, io6[0], cin)
+        mask = net._range_param_mask(i, i + 1, -1)
+        assert sum(mask) == len(list(b.parameters()))
+    assert lib.lf_erfnet_layer_io(plan.handle, 22, io6) != 0
+    for clone in (copy.deepcopy(net),):
+        assert clone.encoder._owner() is clone and clone.decoder.layers[2]._owner() is clone
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert back.encoder.layers[4]._owner() is back
+    with pytest.raises(_lib.LaneFitLibraryError):
+        net.encoder.layers[1](torch.zeros(1, 64, 16, 32))
+    orphan = erfnet.non_bottleneck_1d(64, 0.0, 1)
+    with pytest.raises(RuntimeError):
+        orphan(torch.zeros(1, 64, 16, 32))
