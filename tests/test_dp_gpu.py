@@ -68,7 +68,11 @@ def test_reducer_and_ce_check_do_not_sync_the_host():
     from lanedetection_end2end_amd import dp, losses
     own = not dist.is_initialized()
     if own:
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("nccl", rank=0, world_size=1)      # RCCL with one rank: the bucket path through the real backend
     try:
         ps = [torch.nn.Parameter(torch.randn(1000, 1000, device="cuda")) for _ in range(4)]
