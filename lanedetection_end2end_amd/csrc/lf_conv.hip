@@ -701,7 +701,9 @@ constexpr size_t LB_TAB_PER_TAP = (size_t)WG_WAVES * 64 * sizeof(uint4);
 // s_waitcnt vmcnt(N) + bare s_barrier below instead.  (Compiler-issued waits stay correct: they can only over-wait.)
 typedef int i32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_dma16(i32x4s rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    // (s_nop 0: the wait state between the SALU write of M0 and the LDS-DMA instruction that reads it -- nothing pads the inside of
+    // an asm string)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ i32x4s make_rsrc_words(const void* base, unsigned bytes) {
     const unsigned long long ad = (unsigned long long)base;
@@ -713,9 +715,11 @@ __device__ __forceinline__ i32x4s make_rsrc_words(const void* base, unsigned byt
     return r;
 }
 
-template <int EPIC>
+template <int EPIC, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void tapgemm_bf16_lds_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     constexpr int NT = 4;
+    unsigned long long tstamp[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+    if constexpr (DBG) tstamp[0] = __builtin_amdgcn_s_memrealtime();
     constexpr bool S16 = true, HOISTV = true;
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -791,14 +795,16 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_lds_kernel(const LfTapGeo
     };
     issue();
     issue();
+    if constexpr (DBG) tstamp[1] = __builtin_amdgcn_s_memrealtime();
     // fragment addresses (bytes inside a stage)
     const unsigned xfrag = (unsigned)(wave * 4096 + pl * 64 + ((kq ^ (pl >> 2)) & 3) * 16);       // + m * 1024
     const unsigned wfrag = (unsigned)(LB_X_BYTES + (kq * 64 + pl) * 16);                           // + n * 256
     for (int s = 0; s < nsteps; ++s) {
         // my DMA of step s has landed (the 5 instructions of step s + 1 may still be in flight) ...
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();        // ... and everyone's; everyone is past the fragment reads of step s - 1
         asm volatile("" ::: "memory");
+        if constexpr (DBG) { if (s == 0) tstamp[2] = __builtin_amdgcn_s_memrealtime(); }
         issue();                             // step s + 2 -> the stage step s - 1 occupied
         const unsigned char* st = stages + (s % LB_STAGES) * LB_STAGE_BYTES;
         bf16x8 wb[NT], xb[MT];
@@ -815,6 +821,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_lds_kernel(const LfTapGeo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two trailing (dead) steps: nothing may land in LDS after this
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (DBG) { asm volatile("" ::"v"(acc[0][0][0])); tstamp[3] = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- epilogue: the accumulator layout of tapgemm_bf16_kernel (tile m: pixel m*16 + pl; rows 4*kq + e of tile n)
     int pn[MT], pi[MT], pj[MT];
@@ -830,6 +837,642 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_lds_kernel(const LfTapGeo
         pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
     }
     LF_TAPGEMM_EPILOGUE
+    if constexpr (DBG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp[4] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && a.dbg) {
+            unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WG_WAVES + wave) * 8;
+            d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3]; d[5] = tstamp[4];
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// tapgemm_bf16_ring_kernel: the LDS-staged bf16 tap-GEMM as a PERSISTENT workgroup whose DMA ring runs across tiles.
+//
+// Why (tools/kbench.py --phases16, profiles/r4_bf16_phases.txt): a workgroup of tapgemm_bf16_lds_kernel lives 13 us at 128
+// channels -- 2.7 us building the per-lane tap table (eight 32-bit divisions and ~500 VALU instructions per wave, two waves
+// per SIMD doing it at the same time), 7.2 us in the K loop (12 steps of 0.11 us matrix work each: the loop waits for the ring,
+// 2 workgroups x 2 steps x 20 KB in flight per CU), 2.8 us in the epilogue -- and the memory pipe idles through the first and
+// the last of the three.  Here
+//  * a workgroup walks its work items (pixel tile x output-channel slab) and its load cursor runs two K-steps ahead of the
+//    compute cursor ACROSS item boundaries: the first operands of the next item land while this item's epilogue stores;
+//  * no tap table: the launcher admits geometries whose 16-pixel groups lie in one image row (Wl % 16 == 0), so a DMA
+//    instruction's 16 pixels share (image, row) -- wave-uniform, scalar registers: ONE division pair per wave and item -- and a
+//    lane's byte offset is a scalar base plus a per-lane constant, with the column test (one unsigned compare) selecting the
+//    out-of-range offset for padding;
+//  * NH = 2: the workgroup owns all 128 output channels of its pixels (32 accumulator tiles per wave), so X goes through the
+//    ring once per tap instead of once per tap and slab; the stage grows by the second slab's weights (24 KB, 3 stages = 72 KB,
+//    still two workgroups per CU).
+// Stage layout, swizzle, barrier protocol and K order are those of tapgemm_bf16_lds_kernel (results bit-identical).
+// ---------------------------------------------------------------------------------------
+struct RingGroups { int n[4], i[4], j[4]; bool ok[4]; };
+// the four consecutive 16-pixel groups from group index G0 on: (image, row, first column), all wave-uniform
+__device__ __forceinline__ void groups_at(unsigned G0, int Hl, unsigned GR, unsigned ngroups, RingGroups& o) {
+    const unsigned Gc = G0 < ngroups ? G0 : 0u;
+    const unsigned R = Gc / GR;
+    int jg = __builtin_amdgcn_readfirstlane((int)(Gc - R * GR));
+    int n = __builtin_amdgcn_readfirstlane((int)(R / (unsigned)Hl));
+    int i = __builtin_amdgcn_readfirstlane((int)R) - n * Hl;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        o.ok[m] = G0 + m < ngroups;
+        o.n[m] = n; o.i[m] = i; o.j[m] = jg * 16;
+        if (++jg == (int)GR) { jg = 0; if (++i == Hl) { i = 0; ++n; } }
+    }
+}
+// ... of wave `wave` of the 256-pixel tile `tile`
+__device__ __forceinline__ void ring_groups(unsigned tile, int wave, int Hl, unsigned GR, unsigned ngroups, RingGroups& o) {
+    groups_at((tile * WG_WAVES + (unsigned)wave) * 4u, Hl, GR, ngroups, o);
+}
+
+// DBG: per-wave stamps, 16 x uint64 per wave: start, hardware id, then (K loop done, epilogue stores retired) per item, 7 items
+template <int NH, int EPIC, bool DBG = false>
+__global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
+    constexpr bool S16 = true, HOISTV = NH == 1;
+    unsigned long long* dbgp = nullptr;
+    int dbgk = 0;
+    if constexpr (DBG) {
+        dbgp = a.dbg + ((unsigned long long)blockIdx.x * WG_WAVES + (threadIdx.x >> 6)) * 16;
+        if ((threadIdx.x & 63) == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            dbgp[0] = __builtin_amdgcn_s_memrealtime();
+            dbgp[1] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+        }
+    }
+    constexpr int STAGE = LB_X_BYTES + NH * LB_W_BYTES;
+    const int epi = EPIC >= 0 ? EPIC : epi_rt;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pl = lane & 15, kq = lane >> 4;
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl), ngroups = npix >> 4, GR = (unsigned)g.Wl >> 4;
+    const unsigned ntiles = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
+    const int slsh = (g.Cd / (64 * NH)) > 1 ? 1 : 0;              // output-channel slabs per pixel tile: 1 or 2
+    const unsigned nitems = ntiles << slsh;
+    // work items first, first + stride, ... inside this XCD's contiguous range (see tapgemm_kernel)
+    unsigned it_first = blockIdx.x, it_stride = gridDim.x, it_end = nitems;
+    if ((gridDim.x & 7u) == 0 && (nitems & 7u) == 0) {
+        const unsigned per = nitems >> 3;
+        it_first = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); it_stride = gridDim.x >> 3; it_end = (blockIdx.x & 7u) * per + per;
+    }
+    // tap offsets: tap t in lane t (read back with v_readlane: no dependent scalar loads in the issue path)
+    int tapv = 0;
+#pragma unroll
+    for (int t = 0; t < LF_MAX_TAPS; ++t)
+        if (lane == t) tapv = (g.tdh[t] & 0xffff) | (g.tdw[t] << 16);
+
+    const int ncb = g.Cs >> 5;
+    const int nsteps = g.ntaps * ncb;
+    const i32x4s rx = make_rsrc_words(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB)),
+                 rw = make_rsrc_words(a.wp16, 0xffffffffu);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lf_tap_lds;
+    unsigned char* const stages = lf_tap_lds;
+    const int wstep = g.Cd * 64;                               // bytes per 32-channel step (4 k-blocks x Cd x 16)
+    const int spix2 = g.s_pix * 2;
+    // per-lane constants of the DMA mapping: instruction m, this lane -> pixel (group m) + (lane >> 2), channel block
+    // (lane & 3) ^ ((lane >> 4) & 3) of the 32-channel step
+    const int dq = lane >> 2, dkq = (lane & 3) ^ ((lane >> 4) & 3);
+    const unsigned lane_x = (unsigned)((dq * g.ssw * g.s_pix + g.s_choff + dkq * 8) * 2);
+    const int lane_dx = dq * g.ssw;
+    const unsigned lane_w = (unsigned)((wave * g.Cd + lane) * 16);
+
+    // ---- load cursor (wave-uniform): item, tap, channel block, ring stage; the item's four groups as (pixel index of the
+    // row position without the tap, row, column) and a validity mask
+    unsigned it_ld = it_first;
+    int t_ld = 0, cb_ld = 0, st_ld = 0, wofs = 0, cob_ld = 0;
+    int lrow[4], liy[4], lsx[4];
+    unsigned lok = 0;
+    auto cursor_item = [&]() {
+        lok = 0;
+        if (it_ld < it_end) {
+            RingGroups G;
+            ring_groups(it_ld >> slsh, wave, g.Hl, GR, ngroups, G);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                liy[m] = G.i[m] * g.ssh; lsx[m] = G.j[m] * g.ssw;
+                lrow[m] = (G.n[m] * g.Hs + liy[m]) * g.Ws + lsx[m];
+                lok |= G.ok[m] ? 1u << m : 0u;
+            }
+            cob_ld = (int)(it_ld & (unsigned)slsh) * 64 * NH;
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { liy[m] = 0; lsx[m] = 0; lrow[m] = 0; }
+        }
+    };
+    cursor_item();
+    auto issue = [&]() {                                     // DMA of the cursor's step into stage st_ld
+        const unsigned st = lds0 + (unsigned)(st_ld * STAGE);
+        const int tv = __builtin_amdgcn_readlane(tapv, t_ld);
+        const int dh = (int)(short)(tv & 0xffff), dw = tv >> 16;
+        const int tapoff = dh * g.Ws + dw;
+        const unsigned xs = st + (unsigned)wave * 4096u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int sy = liy[m] + dh;
+            const bool yok = ((lok >> m) & 1u) && sy >= 0 && sy < g.Hs;
+            const unsigned base = (unsigned)((lrow[m] + tapoff) * spix2 + cb_ld * 64);
+            const bool in = yok && (unsigned)(lsx[m] + dw + lane_dx) < (unsigned)g.Ws;
+            lds_dma16(rx, xs + (unsigned)m * 1024u, in ? base + lane_x : LF_OOB, 0u);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            lds_dma16(rw, st + (unsigned)(LB_X_BYTES + (wave * 64 * NH + h * 64) * 16), lane_w + (unsigned)((cob_ld + h * 64) * 16), (unsigned)wofs);
+        // advance; past the last item the X part writes zeros (out-of-range offsets) into a stage nobody reads
+        st_ld = st_ld == LB_STAGES - 1 ? 0 : st_ld + 1;
+        wofs += wstep;
+        if (++cb_ld == ncb) {
+            cb_ld = 0;
+            if (++t_ld == g.ntaps) { t_ld = 0; wofs = 0; it_ld += it_stride; cursor_item(); }
+        }
+    };
+    issue();
+    issue();
+    // fragment addresses (bytes inside a stage)
+    const unsigned xfrag = (unsigned)(wave * 4096 + pl * 64 + ((kq ^ (pl >> 2)) & 3) * 16);       // + m * 1024
+    const unsigned wfrag = (unsigned)(LB_X_BYTES + (kq * 64 * NH + pl) * 16);                      // + (h * 64 + n * 16) * 16
+    int st_c = 0;
+    for (unsigned it = it_first; it < it_end; it += it_stride) {
+        f32x4 accs[NH][4][MT];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) accs[h][n][m] = zero4();
+        for (int s = 0; s < nsteps; ++s) {
+            // my DMA of this step has landed (the instructions of the next step may still be in flight) ...
+            if constexpr (NH == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();        // ... and everyone's; everyone is past the fragment reads of the step before
+            asm volatile("" ::: "memory");
+            issue();                             // two steps ahead -> the stage the previous step occupied
+            const unsigned char* st = stages + st_c * STAGE;
+            st_c = st_c == LB_STAGES - 1 ? 0 : st_c + 1;
+            bf16x8 xb[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(st + xfrag + m * 1024);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                bf16x8 wb[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) wb[n] = *reinterpret_cast<const bf16x8*>(st + wfrag + (h * 64 + n * 16) * 16);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        accs[h][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[n], xb[m], accs[h][n][m], 0, 0, 0);
+            }
+        }
+        if constexpr (DBG) {
+            asm volatile("" ::"v"(accs[0][0][0][0]));
+            if (lane == 0 && dbgk < 7) dbgp[2 + 2 * dbgk] = __builtin_amdgcn_s_memrealtime();
+        }
+        // ---- epilogue of this item (the accumulator layout of tapgemm_bf16_kernel: tile m = group m, pixel m*16 + pl)
+        const unsigned bx = it >> slsh;
+        int pn[MT], pi[MT], pj[MT];
+        bool pv[MT];
+        {
+            RingGroups G;
+            ring_groups(bx, wave, g.Hl, GR, ngroups, G);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { pn[m] = G.n[m]; pi[m] = G.i[m]; pj[m] = G.j[m] + pl; pv[m] = G.ok[m]; }
+        }
+        const int cob0 = (int)(it & (unsigned)slsh) * 64 * NH;
+        // (NH = 2 runs the 64-channel epilogue twice)
+        {
+            constexpr int NT = 4;
+            const int cob = cob0;
+            f32x4 (&acc)[4][MT] = accs[0];
+            LF_TAPGEMM_EPILOGUE
+        }
+        if constexpr (NH == 2) {
+            constexpr int NT = 4;
+            const int cob = cob0 + 64;
+            f32x4 (&acc)[4][MT] = accs[NH - 1];
+            LF_TAPGEMM_EPILOGUE
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (DBG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && dbgk < 7) dbgp[3 + 2 * dbgk] = __builtin_amdgcn_s_memrealtime();
+            ++dbgk;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two trailing (dead) steps: nothing may land in LDS after this
+    __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------
+// tapgemm_bf16_stream_kernel: bf16 tap-GEMM with the REGISTER FILE as the operand ring and the weights resident in LDS.
+//
+// What the stamps of the two LDS-ring kernels showed (tools/kbench.py --phases16): a K-step takes 0.8-0.9 us whatever the
+// stage size -- the ring is full (2 workgroups x 2 stages is all the LDS holds) and each 32-channel step fetches HALF of every
+// 128-byte line it touches, the other half a step later when the line has left the 32 KB L1: ~12 TB/s of useful operand
+// bytes, twice that through the L2s (34.5 TB/s peak).  This form
+//  * keeps a whole TAP of a wave's 64 pixels in flight -- every channel of the pixel, i.e. whole lines, fetched by back-to-back
+//    instructions: CB x 4 dwordx4 loads straight into the MFMA operand registers (16 KB per wave at 128 channels, 128 KB per
+//    CU against 80 KB of ring) -- double-buffered by tap in two named register sets;
+//  * has NO barrier in the loop: the waves share only the weights, which the workgroup loads ONCE (all taps of its
+//    64-output-channel slab, 48 KB at 128 channels) and keeps in LDS across its work items (persistent, one slab per
+//    workgroup); weight fragments are four ds_read_b128 per 32-channel step;
+//  * like the ring kernel runs its load cursor across item boundaries (the first tap of the next item is in flight during
+//    the epilogue) and needs Wl % 16 == 0 for the scalar (image, row) addressing.
+// CB = Cs / 32 (2 or 4).  K order and rounding are those of tapgemm_bf16_kernel: results bit-identical.
+// ---------------------------------------------------------------------------------------
+template <int CB, int EPIC>
+__global__ __launch_bounds__(256, 2) void tapgemm_bf16_stream_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
+    constexpr int NT = 4;
+    constexpr bool S16 = true, HOISTV = CB == 2;
+    const int epi = EPIC >= 0 ? EPIC : epi_rt;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pl = lane & 15, kq = lane >> 4;
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl), ngroups = npix >> 4, GR = (unsigned)g.Wl >> 4;
+    const unsigned ntiles = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
+    // Workgroup b: XCD b & 7 (observed), index q = b >> 3 inside it; slab q % nslab (fixed: its weights stay in LDS), pixel
+    // tiles first, first + stride, ... of the XCD's contiguous range.  The launcher sizes the grid to a multiple of 8 * nslab.
+    const unsigned nslab = (unsigned)g.Cd / 64u;
+    const unsigned q = blockIdx.x >> 3, per = (ntiles + 7u) >> 3;
+    const int cob = (int)(q % nslab) * 64;
+    const unsigned it_first = (blockIdx.x & 7u) * per + q / nslab, it_stride = (gridDim.x >> 3) / nslab;
+    unsigned it_end = (blockIdx.x & 7u) * per + per;
+    if (it_end > ntiles) it_end = ntiles;
+
+    int tapv = 0;           // tap t's offsets in lane t (v_readlane in the issue path instead of dependent scalar loads)
+#pragma unroll
+    for (int t = 0; t < LF_MAX_TAPS; ++t)
+        if (lane == t) tapv = (g.tdh[t] & 0xffff) | (g.tdw[t] << 16);
+
+    // ---- the slab's weights -> LDS: [tap][cb][k-block 4][cout 64][16 B]; wave w carries k-block w of every (tap, cb)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lf_tap_lds;
+    {
+        const i32x4s rw = make_rsrc_words(a.wp16, 0xffffffffu);
+        const unsigned wv = (unsigned)((wave * g.Cd + cob + lane) * 16);
+        const int nw = g.ntaps * CB;
+        for (int i = 0; i < nw; ++i) lds_dma16(rw, lds0 + (unsigned)((i * 4 + wave) * 1024), wv, (unsigned)(i * g.Cd * 64));
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB));
+    const int spix2 = g.s_pix * 2;
+    const unsigned lane_x = (unsigned)((pl * g.ssw * g.s_pix + g.s_choff + kq * 8) * 2);
+    const int lane_dx = pl * g.ssw;
+
+    // ---- load cursor (wave-uniform): item, tap; the item's four 16-pixel groups
+    unsigned it_ld = it_first;
+    int t_ld = 0;
+    int lrow[4], liy[4], lsx[4];
+    unsigned lok = 0;
+    auto cursor_item = [&]() {
+        lok = 0;
+        if (it_ld < it_end) {
+            RingGroups G;
+            ring_groups(it_ld, wave, g.Hl, GR, ngroups, G);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                liy[m] = G.i[m] * g.ssh; lsx[m] = G.j[m] * g.ssw;
+                lrow[m] = (G.n[m] * g.Hs + liy[m]) * g.Ws + lsx[m];
+                lok |= G.ok[m] ? 1u << m : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { liy[m] = 0; lsx[m] = 0; lrow[m] = 0; }
+        }
+    };
+    cursor_item();
+    struct Tap { u32x4v x[CB][MT]; };
+    auto issue = [&](Tap& S) __attribute__((always_inline)) {          // the cursor's tap: every channel of the wave's 64 pixels
+        const int tv = __builtin_amdgcn_readlane(tapv, t_ld);
+        const int dh = (int)(short)(tv & 0xffff), dw = tv >> 16;
+        const int tapoff = dh * g.Ws + dw;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int sy = liy[m] + dh;
+            const bool yok = ((lok >> m) & 1u) && sy >= 0 && sy < g.Hs;
+            const unsigned base = (unsigned)((lrow[m] + tapoff) * spix2);
+            const bool in = yok && (unsigned)(lsx[m] + dw + lane_dx) < (unsigned)g.Ws;
+            const unsigned vo = in ? base + lane_x : LF_OOB;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) S.x[cb][m] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(vo + cb * 64u), 0, 0);
+        }
+        if (++t_ld == g.ntaps) { t_ld = 0; it_ld += it_stride; cursor_item(); }
+    };
+    f32x4 acc[NT][MT];
+    const unsigned char* const wl = lf_tap_lds + (kq * 64 + pl) * 16;       // + ((t * CB + cb) * 4) * 1024 + n * 256
+    auto compute = [&](const Tap& S, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            bf16x8 wb[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wb[n] = *reinterpret_cast<const bf16x8*>(wl + (t * CB + cb) * 4096 + n * 256);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[n], __builtin_bit_cast(bf16x8, S.x[cb][m]), acc[n][m], 0, 0, 0);
+        }
+    };
+    // ODD tap counts only (3-tap and 9-tap convolutions; the launcher sends the 2- and 4-tap transposed-convolution phases to
+    // the ring kernel): the taps go in pairs A, B and the last one in A, so exactly ONE register set -- B, holding the first
+    // tap of the next item -- is live across the epilogue, statically.  PREF = false (128 input channels with a BN-backward-sum
+    // epilogue: 64 + 64 registers beside ~125 of epilogue state) issues that tap behind the epilogue instead.
+    constexpr bool PREF = !(EPIC < 0 || ((EPIC & LF_EPI_STATS_XHAT) != 0 && (CB == 4 || (EPIC & LF_EPI_MASKBN) != 0)));
+    Tap A, B;
+    issue(A);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the weights (and the first tap) have landed ...
+    __syncthreads();                                        // ... everyone's part of them
+    const int ntaps = g.ntaps;
+    for (unsigned bx = it_first; bx < it_end; bx += it_stride) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+        int t = 0;
+        for (; t + 1 < ntaps; t += 2) {
+            issue(B);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A, t);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(A);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(B, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (PREF) { issue(B); __builtin_amdgcn_sched_barrier(0); }      // the first tap of the next item
+        compute(A, t);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue of this item (tile m = group m, pixel m*16 + pl)
+        {
+        int pn[MT], pi[MT], pj[MT];
+        bool pv[MT];
+        {
+            RingGroups G;
+            ring_groups(bx, wave, g.Hl, GR, ngroups, G);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { pn[m] = G.n[m]; pi[m] = G.i[m]; pj[m] = G.j[m] + pl; pv[m] = G.ok[m]; }
+        }
+        LF_TAPGEMM_EPILOGUE
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PREF) A = B;      // (landed during the epilogue)
+        else issue(A);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// tapgemm_bf16_wl_kernel ("whole lines"): the 3-tap bf16 convolutions of non_bottleneck_1d (Cs = Cd = 64 or 128, stride 1).
+//
+// tools/l2_stream.hip measures what bounds every bf16 kernel above (profiles/r4_l2_stream.txt): an instruction whose 64 lanes
+// touch 16 cache lines moves 16 lines' worth of L1 time whatever it uses of them.  The MFMA operand layout -- a lane = 16 bytes of
+// pixel l & 15 -- makes a register load take 64 bytes of each of 16 lines (3 taps of a 52 MB tensor: 26.9 us, 5.9 TB/s; the same
+// bytes as whole lines: 12.5 us, 12.5 TB/s), and the accumulator layout makes the epilogue store 8 bytes per lane, 32 of each
+// line (+17 us for 52 MB against +7 us as whole lines).  All of the above kernels sit at that ~44 us; this one touches memory
+// in whole 128-byte lines only:
+//  * X: LDS-DMA instructions of 8 pixels x 128 bytes (lane -> pixel l >> 3, 16-byte chunk l & 7) into a ring of K-steps of
+//    64 pixels x 64 channels (8 KB); the waves read MFMA fragments from it (chunk XOR (pixel >> 1) & 7 on the SOURCE side
+//    makes the ds_read_b128 lane groups conflict-free);
+//  * output: the epilogue writes bf16 quads into an LDS tile (16-byte chunks XOR pixel), barrier, then every wave stores
+//    1 KB instructions of 4 pixels x 256 bytes (8 x 128 at 64 channels);
+//  * W: NOT in LDS and not in the ring -- the workgroup's 64 pixels are shared by its four waves, each owning a quarter of the
+//    output channels (wave tile 64 pixels x Cd/4), so a wave's weights are 3 taps x Cs x Cd/4 = 24 KB at 128 channels: 96
+//    REGISTERS per lane, loaded once per persistent workgroup, statically indexed by the fully unrolled K loop.  The LDS
+//    is all ring (6 x 8 KB) + output tile (16 KB): two workgroups per CU with 5 K-steps each in flight.
+// Work item = 256 pixels (the BN-statistics row of the other kernels) as four 64-pixel sub-tiles; the ring runs across
+// sub-tiles and items.  K order = tapgemm_bf16_kernel's (tap, then channel): results bit-identical.
+// ---------------------------------------------------------------------------------------
+constexpr int WL_STAGE = 64 * 128;
+template <int CB> struct WlCfg {
+    static constexpr int NT = CB / 2, KS = CB / 2, NSTEP = 3 * KS, STAGES = CB == 4 ? 6 : 8, CD = CB * 32, PIXB = CD * 2;
+    static constexpr int OUT_BYTES = 64 * PIXB;
+    static constexpr size_t LDS = (size_t)STAGES * WL_STAGE + OUT_BYTES;
+};
+
+template <int CB, int EPIC>
+__global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
+    typedef WlCfg<CB> C;
+    constexpr int NT = C::NT, KS = C::KS, NSTEP = C::NSTEP, S = C::STAGES, CD = C::CD, PIXB = C::PIXB, NCH = PIXB / 16;
+    constexpr bool S16 = true;
+    const int epi = EPIC >= 0 ? EPIC : epi_rt;
+    constexpr bool NOBIAS = EPIC >= 0 && (EPIC & (LF_EPI_MASK | LF_EPI_ADD | LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) != 0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pl = lane & 15, kq = lane >> 4;
+    const int cobw = wave * 16 * NT;                        // this wave's output channels
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl), ngroups = npix >> 4, GR = (unsigned)g.Wl >> 4;
+    const unsigned nitems = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
+    unsigned it_first = blockIdx.x, it_stride = gridDim.x, it_end = nitems;
+    if ((gridDim.x & 7u) == 0 && (nitems & 7u) == 0) {
+        const unsigned per = nitems >> 3;
+        it_first = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); it_stride = gridDim.x >> 3; it_end = (blockIdx.x & 7u) * per + per;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lf_tap_lds;
+    unsigned char* const ring = lf_tap_lds;
+    unsigned char* const otile = lf_tap_lds + S * WL_STAGE;
+
+    // ---- this wave's weights -> registers: [tap][32-channel k-block][16-channel output tile], the MFMA A operand
+    bf16x8 wr[3][CB][NT];
+    {
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp16, 0xffffffffu);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int kb = 0; kb < CB; ++kb)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    wr[t][kb][n] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        rw, (int)((((t * CB + kb) * 4 + kq) * CD + cobw + n * 16 + pl) * 16), 0, 0));
+    }
+    // tap t's offsets in lane t, read back with v_readlane (a select chain over three values indexed by the run-time tap becomes an
+    // indexed array in scratch memory -- and the kernel-argument struct with it)
+    int tapv = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (lane == t) tapv = (g.tdh[t] & 0xffff) | (g.tdw[t] << 16);
+    const i32x4s rx = make_rsrc_words(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB));
+    const int spix2 = g.s_pix * 2;
+    // DMA mapping: this wave carries group `wave` of the sub-tile (pixels wave*16 ..+15) as two instructions jj of 8 pixels;
+    // lane -> pixel jj*8 + (lane >> 3), LDS slot lane & 7 = chunk XOR ((pixel >> 1) & 7)
+    const int dpx = lane >> 3;
+    unsigned lane_x[2];
+    int lane_dx[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int chunk = (lane & 7) ^ ((jj * 4 + (lane >> 4)) & 7);
+        lane_x[jj] = (unsigned)(((jj * 8 + dpx) * g.s_pix + g.s_choff) * 2 + chunk * 16);
+        lane_dx[jj] = jj * 8 + dpx;
+    }
+    // ---- load cursor (wave-uniform): item, sub-tile, step; this wave's group of the cursor's sub-tile
+    unsigned it_ld = it_first;
+    int sub_ld = 0, s_ld = 0, st_ld = 0;
+    int lrow = 0, liy = 0, lsx = 0;
+    bool lok = false;
+    auto cursor_sub = [&]() __attribute__((always_inline)) {
+        lok = false;
+        if (it_ld < it_end) {
+            const unsigned G = (it_ld * 4u + (unsigned)sub_ld) * 4u + (unsigned)wave;
+            lok = G < ngroups;
+            const unsigned Gc = lok ? G : 0u;
+            const unsigned R = Gc / GR;
+            const int jg = __builtin_amdgcn_readfirstlane((int)(Gc - R * GR));
+            const int n = __builtin_amdgcn_readfirstlane((int)(R / (unsigned)g.Hl));
+            const int i = __builtin_amdgcn_readfirstlane((int)R) - n * g.Hl;
+            liy = i; lsx = jg * 16;
+            lrow = (n * g.Hs + i) * g.Ws + lsx;
+        }
+    };
+    cursor_sub();
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int t = KS == 1 ? s_ld : s_ld >> 1, ks = KS == 1 ? 0 : s_ld & 1;
+        const int tv = __builtin_amdgcn_readlane(tapv, t);
+        const int dh = (int)(short)(tv & 0xffff), dw = tv >> 16;
+        const int sy = liy + dh;
+        const bool yok = lok && sy >= 0 && sy < g.Hs;
+        const unsigned base = (unsigned)((lrow + dh * g.Ws + dw) * spix2 + ks * 128);
+        const unsigned dst = lds0 + (unsigned)(st_ld * WL_STAGE + wave * 2048);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const bool in = yok && (unsigned)(lsx + dw + lane_dx[jj]) < (unsigned)g.Ws;
+            lds_dma16(rx, dst + (unsigned)jj * 1024u, in ? base + lane_x[jj] : LF_OOB, 0u);
+        }
+        st_ld = st_ld == S - 1 ? 0 : st_ld + 1;
+        if (++s_ld == NSTEP) {
+            s_ld = 0;
+            if (++sub_ld == 4) { sub_ld = 0; it_ld += it_stride; }
+            cursor_sub();
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < S - 1; ++i) issue();
+
+    // epilogue constants
+    const __amdgpu_buffer_rsrc_t r_dst = make_rsrc(a.dst, 0xffffffffu), r_add = make_rsrc(a.add_src, 0xffffffffu),
+                                 r_msk = make_rsrc(a.mask_src, 0xffffffffu), r_aux = make_rsrc(a.aux, 0xffffffffu),
+                                 r_bias = make_rsrc(a.bias, 0xffffffffu), r_msc = make_rsrc(a.msc, 0xffffffffu),
+                                 r_msh = make_rsrc(a.msh, 0xffffffffu), r_dm = make_rsrc(a.dm, 0xffffffffu);
+    // fragment read addresses inside a stage: pixel m*16 + pl (128 B rows), chunk kb*4 + kq XOR (pl >> 1) & 7
+    const unsigned xf0 = (unsigned)(pl * 128 + (((0 + kq) ^ (pl >> 1)) & 7) * 16), xf1 = (unsigned)(pl * 128 + (((4 + kq) ^ (pl >> 1)) & 7) * 16);
+    const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0;
+    int st_c = 0;
+    for (unsigned bx = it_first; bx < it_end; bx += it_stride) {
+        f32x4 s1[NT], s2[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { s1[n] = zero4(); s2[n] = zero4(); }
+        for (int sub = 0; sub < 4; ++sub) {
+            f32x4 acc[NT][MT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                // my DMA of this step has landed (S - 2 younger steps of 2 instructions may be in flight) ...
+                // ... and MY fragment reads of the step before have retired (lgkmcnt): hipcc moves that step's last MFMAs -- and the
+                // waits for their operands -- behind the barrier, and the stage is restaged right behind it: a DMA instruction whose 8
+                // pixels are all padding returns its zeros without a memory round trip and overtook those reads (wrong tiles in 1 of
+                // 3 launches at dilation 8, row width 80)
+                if constexpr (S == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();        // ... and everyone's; everyone is past the fragment reads of the step before
+                asm volatile("" ::: "memory");
+                issue();                             // S - 1 steps ahead -> the stage the previous step occupied
+                const unsigned char* st = ring + st_c * WL_STAGE;
+                st_c = st_c == S - 1 ? 0 : st_c + 1;
+                const int t = KS == 1 ? s : s >> 1, ks = KS == 1 ? 0 : s & 1;          // (compile-time after unrolling: wr is indexed statically)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8 xb[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(st + (kb ? xf1 : xf0) + m * 2048);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t][ks * 2 + kb][n], xb[m], acc[n][m], 0, 0, 0);
+                }
+            }
+            // ---- epilogue of the sub-tile: accumulator tile (n, m) = channels cobw + n*16 + kq*4 .. +3 of pixel m*16 + pl
+            RingGroups G;
+            groups_at((bx * 4u + (unsigned)sub) * 4u, g.Hl, GR, ngroups, G);
+            f32x4 bs[NOBIAS ? 1 : NT], hsc[NT], hsh[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const unsigned co = (unsigned)(cobw + n * 16 + kq * 4);
+                if constexpr (!NOBIAS) bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4();
+                if (epi & LF_EPI_MASKBN) { hsc[n] = ldb4(r_msc, co * 4u, 0u); hsh[n] = ldb4(r_msh, co * 4u, 0u); }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const unsigned dbase = (unsigned)(((G.n[m] * g.Hd + G.i[m]) * g.Wd + G.j[m] + pl) * g.d_pix + g.d_choff + cobw + kq * 4);
+                f32x4 la[NT], lm[NT], lx[NT], ld[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (epi & LF_EPI_ADD) la[n] = epi_ld<S16>(r_add, dbase + n * 16);
+                    if (epi & LF_EPI_MASK) lm[n] = epi_ld<S16>(r_msk, dbase + n * 16);
+                    if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[n] = epi_ld<S16>(r_aux, dbase + n * 16);
+                    if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[n] = ldb4(r_dm, (unsigned)(G.n[m] * g.Cd + cobw + n * 16 + kq * 4) * 4u, 0u);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 v = acc[n][m];
+                    if constexpr (!NOBIAS) v += bs[n];
+                    if (epi & LF_EPI_ADD) v += la[n];
+                    if (epi & LF_EPI_MASK) v = keep_pos(v, lm[n]);
+                    if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[n] * hsc[n] + hsh[n]);
+                    if (epi & LF_EPI_RELU) v = max0(v);
+                    lf_bf16x4 b;
+                    b[0] = (lf_bf16)v.x; b[1] = (lf_bf16)v.y; b[2] = (lf_bf16)v.z; b[3] = (lf_bf16)v.w;
+                    // output tile: pixel p = m*16 + pl, 16-byte chunk (channel / 8) XOR p, half kq & 1
+                    const int p = m * 16 + pl, chunk = (cobw + n * 16 + kq * 4) >> 3;
+                    *reinterpret_cast<lf_bf16x4*>(otile + p * PIXB + ((chunk ^ p) & (NCH - 1)) * 16 + (kq & 1) * 8) = b;
+                    if (stats) {
+                        v.x = (float)b[0]; v.y = (float)b[1]; v.z = (float)b[2]; v.w = (float)b[3];     // statistics of the values as stored
+                        if (!G.ok[m]) v = zero4();
+                        if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; }
+                        if (epi & LF_EPI_STATS_XHAT) {
+                            const f32x4 gm = a.dm ? v * ld[n] : v;
+                            s1[n] += gm; s2[n] += gm * lx[n];
+                        }
+                    }
+                }
+            }
+            __syncthreads();                          // the output tile is complete (this also drains the ring's loads: they are needed next)
+            // whole-line stores: instruction ii of the tile = bytes ii*1024 .. +1023 of the (pixel-major) tile
+            constexpr int NI = C::OUT_BYTES / 1024 / WG_WAVES;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int ii = wave * NI + k;
+                const int p = (ii * 1024) / PIXB + (lane * 16) / PIXB;            // pixel of the sub-tile
+                const int slot = ((lane * 16) % PIXB) / 16;
+                const int grp = (ii * 1024 / PIXB) >> 4;                          // uniform: an instruction's pixels lie in one group
+                const int gn = grp == 0 ? G.n[0] : grp == 1 ? G.n[1] : grp == 2 ? G.n[2] : G.n[3];
+                const int gi = grp == 0 ? G.i[0] : grp == 1 ? G.i[1] : grp == 2 ? G.i[2] : G.i[3];
+                const int gj = grp == 0 ? G.j[0] : grp == 1 ? G.j[1] : grp == 2 ? G.j[2] : G.j[3];
+                const bool gok = grp == 0 ? G.ok[0] : grp == 1 ? G.ok[1] : grp == 2 ? G.ok[2] : G.ok[3];
+                if (gok) {
+                    const u32x4v v = *reinterpret_cast<const u32x4v*>(otile + ii * 1024 + lane * 16);
+                    const unsigned off = (unsigned)((((gn * g.Hd + gi) * g.Wd + gj + (p & 15)) * g.d_pix + g.d_choff) * 2 + ((slot ^ p) & (NCH - 1)) * 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, r_dst, (int)off, 0, 0);
+                }
+            }
+            // (the next sub-tile's first barrier orders these reads of the output tile before its next writes)
+        }
+        if (stats) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x4 r1, r2;
+                r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w);
+                r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w);
+                if (pl == 0) {
+                    float* d = a.stats + ((long)bx * 2) * g.Cd + cobw + n * 16 + kq * 4;
+                    *reinterpret_cast<f32x4*>(d) = r1;
+                    *reinterpret_cast<f32x4*>(d + g.Cd) = r2;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing (dead) steps: nothing may land in LDS after this
+    __builtin_amdgcn_s_barrier();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1211,7 +1854,8 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
 }
 
 int g_split_any_size = 0;      // kernel-level tests only: let the split kernel take launches below its shipped size rule
-int g_bf16_lds = 1;            // tools / A-B runs only: 0 = the streaming bf16 kernel for the launches the LDS-staged one takes
+int g_bf16_lds = 4;            // tools / A-B runs only: 4 = whole-line kernel where it applies, else the persistent ring; 0 = the streaming bf16 kernel, 1 = the one-tile LDS-staged kernel, 2 = the persistent ring, 3 = register streaming + resident weights
+int g_bf16_ring_nh = 0;        // tools only: 0 = the launcher's choice, 1 / 2 = output-channel slabs of 64 / all 128 channels per workgroup
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -1224,7 +1868,7 @@ int pick_nt(int Cd) {
 }  // namespace
 
 void lf_tapgemm_set_split_any_size(int v) { g_split_any_size = v; }
-void lf_tapgemm_set_bf16_lds(int v) { g_bf16_lds = v; }
+void lf_tapgemm_set_bf16_lds(int v) { g_bf16_lds = v & 7; g_bf16_ring_nh = (v >> 3) & 3; }
 
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
 // workgroups (its two 4-wave groups each own one 256-pixel statistics row), 16-byte aligned pixels
@@ -1272,6 +1916,62 @@ void launch_tapgemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const LfTap
     if (grid.x > res && res >= 8) grid.x = res & ~7u;
     if (g_launch_flags) hipExtLaunchKernelGGL(kernel, grid, dim3(256), (unsigned)lds, st, nullptr, nullptr, g_launch_flags, g, a, pro, epi);
     else hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, g, a, pro, epi);
+}
+// tapgemm_bf16_ring_kernel: persistent, at most the resident workgroups (a multiple of 8: XCD-contiguous item ranges).  NH = 2
+// (all 128 output channels per workgroup) exists for the light epilogues only: beside 128 accumulators the BN-backward-sum
+// epilogues spill (10-46 registers), those launches run as two 64-channel slabs per pixel tile.
+template <int NHV, int EPIV, bool DBGV = false>
+void launch_bf16_ring1(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
+    auto kern = tapgemm_bf16_ring_kernel<NHV, EPIV, DBGV>;
+    const size_t ring_lds = (size_t)LB_STAGES * (LB_X_BYTES + NHV * LB_W_BYTES);
+    static bool attr_set = false;           // dynamic LDS beyond 64 KB needs the attribute, once per instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_set = true;
+    }
+    unsigned gx = nitems;
+    const unsigned res = (unsigned)resident_workgroups(kern, ring_lds);
+    if (gx > res && res >= 8) gx = res & ~7u;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), ring_lds, st, g, a, pro, epi);
+}
+// tapgemm_bf16_stream_kernel: persistent, one output-channel slab per workgroup; the grid is the resident workgroups rounded
+// down to a multiple of 8 (XCDs) x slabs, or fewer when the launch has fewer (tile, slab) items
+template <int CBV, int EPIV>
+void launch_bf16_stream(unsigned ntiles, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
+    auto kern = tapgemm_bf16_stream_kernel<CBV, EPIV>;
+    const size_t lds = (size_t)g.ntaps * CBV * 4096;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_set = true;
+    }
+    const unsigned nslab = (unsigned)g.Cd / 64u, unit = 8u * nslab;
+    const unsigned per = (ntiles + 7u) / 8u;                       // pixel tiles per XCD
+    unsigned gx = per * unit;                                      // one workgroup per (tile, slab) of the largest XCD range
+    const unsigned res = (unsigned)resident_workgroups(kern, lds);
+    if (gx > res && res >= unit) gx = res / unit * unit;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, st, g, a, pro, epi);
+}
+template <int CBV, int EPIV>
+void launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
+    auto kern = tapgemm_bf16_wl_kernel<CBV, EPIV>;
+    const size_t lds = WlCfg<CBV>::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_set = true;
+    }
+    unsigned gx = nitems;
+    const unsigned res = (unsigned)resident_workgroups(kern, lds);
+    if (gx > res && res >= 8) gx = res & ~7u;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, st, g, a, pro, epi);
+}
+template <int EPIV>
+void launch_bf16_ring(int nh, unsigned ntiles, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
+    if constexpr (EPIV >= 0 && (EPIV & LF_EPI_STATS_XHAT) == 0) {
+        if (nh == 2) { launch_bf16_ring1<2, EPIV>(ntiles, st, g, a, pro, epi); return; }
+    }
+    launch_bf16_ring1<1, EPIV>(ntiles * (unsigned)(g.Cd / 64), st, g, a, pro, epi);
 }
 }  // namespace
 
@@ -1368,7 +2068,77 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         // LDS-staged form (three K-steps of operands in flight per wave): every FAST launch whose ring + tap table fit the CU
         const size_t lds_bytes = (size_t)LB_STAGES * LB_STAGE_BYTES + LB_TAB_PER_TAP * g.ntaps;
         const bool use_lds = g_bf16_lds && lds_bytes <= 128 * 1024;
-        if (fast16) {       // the bf16-tensor launches of the network at 64 output channels per workgroup
+        // persistent ring form (tapgemm_bf16_ring_kernel): 16-pixel groups inside one image row, 64 or 128 output channels
+        const bool wl = fast16 && g_bf16_lds == 4 && !a.dbg && g.ntaps == 3 && g.Cs == g.Cd && (g.Cd == 64 || g.Cd == 128) && g.Wl % 16 == 0 &&
+                        g.ssh == 1 && g.ssw == 1 && g.dsh == 1 && g.dsw == 1 && g.dah == 0 && g.daw == 0 && g.Hs == g.Hl && g.Ws == g.Wl &&
+                        g.Hd == g.Hl && g.Wd == g.Wl && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0;
+        if (wl) {
+            const unsigned nitems = (unsigned)lf_cdiv(npix, PIX_PER_WG);
+#define LF_TGW(EPIV) do { if (g.Cs == 128) launch_bf16_wl<4, EPIV>(nitems, st, g, a, pro, epi); else launch_bf16_wl<2, EPIV>(nitems, st, g, a, pro, epi); } while (0)
+            switch (epis) {
+                case 0: LF_TGW(0); break;
+                case LF_EPI_RELU: LF_TGW(LF_EPI_RELU); break;
+                case LF_EPI_MASK: LF_TGW(LF_EPI_MASK); break;
+                case LF_EPI_ADD: LF_TGW(LF_EPI_ADD); break;
+                case LF_EPI_STATS_SQ: LF_TGW(LF_EPI_STATS_SQ); break;
+                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGW(LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGW(LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TGW(LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                default: LF_TGW(-1); break;
+            }
+#undef LF_TGW
+            LF_CHECK_LAUNCH("tapgemm_bf16_wl");
+            return 0;
+        }
+        const bool ring = fast16 && (g_bf16_lds == 2 || g_bf16_lds == 4) && g.Wl % 16 == 0 && (g.Cd == 64 || g.Cd == 128);
+        const bool stream = fast16 && g_bf16_lds == 3 && !a.dbg && g.Wl % 16 == 0 && (g.Cd == 64 || g.Cd == 128) &&
+                            (g.Cs == 64 || g.Cs == 128) && (g.ntaps & 1) && (size_t)g.ntaps * (g.Cs / 32) * 4096 <= 72 * 1024;
+        if (stream) {
+            const unsigned ntiles = (unsigned)lf_cdiv(npix, PIX_PER_WG);
+#define LF_TGS(EPIV) do { if (g.Cs == 128) launch_bf16_stream<4, EPIV>(ntiles, st, g, a, pro, epi); else launch_bf16_stream<2, EPIV>(ntiles, st, g, a, pro, epi); } while (0)
+            switch (epis) {
+                case 0: LF_TGS(0); break;
+                case LF_EPI_RELU: LF_TGS(LF_EPI_RELU); break;
+                case LF_EPI_MASK: LF_TGS(LF_EPI_MASK); break;
+                case LF_EPI_ADD: LF_TGS(LF_EPI_ADD); break;
+                case LF_EPI_STATS_SQ: LF_TGS(LF_EPI_STATS_SQ); break;
+                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGS(LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGS(LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TGS(LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                default: LF_TGS(-1); break;
+            }
+#undef LF_TGS
+        } else
+        if (ring && a.dbg) {        // stamps (tools/kbench.py --phases16): the plain convolution only
+            LF_REQUIRE(epis == 0, "tapgemm bf16 ring: stamps are compiled into the plain convolution only");
+            const unsigned ntiles = (unsigned)lf_cdiv(npix, PIX_PER_WG);
+            if (g.Cd == 128 && g_bf16_ring_nh != 1) launch_bf16_ring1<2, 0, true>(ntiles, st, g, a, pro, epi);
+            else launch_bf16_ring1<1, 0, true>(ntiles * (unsigned)(g.Cd / 64), st, g, a, pro, epi);
+        } else
+        if (ring) {
+            const unsigned ntiles = (unsigned)lf_cdiv(npix, PIX_PER_WG);
+            // NH = 2 (all 128 output channels in one workgroup) once the launch has tiles for every resident workgroup anyway
+            const int nh = g.Cd == 128 && (g_bf16_ring_nh == 2 || (g_bf16_ring_nh == 0 && ntiles >= 768u)) ? 2 : 1;
+#define LF_TGR(EPIV) launch_bf16_ring<EPIV>(nh, ntiles, st, g, a, pro, epi)
+            switch (epis) {
+                case 0: LF_TGR(0); break;
+                case LF_EPI_RELU: LF_TGR(LF_EPI_RELU); break;
+                case LF_EPI_MASK: LF_TGR(LF_EPI_MASK); break;
+                case LF_EPI_ADD: LF_TGR(LF_EPI_ADD); break;
+                case LF_EPI_STATS_SQ: LF_TGR(LF_EPI_STATS_SQ); break;
+                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGR(LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGR(LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TGR(LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                default: LF_TGR(-1); break;
+            }
+#undef LF_TGR
+        } else
+        if (fast16 && a.dbg) {      // phase stamps (tools/kbench.py --phases16): the plain LDS-staged launch only
+            LF_REQUIRE(use_lds && epis == 0, "tapgemm bf16: phase stamps are compiled into the plain LDS-staged convolution only");
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tapgemm_bf16_lds_kernel<0, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            hipLaunchKernelGGL((tapgemm_bf16_lds_kernel<0, true>), grid, dim3(256), lds_bytes, st, g, a, pro, epi);
+        } else if (fast16) {       // the bf16-tensor launches of the network at 64 output channels per workgroup
             switch (epis) {
                 case 0: LF_TG16F(0); break;
                 case LF_EPI_RELU: LF_TG16F(LF_EPI_RELU); break;

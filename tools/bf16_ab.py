@@ -37,7 +37,8 @@ def main():
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     # (N, C, H, W, axis, dil): the headline geometry at batch 32 and config 3's (320 x 640, batch 64), a ragged one
     shapes = [(32, 128, 32, 64, 0, 4), (32, 128, 32, 64, 1, 16), (32, 64, 64, 128, 0, 1), (32, 64, 64, 128, 1, 1),
-              (64, 128, 40, 80, 1, 8), (64, 64, 80, 160, 0, 1), (3, 64, 6, 20, 1, 2)]
+              (64, 128, 40, 80, 1, 8), (64, 128, 40, 80, 0, 4), (64, 64, 80, 160, 0, 1), (64, 64, 80, 160, 1, 1), (3, 64, 6, 20, 1, 2),
+              (3, 128, 5, 48, 0, 2), (2, 64, 3, 16, 1, 1)]
     lib.lf_debug_set_ops_precision(2)
     try:
         for N, C, H, W, axis, d in shapes:
@@ -48,22 +49,27 @@ def main():
             b = torch.randn(C, device="cuda")
             scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096, device="cuda")
             res, tim = {}, {}
-            for mode in (0, 1):
+            # lf_debug_set_bf16_lds: bits 0-2 = 0 streaming / 1 one-tile LDS ring / 2 persistent ring / 3 register streaming / 4 whole lines; bits 3-4 = the persistent
+            # ring's output channels per workgroup (0 launcher's choice, 1 = 64-channel slabs, 2 = all 128)
+            modes = [("streaming", 0), ("LDS", 1), ("ring64", 2 | 1 << 3)] + ([("ring128", 2 | 2 << 3)] if C == 128 else []) + [("stream2", 3), ("whole-line", 4)]
+            for name, mode in modes:
                 lib.lf_debug_set_bf16_lds(mode)
                 y, gx = torch.empty_like(x), torch.empty_like(x)
                 f = lambda: _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 1, P(scratch), st), "fwd")
                 g = lambda: _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), P(x), P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
-                tim[mode] = (timeit(f, a.iters), timeit(g, a.iters))
-                res[mode] = (y.clone(), gx.clone())
-            same = torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+                tim[name] = (timeit(f, a.iters), timeit(g, a.iters))
+                res[name] = (y.clone(), gx.clone())
+            same = all(torch.equal(res["streaming"][0], r[0]) and torch.equal(res["streaming"][1], r[1]) for r in res.values())
             nbytes = 2 * N * H * W * C * 2
-            print("N=%2d C=%3d %3dx%3d axis %d dil %2d | streaming fwd %6.1f dgrad %6.1f us | LDS-staged fwd %6.1f dgrad %6.1f us | "
-                  "bit-identical %s | LDS fwd %.2f TB/s algorithmic (launch + pack included)"
-                  % (N, C, H, W, axis, d, tim[0][0], tim[0][1], tim[1][0], tim[1][1], same, nbytes / tim[1][0] / 1e6), flush=True)
-            assert torch.isfinite(res[1][0].float()).all()
+            best = min(t[0] for t in tim.values())
+            print("N=%2d C=%3d %3dx%3d axis %d dil %2d | %s | bit-identical %s | best fwd %.2f TB/s algorithmic (launch + pack included)"
+                  % (N, C, H, W, axis, d, " | ".join("%s fwd %6.1f dgrad %6.1f us" % (k, v[0], v[1]) for k, v in tim.items()), same,
+                     nbytes / best / 1e6), flush=True)
+            for r in res.values():
+                assert torch.isfinite(r[0].float()).all()
     finally:
         lib.lf_debug_set_ops_precision(0)
-        lib.lf_debug_set_bf16_lds(1)
+        lib.lf_debug_set_bf16_lds(4)
 
 
 if __name__ == "__main__":

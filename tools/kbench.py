@@ -119,7 +119,7 @@ def main():
                      flops / td / 1e12, e2, tw * 1e6, flops / tw / 1e12, e3, e4), flush=True)
 
 
-if __name__ == "__main__" and "--phases" not in sys.argv:
+if __name__ == "__main__" and "--phases" not in sys.argv and "--phases16" not in sys.argv:
     main()
 
 
@@ -202,6 +202,61 @@ def wgrad_phases(batch=32, shapes=((128, 32, 64, 1, 16), (64, 64, 128, 1, 1))):
                                                      (t[:, 2] - t0).min(), (t[:, 2] - t0).max(), (t[:, 3] - t0).mean(), (t[:, 3] - t0).max()), flush=True)
         _simd_report(t, hw, t0)
 
+
+def phases16(shapes=((32, 128, 32, 64, 1, 16), (64, 128, 40, 80, 1, 8), (32, 64, 64, 128, 1, 1), (64, 64, 80, 160, 0, 1))):
+    """Per-wave stamps of the persistent bf16 ring kernel (tapgemm_bf16_ring_kernel): when each workgroup started and, per work
+    item, when its K loop was done and when its epilogue's stores had retired."""
+    import numpy as np
+    lib = _lib.load()
+    lib.lf_debug_set_ops_precision(2)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        for N, C, H, W, axis, d in shapes:
+            for nh in ((1, 2) if C == 128 else (1,)):
+                lib.lf_debug_set_bf16_lds(2 | nh << 3)
+                x = torch.randn(N, H, W, C, device="cuda").bfloat16()
+                w = torch.randn(C, C, 3, device="cuda") * 0.05
+                b = torch.randn(C, device="cuda")
+                y = torch.empty_like(x)
+                scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096, device="cuda")
+                nw = 4096 * 4
+                dbg = torch.zeros(nw * 16, dtype=torch.int64, device="cuda")
+                f = lambda: _lib.check(lib.lf_debug_conv1d_fwd_phases(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, P(scratch), P(dbg), st), "phases16")
+                us = timeit(f, 200) * 1e6
+                dbg.zero_()
+                f()
+                torch.cuda.synchronize()
+                t = dbg.cpu().numpy().reshape(nw, 16)
+                t = t[t[:, 0] > 0]
+                hw = t[:, 1]
+                T = t[:, [0] + list(range(2, 16))].astype(np.float64) * 0.01
+                t0 = T[:, 0].min()
+                T = np.where(T > 0, T - t0, np.nan)
+                nit = (~np.isnan(T[:, 1::2])).sum(1)
+                print("bf16 ring N=%2d C=%3d %3dx%3d axis %d dil %2d, %d output channels per workgroup | launch+pack %6.1f us | waves %d | kernel span %.2f us | "
+                      "items per workgroup %s" % (N, C, H, W, axis, d, 64 * nh, us, len(T), np.nanmax(T), np.bincount(nit).tolist()))
+                loop = T[:, 1::2] - np.concatenate([T[:, :1], T[:, 2:-1:2]], 1)       # K loop of item k: from the previous epilogue's end (or the start)
+                epi = T[:, 2::2] - T[:, 1::2]
+                for k in range(min(4, int(nit.max()))):
+                    print("     item %d: K loop (incl. the wait for its first operands) %.2f us (p10 %.2f p90 %.2f) | epilogue + stores retired %.2f us (p10 %.2f p90 %.2f)"
+                          % (k, np.nanmean(loop[:, k]), np.nanpercentile(loop[:, k], 10), np.nanpercentile(loop[:, k], 90),
+                             np.nanmean(epi[:, k]), np.nanpercentile(epi[:, k], 10), np.nanpercentile(epi[:, k], 90)))
+                key = ((hw >> 32) & 15) * 65536 + ((hw >> 8) & 15) * 4 + ((hw >> 12) & 0xf) * 64          # CU
+                cus = {}
+                for i, k in enumerate(key):
+                    cus.setdefault(int(k), []).append(T[i])
+                print("     CUs used %d, waves per CU %s" % (len(cus), np.bincount([len(v) for v in cus.values()]).tolist()))
+                k0 = sorted(cus)[len(cus) // 2]
+                for v in sorted(cus[k0], key=lambda v: v[0])[::4]:
+                    print("     CU %06x workgroup: %s" % (k0, " ".join("%.1f" % q for q in v if not np.isnan(q))))
+    finally:
+        lib.lf_debug_set_ops_precision(0)
+        lib.lf_debug_set_bf16_lds(4)
+
+
+if __name__ == "__main__" and "--phases16" in sys.argv:
+    phases16()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--phases" in sys.argv:
     sp = int(sys.argv[sys.argv.index("--split") + 1]) if "--split" in sys.argv else 0
