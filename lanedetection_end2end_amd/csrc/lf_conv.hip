@@ -1476,6 +1476,89 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
 }
 
 // ---------------------------------------------------------------------------------------
+// tapgemm_bf16_lean_kernel: the 16 -> 16 channel 3-tap convolutions on bf16 tensors (decoder, full-resolution stage: HBM-bound,
+// a pixel is 32 bytes).  The general bf16 kernel ran them in its run-time-flag form, one 32-channel K-step per tap with half
+// of every operand register zero padding and one step in flight (101 us per launch at 160 x 320 x 64 images, 2.1 TB/s).  Here
+//  * one MFMA contracts TWO taps: k-blocks 0-1 of the K = 32 step are tap 2i's 16 channels, k-blocks 2-3 tap 2i+1's -- a lane's
+//    16-byte load is half a pixel at the tap its k-block belongs to, an instruction covers 2 x 16 consecutive pixels x 32 B
+//    (whole lines); the three taps are 2 MFMAs per 16 x 16 tile, all 8 loads of a wave requested up front;
+//  * prologue and epilogue flags compiled in, (image, row) of the 16-pixel groups in scalar registers (Wl % 16 == 0).
+// The chain order (tap 0 + tap 1 in one K = 32 dot product, then tap 2) differs from tapgemm_bf16_kernel's three K-steps:
+// results agree to fp32 rounding, not bit for bit.
+// ---------------------------------------------------------------------------------------
+template <int PROC, int EPIC>
+__global__ __launch_bounds__(256, 4) void tapgemm_bf16_lean_kernel(const LfTapGeom g, const LfTapArgs a, const int pro_rt, const int epi_rt) {
+    constexpr int NT = 1;
+    constexpr bool S16 = true, HOISTV = EPIC >= 0;
+    const int epi = EPIC >= 0 ? EPIC : epi_rt;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pl = lane & 15, kq = lane >> 4;
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl), ngroups = npix >> 4, GR = (unsigned)g.Wl >> 4;
+    const int cob = 0;
+    unsigned bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    RingGroups G;
+    ring_groups(bx, wave, g.Hl, GR, ngroups, G);
+    const int hi = kq >> 1, c8 = (kq & 1) * 8;              // which tap of the pair, which half of the pixel
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp16, 0xffffffffu),
+                                 rx = make_rsrc(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB));
+    // weights: packed [tap][4 k-blocks of 8 channels (2 real, 2 zero)][Cd][8]; MFMA i, lane (pl, kq): tap 2i + hi, k-block kq & 1
+    bf16x8 wb[2];
+    wb[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)((((hi ? 1 : 0) * 4 + (kq & 1)) * g.Cd + pl) * 16), 0, 0));
+    {
+        u32x4v w2 = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(((2 * 4 + (kq & 1)) * g.Cd + pl) * 16), 0, 0);
+        if (hi) { w2[0] = 0u; w2[1] = 0u; w2[2] = 0u; w2[3] = 0u; }       // there is no fourth tap
+        wb[1] = __builtin_bit_cast(bf16x8, w2);
+    }
+    (void)pro_rt;
+    u32x4v xr[2][MT];
+    bool in[2][MT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int dh = i == 0 ? (hi ? g.tdh[1] : g.tdh[0]) : g.tdh[2], dw = i == 0 ? (hi ? g.tdw[1] : g.tdw[0]) : g.tdw[2];
+        const bool tapok = i == 0 || !hi;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int sy = G.i[m] * g.ssh + dh, sx = (G.j[m] + pl) * g.ssw + dw;
+            in[i][m] = tapok && G.ok[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            const unsigned off = (unsigned)((((G.n[m] * g.Hs + sy) * g.Ws + sx) * g.s_pix + g.s_choff + c8) * 2);
+            xr[i][m] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(in[i][m] ? off : LF_OOB), 0, 0);
+        }
+    }
+    f32x4 sc0, sc1, sh0, sh1;
+    if constexpr (PROC == LF_PRO_BNRELU) {
+        sc0 = ldg4(a.pro_sc + c8); sc1 = ldg4(a.pro_sc + c8 + 4);
+        sh0 = ldg4(a.pro_sh + c8); sh1 = ldg4(a.pro_sh + c8 + 4);
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            bf16x8 xb;
+            if constexpr (PROC == LF_PRO_BNRELU) {          // relu(bn(x)) in fp32 on the widened values; padding is zero AFTER the transform
+                const u32x4v r = xr[i][m];
+                f32x4 lo, hv;
+                lo.x = __uint_as_float(r[0] << 16); lo.y = __uint_as_float(r[0] & 0xffff0000u);
+                lo.z = __uint_as_float(r[1] << 16); lo.w = __uint_as_float(r[1] & 0xffff0000u);
+                hv.x = __uint_as_float(r[2] << 16); hv.y = __uint_as_float(r[2] & 0xffff0000u);
+                hv.z = __uint_as_float(r[3] << 16); hv.w = __uint_as_float(r[3] & 0xffff0000u);
+                lo = max0(lo * sc0 + sh0); hv = max0(hv * sc1 + sh1);
+                const bool ok = in[i][m];
+                lo.x = ok ? lo.x : 0.f; lo.y = ok ? lo.y : 0.f; lo.z = ok ? lo.z : 0.f; lo.w = ok ? lo.w : 0.f;
+                hv.x = ok ? hv.x : 0.f; hv.y = ok ? hv.y : 0.f; hv.z = ok ? hv.z : 0.f; hv.w = ok ? hv.w : 0.f;
+                xb = cvt_bf16x8(lo, hv);
+            } else xb = __builtin_bit_cast(bf16x8, xr[i][m]);
+            acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], xb, i ? acc[0][m] : zero4(), 0, 0, 0);
+        }
+    int pn[MT], pi[MT], pj[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { pn[m] = G.n[m]; pi[m] = G.i[m]; pj[m] = G.j[m] + pl; pv[m] = G.ok[m]; }
+    LF_TAPGEMM_EPILOGUE
+}
+
+// ---------------------------------------------------------------------------------------
 // fp32 ON THE bf16 MATRIX CORES ("split" mode, LfTapArgs::split = 9 or 6).  gfx950 multiplies bf16 16x faster
 // than fp32 (v_mfma_f32_16x16x32_bf16: 16 cycles for K = 32; v_mfma_f32_16x16x4_f32: 8 x 32 cycles for the same K),
 // so an fp32 product is formed from bf16 pieces instead: every fp32 operand is split EXACTLY into three bf16 values
@@ -2063,6 +2146,26 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         } else                                                                                                           \
             hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 0, true, EPIV, true>), grid, dim3(256), 0, st, g, a, pro, epi);   \
     } while (0)
+        // the 16 -> 16 channel 3-tap convolutions on bf16 tensors: tapgemm_bf16_lean_kernel
+        if (a.s16 && g_bf16_lds == 4 && !a.dbg && g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0 && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 &&
+            (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB) {
+#define LF_TGL(EPIV) do { if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_lean_kernel<1, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi); \
+                          else hipLaunchKernelGGL((tapgemm_bf16_lean_kernel<0, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi); } while (0)
+            switch (epis) {
+                case 0: LF_TGL(0); break;
+                case LF_EPI_RELU: LF_TGL(LF_EPI_RELU); break;
+                case LF_EPI_MASK: LF_TGL(LF_EPI_MASK); break;
+                case LF_EPI_ADD: LF_TGL(LF_EPI_ADD); break;
+                case LF_EPI_STATS_SQ: LF_TGL(LF_EPI_STATS_SQ); break;
+                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGL(LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGL(LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TGL(LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                default: LF_TGL(-1); break;
+            }
+#undef LF_TGL
+            LF_CHECK_LAUNCH("tapgemm_bf16_lean");
+            return 0;
+        }
         const bool fast16 = nt == 4 && a.s16 && pro != LF_PRO_BNRELU && g.Cs % 32 == 0 &&
                             (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB;
         // LDS-staged form (three K-steps of operands in flight per wave): every FAST launch whose ring + tap table fit the CU

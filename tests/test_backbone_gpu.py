@@ -729,8 +729,12 @@ def test_bf16_tensor_mode_kernel_parity():
         lib.lf_debug_set_ops_precision(2)
         # (.., 6, 20, ..) and (.., 3, 12, ..): widths that are not multiples of 16 take the one-pixel-group weight-gradient
         # path (widened loads, fp32 matrix cores) and partial pixel tiles in the forward / data gradient
+        # (128, 40, 80, ..) / (64, 20, 48, ..) / (16, 20, 48, ..): row widths that are multiples of 16 but not of 64 -- the whole-line and
+        # 16-channel kernels' 16-pixel groups straddle image rows, a padding tap can empty a whole DMA instruction, the last work
+        # item is partial (9600 / 2880 pixels)
         for (C, H, W, axis, d) in ((128, 16, 32, 0, 4), (64, 24, 40, 1, 2), (16, 32, 64, 1, 1), (16, 32, 64, 0, 1),
-                                   (64, 6, 20, 1, 2), (128, 3, 12, 0, 1)):
+                                   (64, 6, 20, 1, 2), (128, 3, 12, 0, 1), (128, 40, 80, 1, 8), (128, 40, 80, 0, 16), (64, 20, 48, 0, 2),
+                                   (64, 20, 48, 1, 16), (16, 20, 48, 1, 2)):
             N = 3
             torch.manual_seed(C + axis)
             x = torch.randn(N, H, W, C, device="cuda").bfloat16()
