@@ -664,35 +664,23 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 }
 
 // ---------------------------------------------------------------------------------------
-// bf16 tensors, LDS-staged (round 4): the launches of precision mode "bf16" without an operand prologue, whole 32-channel
-// K-steps, 64-output-channel slabs (the FAST launches of tapgemm_bf16_kernel above).
-//
-// Why: at the bf16 rate a wave's whole contraction is ~1.3 us of matrix work (12 K-steps x 16 MFMAs x 16 cycles at 128
-// channels) behind 12 dependent round trips to L2: the streaming kernel -- one K-step of loads in flight per wave, in
-// registers -- is latency-bound (34 us per 128-channel launch at batch 32 where the bytes take 6 us; 7 % of the bf16 MFMA
-// roof, 24 % of the HBM roof: VERDICT round 3, Weak #4).  Here the operands of THREE K-steps are in flight per wave without
-// costing a register: `buffer_load_dwordx4 ... lds` (LDS-DMA) writes them straight into a ring of LDS stages, the weights once
-// per workgroup instead of once per wave, and the waves read MFMA fragments with conflict-free ds_read_b128.
-//
-// Stage (20 KB) = X [wave 4][pixel 64][slot 4][16 B] + W [k-block 4][cout 64][16 B]; 3 stages + the tap table (4 KB per tap)
-// = 72 KB for a 3-tap conv: two workgroups per CU, ~80 KB of operands in flight per CU.
-//  * X: DMA instruction j of wave w carries pixels w*64 + j*16 + (lane >> 2), 16 bytes (8 channels) per lane, lane-linear in
-//    LDS (that is what LDS-DMA does); a pixel's four 16-byte slots are XOR-swizzled by (pixel >> 2) & 3 -- applied to the
-//    SOURCE channel block of the lane -- so that the fragment read of 8 consecutive lanes (8 pixels x one slot) touches 8
-//    different bank groups.  A padding tap position carries the out-of-range offset: the DMA writes zeros.
-//  * W: the packed bf16 weights [tap][k-block][Cd][8] make a (tap, 32-channel) step's 64-channel slab four 1 KB runs: one DMA
-//    instruction per wave, fragment reads contiguous.
-//  * One workgroup barrier per K-step: wait for my own DMA of step s (vmcnt: two younger steps may stay in flight), barrier
-//    (everyone's part of step s has landed, everyone has finished reading stage s - 1), issue the DMA of step s + 2 into the
-//    stage just freed, read fragments, 16 MFMAs.  The barrier is the bare s_barrier: __syncthreads() carries a release
-//    fence that drains vmcnt to 0 -- i.e. the whole ring -- every step.
-// Tile, pixel mapping, tap table and the epilogue (LF_TAPGEMM_EPILOGUE) are those of tapgemm_bf16_kernel.
+// bf16 tensors through LDS (round 4): the launches of precision mode "bf16" without an operand prologue.  Two kernels,
+// tapgemm_bf16_ring_kernel (any tap table; 32-channel K-steps) and tapgemm_bf16_wl_kernel (the 3-tap convolutions, whole
+// 128-byte lines), share the machinery below: operands travel by `buffer_load_dwordx4 ... lds` (LDS-DMA: no register is held
+// while the load is in flight) into a ring of LDS stages; the ring is ordered by hand --
+//     s_waitcnt vmcnt(N) lgkmcnt(0)   my DMA of this step has landed (N instructions of younger steps may be in flight) and my
+//                                     fragment reads of the step before have retired
+//     s_barrier                       ... everyone's
+//     issue the step that is R - 1 ahead into the stage the previous step occupied; read fragments; MFMAs
+// -- with the bare s_barrier, because __syncthreads() carries a release fence that drains vmcnt to 0, i.e. the whole ring, every
+// step.  The lgkmcnt(0) is not optional: hipcc moves a step's last MFMAs, and the waits for their operands, behind the next
+// barrier, and a DMA instruction whose pixels are all padding returns its zeros without a memory round trip and overtakes those
+// reads (wrong tiles in one launch of three at dilation 8 and row width 80 before the wait was there).
 // ---------------------------------------------------------------------------------------
 constexpr int LB_STAGES = 3;
 constexpr int LB_X_BYTES = WG_WAVES * 64 * 64;          // 16 KB
 constexpr int LB_W_BYTES = 4 * 64 * 16;                 // 4 KB
 constexpr int LB_STAGE_BYTES = LB_X_BYTES + LB_W_BYTES;
-constexpr size_t LB_TAB_PER_TAP = (size_t)WG_WAVES * 64 * sizeof(uint4);
 
 // One LDS-DMA instruction: 64 lanes x 16 bytes, lane-linear at LDS byte address `lds_addr` (wave-uniform, through M0).
 // Inline asm on purpose: with the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc tracks the asynchronous LDS writes and
@@ -715,160 +703,27 @@ __device__ __forceinline__ i32x4s make_rsrc_words(const void* base, unsigned byt
     return r;
 }
 
-template <int EPIC, bool DBG = false>
-__global__ __launch_bounds__(256, 2) void tapgemm_bf16_lds_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
-    constexpr int NT = 4;
-    unsigned long long tstamp[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-    if constexpr (DBG) tstamp[0] = __builtin_amdgcn_s_memrealtime();
-    constexpr bool S16 = true, HOISTV = true;
-    const int epi = EPIC >= 0 ? EPIC : epi_rt;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int pl = lane & 15, kq = lane >> 4;
-    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
-    const int cob = blockIdx.y * NT * 16;
-    unsigned bx = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
-    const unsigned tile0 = (bx * WG_WAVES + wave) * (MT * 16);
-    unsigned char* const stages = lf_tap_lds;
-    uint4* const tab = reinterpret_cast<uint4*>(lf_tap_lds + LB_STAGES * LB_STAGE_BYTES) + wave * g.ntaps * 64;
-
-    // ---- tap table of the DMA mapping: instruction j, this lane -> pixel tile0 + j*16 + (lane >> 2), channel block
-    // (lane & 3) ^ ((lane >> 4) & 3) of the 32-channel step; byte offsets, LF_OOB where the tap leaves the image
-    {
-        const int dq = lane >> 2, dkq = (lane & 3) ^ ((lane >> 4) & 3);
-        int dn[4], di[4], dj[4];
-        bool dv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned p = tile0 + j * 16 + dq;
-            dv[j] = p < npix;
-            const unsigned q = dv[j] ? p : 0u;
-            const unsigned r = q / (unsigned)g.Wl;
-            dj[j] = (int)(q - r * (unsigned)g.Wl);
-            dn[j] = (int)(r / (unsigned)g.Hl);
-            di[j] = (int)(r - (unsigned)dn[j] * (unsigned)g.Hl);
-        }
-        for (int t = 0; t < g.ntaps; ++t) {
-            const int dh = g.tdh[t], dw = g.tdw[t];
-            unsigned o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sy = di[j] * g.ssh + dh, sx = dj[j] * g.ssw + dw;
-                const bool in = dv[j] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-                o[j] = in ? (unsigned)(((dn[j] * g.Hs + sy) * g.Ws + sx) * g.s_pix + g.s_choff + dkq * 8) * 2u : LF_OOB;
-            }
-            tab[t * 64 + lane] = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-        // (each lane reads back only what it wrote: no barrier needed)
-    }
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
-
-    const int ncb = g.Cs >> 5;
-    const int nsteps = g.ntaps * ncb;
-    const i32x4s rx = make_rsrc_words(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB)),
-                 rw = make_rsrc_words(a.wp16, 0xffffffffu);
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lf_tap_lds;
-    // W: wave w carries k-block w of the step: 64 output channels x 16 bytes, lane = channel
-    const unsigned wvoff = (unsigned)((wave * g.Cd + cob + lane) * 16);
-    const int wstep = g.Cd * 64;                               // bytes per 32-channel step (4 k-blocks x Cd x 16)
-    int t_ld = 0, cb_ld = 0, s_ld = 0, wofs = 0;
-    auto issue = [&]() {                                     // DMA of step s_ld into stage s_ld % LB_STAGES (wave-uniform state)
-        const unsigned st = lds0 + (unsigned)((s_ld % LB_STAGES) * LB_STAGE_BYTES);
-        const uint4 o = tab[t_ld * 64 + lane];
-        const unsigned cs = (unsigned)cb_ld * 64u;          // bytes: the 32-channel step inside the pixel
-        const unsigned xs = st + (unsigned)wave * 4096u;
-        lds_dma16(rx, xs, o.x, cs);
-        lds_dma16(rx, xs + 1024u, o.y, cs);
-        lds_dma16(rx, xs + 2048u, o.z, cs);
-        lds_dma16(rx, xs + 3072u, o.w, cs);
-        lds_dma16(rw, st + (unsigned)(LB_X_BYTES + wave * 1024), wvoff, (unsigned)wofs);
-        // advance; past the end the last live step is issued again (valid addresses, a stage nobody reads)
-        ++s_ld;
-        if (s_ld < nsteps) {
-            wofs += wstep;
-            if (++cb_ld == ncb) { cb_ld = 0; ++t_ld; }
-        }
-    };
-    issue();
-    issue();
-    if constexpr (DBG) tstamp[1] = __builtin_amdgcn_s_memrealtime();
-    // fragment addresses (bytes inside a stage)
-    const unsigned xfrag = (unsigned)(wave * 4096 + pl * 64 + ((kq ^ (pl >> 2)) & 3) * 16);       // + m * 1024
-    const unsigned wfrag = (unsigned)(LB_X_BYTES + (kq * 64 + pl) * 16);                           // + n * 256
-    for (int s = 0; s < nsteps; ++s) {
-        // my DMA of step s has landed (the 5 instructions of step s + 1 may still be in flight) ...
-        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();        // ... and everyone's; everyone is past the fragment reads of step s - 1
-        asm volatile("" ::: "memory");
-        if constexpr (DBG) { if (s == 0) tstamp[2] = __builtin_amdgcn_s_memrealtime(); }
-        issue();                             // step s + 2 -> the stage step s - 1 occupied
-        const unsigned char* st = stages + (s % LB_STAGES) * LB_STAGE_BYTES;
-        bf16x8 wb[NT], xb[MT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) wb[n] = *reinterpret_cast<const bf16x8*>(st + wfrag + n * 256);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(st + xfrag + m * 1024);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[n], xb[m], acc[n][m], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two trailing (dead) steps: nothing may land in LDS after this
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if constexpr (DBG) { asm volatile("" ::"v"(acc[0][0][0])); tstamp[3] = __builtin_amdgcn_s_memrealtime(); }
-
-    // ---- epilogue: the accumulator layout of tapgemm_bf16_kernel (tile m: pixel m*16 + pl; rows 4*kq + e of tile n)
-    int pn[MT], pi[MT], pj[MT];
-    bool pv[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const unsigned p = tile0 + m * 16 + pl;
-        pv[m] = p < npix;
-        const unsigned q = pv[m] ? p : 0u;
-        const unsigned r = q / (unsigned)g.Wl;
-        pj[m] = (int)(q - r * (unsigned)g.Wl);
-        pn[m] = (int)(r / (unsigned)g.Hl);
-        pi[m] = (int)(r - (unsigned)pn[m] * (unsigned)g.Hl);
-    }
-    LF_TAPGEMM_EPILOGUE
-    if constexpr (DBG) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tstamp[4] = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0 && a.dbg) {
-            unsigned long long* d = a.dbg + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * WG_WAVES + wave) * 8;
-            d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3]; d[5] = tstamp[4];
-            unsigned hwid, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
-// tapgemm_bf16_ring_kernel: the LDS-staged bf16 tap-GEMM as a PERSISTENT workgroup whose DMA ring runs across tiles.
+// tapgemm_bf16_ring_kernel: LDS-staged bf16 tap-GEMM for ANY tap table (the 9-tap stride-2 convolution, the transposed-convolution
+// phases, their gradients; the 3-tap convolutions go to tapgemm_bf16_wl_kernel), 64-output-channel slabs, 32-channel K-steps.
 //
-// Why (tools/kbench.py --phases16, profiles/r4_bf16_phases.txt): a workgroup of tapgemm_bf16_lds_kernel lives 13 us at 128
-// channels -- 2.7 us building the per-lane tap table (eight 32-bit divisions and ~500 VALU instructions per wave, two waves
-// per SIMD doing it at the same time), 7.2 us in the K loop (12 steps of 0.11 us matrix work each: the loop waits for the ring,
-// 2 workgroups x 2 steps x 20 KB in flight per CU), 2.8 us in the epilogue -- and the memory pipe idles through the first and
-// the last of the three.  Here
-//  * a workgroup walks its work items (pixel tile x output-channel slab) and its load cursor runs two K-steps ahead of the
-//    compute cursor ACROSS item boundaries: the first operands of the next item land while this item's epilogue stores;
-//  * no tap table: the launcher admits geometries whose 16-pixel groups lie in one image row (Wl % 16 == 0), so a DMA
+// Stage (20 KB) = X [wave 4][pixel 64][slot 4][16 B] + W [k-block 4][cout 64][16 B], 3 stages: two workgroups per CU.
+//  * X: DMA instruction m of wave w carries pixels w*64 + m*16 + (lane >> 2), 16 bytes (8 channels) per lane, lane-linear in LDS
+//    (that is what LDS-DMA does); a pixel's four 16-byte slots are XOR-swizzled by (pixel >> 2) & 3 -- applied to the SOURCE channel
+//    block of the lane -- so that the fragment read of 8 consecutive lanes touches 8 different bank groups.  A padding tap
+//    position carries the out-of-range offset: the DMA writes zeros.
+//  * W: the packed bf16 weights [tap][k-block][Cd][8] make a (tap, 32-channel) step's 64-channel slab four 1 KB runs: one DMA
+//    instruction per wave, fragment reads contiguous.
+//  * PERSISTENT: a workgroup walks its work items (pixel tile x output-channel slab) and its load cursor runs two K-steps ahead
+//    of the compute cursor ACROSS item boundaries: the first operands of the next item land while this item's epilogue stores
+//    (the one-tile form of this kernel spent 2.7 of its 13 us building a per-lane tap table and 2.8 in the epilogue with the
+//    memory pipe idle: profiles/r4_bf16_phases_one_tile.txt).
+//  * No tap table: the launcher admits geometries whose 16-pixel groups lie in one image row (Wl % 16 == 0), so a DMA
 //    instruction's 16 pixels share (image, row) -- wave-uniform, scalar registers: ONE division pair per wave and item -- and a
 //    lane's byte offset is a scalar base plus a per-lane constant, with the column test (one unsigned compare) selecting the
-//    out-of-range offset for padding;
-//  * NH = 2: the workgroup owns all 128 output channels of its pixels (32 accumulator tiles per wave), so X goes through the
-//    ring once per tap instead of once per tap and slab; the stage grows by the second slab's weights (24 KB, 3 stages = 72 KB,
-//    still two workgroups per CU).
-// Stage layout, swizzle, barrier protocol and K order are those of tapgemm_bf16_lds_kernel (results bit-identical).
+//    out-of-range offset for padding.
+// K order = tapgemm_bf16_kernel's: results bit-identical (tools/bf16_ab.py).  (A form owning all 128 output channels per
+// workgroup -- X through the ring once per tap -- and the one-tile form are in DESIGN.md section 9.)
 // ---------------------------------------------------------------------------------------
 struct RingGroups { int n[4], i[4], j[4]; bool ok[4]; };
 // the four consecutive 16-pixel groups from group index G0 on: (image, row, first column), all wave-uniform
@@ -891,9 +746,9 @@ __device__ __forceinline__ void ring_groups(unsigned tile, int wave, int Hl, uns
 }
 
 // DBG: per-wave stamps, 16 x uint64 per wave: start, hardware id, then (K loop done, epilogue stores retired) per item, 7 items
-template <int NH, int EPIC, bool DBG = false>
+template <int EPIC, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
-    constexpr bool S16 = true, HOISTV = NH == 1;
+    constexpr bool S16 = true, HOISTV = true;
     unsigned long long* dbgp = nullptr;
     int dbgk = 0;
     if constexpr (DBG) {
@@ -906,13 +761,13 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
             dbgp[1] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
         }
     }
-    constexpr int STAGE = LB_X_BYTES + NH * LB_W_BYTES;
+    constexpr int STAGE = LB_STAGE_BYTES;
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int pl = lane & 15, kq = lane >> 4;
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl), ngroups = npix >> 4, GR = (unsigned)g.Wl >> 4;
     const unsigned ntiles = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
-    const int slsh = (g.Cd / (64 * NH)) > 1 ? 1 : 0;              // output-channel slabs per pixel tile: 1 or 2
+    const int slsh = g.Cd > 64 ? 1 : 0;                           // output-channel slabs per pixel tile: 1 or 2
     const unsigned nitems = ntiles << slsh;
     // work items first, first + stride, ... inside this XCD's contiguous range (see tapgemm_kernel)
     unsigned it_first = blockIdx.x, it_stride = gridDim.x, it_end = nitems;
@@ -958,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
                 lrow[m] = (G.n[m] * g.Hs + liy[m]) * g.Ws + lsx[m];
                 lok |= G.ok[m] ? 1u << m : 0u;
             }
-            cob_ld = (int)(it_ld & (unsigned)slsh) * 64 * NH;
+            cob_ld = (int)(it_ld & (unsigned)slsh) * 64;
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) { liy[m] = 0; lsx[m] = 0; lrow[m] = 0; }
@@ -979,9 +834,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
             const bool in = yok && (unsigned)(lsx[m] + dw + lane_dx) < (unsigned)g.Ws;
             lds_dma16(rx, xs + (unsigned)m * 1024u, in ? base + lane_x : LF_OOB, 0u);
         }
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-            lds_dma16(rw, st + (unsigned)(LB_X_BYTES + (wave * 64 * NH + h * 64) * 16), lane_w + (unsigned)((cob_ld + h * 64) * 16), (unsigned)wofs);
+        lds_dma16(rw, st + (unsigned)(LB_X_BYTES + wave * 1024), lane_w + (unsigned)(cob_ld * 16), (unsigned)wofs);
         // advance; past the last item the X part writes zeros (out-of-range offsets) into a stage nobody reads
         st_ld = st_ld == LB_STAGES - 1 ? 0 : st_ld + 1;
         wofs += wstep;
@@ -994,20 +847,18 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
     issue();
     // fragment addresses (bytes inside a stage)
     const unsigned xfrag = (unsigned)(wave * 4096 + pl * 64 + ((kq ^ (pl >> 2)) & 3) * 16);       // + m * 1024
-    const unsigned wfrag = (unsigned)(LB_X_BYTES + (kq * 64 * NH + pl) * 16);                      // + (h * 64 + n * 16) * 16
+    const unsigned wfrag = (unsigned)(LB_X_BYTES + (kq * 64 + pl) * 16);                           // + n * 256
     int st_c = 0;
     for (unsigned it = it_first; it < it_end; it += it_stride) {
-        f32x4 accs[NH][4][MT];
+        constexpr int NT = 4;
+        f32x4 acc[NT][MT];
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) accs[h][n][m] = zero4();
+            for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
         for (int s = 0; s < nsteps; ++s) {
             // my DMA of this step has landed (the instructions of the next step may still be in flight) ...
-            if constexpr (NH == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();        // ... and everyone's; everyone is past the fragment reads of the step before
             asm volatile("" ::: "memory");
             issue();                             // two steps ahead -> the stage the previous step occupied
@@ -1016,20 +867,17 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
             bf16x8 xb[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(st + xfrag + m * 1024);
+            bf16x8 wb[NT];
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                bf16x8 wb[4];
+            for (int n = 0; n < NT; ++n) wb[n] = *reinterpret_cast<const bf16x8*>(st + wfrag + n * 256);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) wb[n] = *reinterpret_cast<const bf16x8*>(st + wfrag + (h * 64 + n * 16) * 16);
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        accs[h][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[n], xb[m], accs[h][n][m], 0, 0, 0);
-            }
+                for (int m = 0; m < MT; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[n], xb[m], acc[n][m], 0, 0, 0);
         }
         if constexpr (DBG) {
-            asm volatile("" ::"v"(accs[0][0][0][0]));
+            asm volatile("" ::"v"(acc[0][0][0]));
             if (lane == 0 && dbgk < 7) dbgp[2 + 2 * dbgk] = __builtin_amdgcn_s_memrealtime();
         }
         // ---- epilogue of this item (the accumulator layout of tapgemm_bf16_kernel: tile m = group m, pixel m*16 + pl)
@@ -1042,20 +890,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
 #pragma unroll
             for (int m = 0; m < MT; ++m) { pn[m] = G.n[m]; pi[m] = G.i[m]; pj[m] = G.j[m] + pl; pv[m] = G.ok[m]; }
         }
-        const int cob0 = (int)(it & (unsigned)slsh) * 64 * NH;
-        // (NH = 2 runs the 64-channel epilogue twice)
-        {
-            constexpr int NT = 4;
-            const int cob = cob0;
-            f32x4 (&acc)[4][MT] = accs[0];
-            LF_TAPGEMM_EPILOGUE
-        }
-        if constexpr (NH == 2) {
-            constexpr int NT = 4;
-            const int cob = cob0 + 64;
-            f32x4 (&acc)[4][MT] = accs[NH - 1];
-            LF_TAPGEMM_EPILOGUE
-        }
+        const int cob = (int)(it & (unsigned)slsh) * 64;
+        LF_TAPGEMM_EPILOGUE
         __builtin_amdgcn_s_setprio(0);
         if constexpr (DBG) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1065,160 +901,6 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two trailing (dead) steps: nothing may land in LDS after this
     __builtin_amdgcn_s_barrier();
-}
-
-// ---------------------------------------------------------------------------------------
-// tapgemm_bf16_stream_kernel: bf16 tap-GEMM with the REGISTER FILE as the operand ring and the weights resident in LDS.
-//
-// What the stamps of the two LDS-ring kernels showed (tools/kbench.py --phases16): a K-step takes 0.8-0.9 us whatever the
-// stage size -- the ring is full (2 workgroups x 2 stages is all the LDS holds) and each 32-channel step fetches HALF of every
-// 128-byte line it touches, the other half a step later when the line has left the 32 KB L1: ~12 TB/s of useful operand
-// bytes, twice that through the L2s (34.5 TB/s peak).  This form
-//  * keeps a whole TAP of a wave's 64 pixels in flight -- every channel of the pixel, i.e. whole lines, fetched by back-to-back
-//    instructions: CB x 4 dwordx4 loads straight into the MFMA operand registers (16 KB per wave at 128 channels, 128 KB per
-//    CU against 80 KB of ring) -- double-buffered by tap in two named register sets;
-//  * has NO barrier in the loop: the waves share only the weights, which the workgroup loads ONCE (all taps of its
-//    64-output-channel slab, 48 KB at 128 channels) and keeps in LDS across its work items (persistent, one slab per
-//    workgroup); weight fragments are four ds_read_b128 per 32-channel step;
-//  * like the ring kernel runs its load cursor across item boundaries (the first tap of the next item is in flight during
-//    the epilogue) and needs Wl % 16 == 0 for the scalar (image, row) addressing.
-// CB = Cs / 32 (2 or 4).  K order and rounding are those of tapgemm_bf16_kernel: results bit-identical.
-// ---------------------------------------------------------------------------------------
-template <int CB, int EPIC>
-__global__ __launch_bounds__(256, 2) void tapgemm_bf16_stream_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
-    constexpr int NT = 4;
-    constexpr bool S16 = true, HOISTV = CB == 2;
-    const int epi = EPIC >= 0 ? EPIC : epi_rt;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int pl = lane & 15, kq = lane >> 4;
-    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl), ngroups = npix >> 4, GR = (unsigned)g.Wl >> 4;
-    const unsigned ntiles = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
-    // Workgroup b: XCD b & 7 (observed), index q = b >> 3 inside it; slab q % nslab (fixed: its weights stay in LDS), pixel
-    // tiles first, first + stride, ... of the XCD's contiguous range.  The launcher sizes the grid to a multiple of 8 * nslab.
-    const unsigned nslab = (unsigned)g.Cd / 64u;
-    const unsigned q = blockIdx.x >> 3, per = (ntiles + 7u) >> 3;
-    const int cob = (int)(q % nslab) * 64;
-    const unsigned it_first = (blockIdx.x & 7u) * per + q / nslab, it_stride = (gridDim.x >> 3) / nslab;
-    unsigned it_end = (blockIdx.x & 7u) * per + per;
-    if (it_end > ntiles) it_end = ntiles;
-
-    int tapv = 0;           // tap t's offsets in lane t (v_readlane in the issue path instead of dependent scalar loads)
-#pragma unroll
-    for (int t = 0; t < LF_MAX_TAPS; ++t)
-        if (lane == t) tapv = (g.tdh[t] & 0xffff) | (g.tdw[t] << 16);
-
-    // ---- the slab's weights -> LDS: [tap][cb][k-block 4][cout 64][16 B]; wave w carries k-block w of every (tap, cb)
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lf_tap_lds;
-    {
-        const i32x4s rw = make_rsrc_words(a.wp16, 0xffffffffu);
-        const unsigned wv = (unsigned)((wave * g.Cd + cob + lane) * 16);
-        const int nw = g.ntaps * CB;
-        for (int i = 0; i < nw; ++i) lds_dma16(rw, lds0 + (unsigned)((i * 4 + wave) * 1024), wv, (unsigned)(i * g.Cd * 64));
-    }
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB));
-    const int spix2 = g.s_pix * 2;
-    const unsigned lane_x = (unsigned)((pl * g.ssw * g.s_pix + g.s_choff + kq * 8) * 2);
-    const int lane_dx = pl * g.ssw;
-
-    // ---- load cursor (wave-uniform): item, tap; the item's four 16-pixel groups
-    unsigned it_ld = it_first;
-    int t_ld = 0;
-    int lrow[4], liy[4], lsx[4];
-    unsigned lok = 0;
-    auto cursor_item = [&]() {
-        lok = 0;
-        if (it_ld < it_end) {
-            RingGroups G;
-            ring_groups(it_ld, wave, g.Hl, GR, ngroups, G);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                liy[m] = G.i[m] * g.ssh; lsx[m] = G.j[m] * g.ssw;
-                lrow[m] = (G.n[m] * g.Hs + liy[m]) * g.Ws + lsx[m];
-                lok |= G.ok[m] ? 1u << m : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { liy[m] = 0; lsx[m] = 0; lrow[m] = 0; }
-        }
-    };
-    cursor_item();
-    struct Tap { u32x4v x[CB][MT]; };
-    auto issue = [&](Tap& S) __attribute__((always_inline)) {          // the cursor's tap: every channel of the wave's 64 pixels
-        const int tv = __builtin_amdgcn_readlane(tapv, t_ld);
-        const int dh = (int)(short)(tv & 0xffff), dw = tv >> 16;
-        const int tapoff = dh * g.Ws + dw;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int sy = liy[m] + dh;
-            const bool yok = ((lok >> m) & 1u) && sy >= 0 && sy < g.Hs;
-            const unsigned base = (unsigned)((lrow[m] + tapoff) * spix2);
-            const bool in = yok && (unsigned)(lsx[m] + dw + lane_dx) < (unsigned)g.Ws;
-            const unsigned vo = in ? base + lane_x : LF_OOB;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) S.x[cb][m] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(vo + cb * 64u), 0, 0);
-        }
-        if (++t_ld == g.ntaps) { t_ld = 0; it_ld += it_stride; cursor_item(); }
-    };
-    f32x4 acc[NT][MT];
-    const unsigned char* const wl = lf_tap_lds + (kq * 64 + pl) * 16;       // + ((t * CB + cb) * 4) * 1024 + n * 256
-    auto compute = [&](const Tap& S, int t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            bf16x8 wb[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) wb[n] = *reinterpret_cast<const bf16x8*>(wl + (t * CB + cb) * 4096 + n * 256);
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[n], __builtin_bit_cast(bf16x8, S.x[cb][m]), acc[n][m], 0, 0, 0);
-        }
-    };
-    // ODD tap counts only (3-tap and 9-tap convolutions; the launcher sends the 2- and 4-tap transposed-convolution phases to
-    // the ring kernel): the taps go in pairs A, B and the last one in A, so exactly ONE register set -- B, holding the first
-    // tap of the next item -- is live across the epilogue, statically.  PREF = false (128 input channels with a BN-backward-sum
-    // epilogue: 64 + 64 registers beside ~125 of epilogue state) issues that tap behind the epilogue instead.
-    constexpr bool PREF = !(EPIC < 0 || ((EPIC & LF_EPI_STATS_XHAT) != 0 && (CB == 4 || (EPIC & LF_EPI_MASKBN) != 0)));
-    Tap A, B;
-    issue(A);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the weights (and the first tap) have landed ...
-    __syncthreads();                                        // ... everyone's part of them
-    const int ntaps = g.ntaps;
-    for (unsigned bx = it_first; bx < it_end; bx += it_stride) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
-        int t = 0;
-        for (; t + 1 < ntaps; t += 2) {
-            issue(B);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(A, t);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(A);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(B, t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (PREF) { issue(B); __builtin_amdgcn_sched_barrier(0); }      // the first tap of the next item
-        compute(A, t);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue of this item (tile m = group m, pixel m*16 + pl)
-        {
-        int pn[MT], pi[MT], pj[MT];
-        bool pv[MT];
-        {
-            RingGroups G;
-            ring_groups(bx, wave, g.Hl, GR, ngroups, G);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) { pn[m] = G.n[m]; pi[m] = G.i[m]; pj[m] = G.j[m] + pl; pv[m] = G.ok[m]; }
-        }
-        LF_TAPGEMM_EPILOGUE
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if constexpr (PREF) A = B;      // (landed during the epilogue)
-        else issue(A);
-    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1394,12 +1076,15 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
             // ---- epilogue of the sub-tile: accumulator tile (n, m) = channels cobw + n*16 + kq*4 .. +3 of pixel m*16 + pl
             RingGroups G;
             groups_at((bx * 4u + (unsigned)sub) * 4u, g.Hl, GR, ngroups, G);
-            f32x4 bs[NOBIAS ? 1 : NT], hsc[NT], hsh[NT];
+            // (128 channels, MASKBN + BN-backward sums: the mask's per-channel vectors are re-read from L1 per use -- held, they are the
+            // 9 registers that variant would spill beside its 96 weight registers)
+            constexpr bool HOISTM = !(CB == 4 && EPIC >= 0 && (EPIC & LF_EPI_MASKBN) != 0 && (EPIC & LF_EPI_STATS_XHAT) != 0);
+            f32x4 bs[NOBIAS ? 1 : NT], hsc[HOISTM ? NT : 1], hsh[HOISTM ? NT : 1];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const unsigned co = (unsigned)(cobw + n * 16 + kq * 4);
                 if constexpr (!NOBIAS) bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4();
-                if (epi & LF_EPI_MASKBN) { hsc[n] = ldb4(r_msc, co * 4u, 0u); hsh[n] = ldb4(r_msh, co * 4u, 0u); }
+                if constexpr (HOISTM) { if (epi & LF_EPI_MASKBN) { hsc[n] = ldb4(r_msc, co * 4u, 0u); hsh[n] = ldb4(r_msh, co * 4u, 0u); } }
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -1418,7 +1103,10 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
                     if constexpr (!NOBIAS) v += bs[n];
                     if (epi & LF_EPI_ADD) v += la[n];
                     if (epi & LF_EPI_MASK) v = keep_pos(v, lm[n]);
-                    if (epi & LF_EPI_MASKBN) v = keep_pos(v, lx[n] * hsc[n] + hsh[n]);
+                    if (epi & LF_EPI_MASKBN) {
+                        const unsigned co = (unsigned)(cobw + n * 16 + kq * 4);
+                        v = keep_pos(v, lx[n] * (HOISTM ? hsc[HOISTM ? n : 0] : ldb4(r_msc, co * 4u, 0u)) + (HOISTM ? hsh[HOISTM ? n : 0] : ldb4(r_msh, co * 4u, 0u)));
+                    }
                     if (epi & LF_EPI_RELU) v = max0(v);
                     lf_bf16x4 b;
                     b[0] = (lf_bf16)v.x; b[1] = (lf_bf16)v.y; b[2] = (lf_bf16)v.z; b[3] = (lf_bf16)v.w;
@@ -1435,8 +1123,9 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
                         }
                     }
                 }
+                if constexpr (!HOISTM) __builtin_amdgcn_sched_barrier(0);      // one pixel tile's operands at a time
             }
-            __syncthreads();                          // the output tile is complete (this also drains the ring's loads: they are needed next)
+            __syncthreads();                          // the output tile is complete
             // whole-line stores: instruction ii of the tile = bytes ii*1024 .. +1023 of the (pixel-major) tile
             constexpr int NI = C::OUT_BYTES / 1024 / WG_WAVES;
 #pragma unroll
@@ -1937,8 +1626,8 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
 }
 
 int g_split_any_size = 0;      // kernel-level tests only: let the split kernel take launches below its shipped size rule
-int g_bf16_lds = 4;            // tools / A-B runs only: 4 = whole-line kernel where it applies, else the persistent ring; 0 = the streaming bf16 kernel, 1 = the one-tile LDS-staged kernel, 2 = the persistent ring, 3 = register streaming + resident weights
-int g_bf16_ring_nh = 0;        // tools only: 0 = the launcher's choice, 1 / 2 = output-channel slabs of 64 / all 128 channels per workgroup
+int g_bf16_lds = 4;            // tools / A-B runs only: 4 = whole-line + 16-channel kernels where they apply, else the ring (shipped); 2 = the ring
+                               // for every launch it takes; 0 = the streaming bf16 kernel only
 
 int pick_nt(int Cd) {
     const int tiles = Cd / 16;
@@ -1951,7 +1640,7 @@ int pick_nt(int Cd) {
 }  // namespace
 
 void lf_tapgemm_set_split_any_size(int v) { g_split_any_size = v; }
-void lf_tapgemm_set_bf16_lds(int v) { g_bf16_lds = v & 7; g_bf16_ring_nh = (v >> 3) & 3; }
+void lf_tapgemm_set_bf16_lds(int v) { g_bf16_lds = v; }
 
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
 // workgroups (its two 4-wave groups each own one 256-pixel statistics row), 16-byte aligned pixels
@@ -2000,40 +1689,15 @@ void launch_tapgemm(K kernel, dim3 grid, size_t lds, hipStream_t st, const LfTap
     if (g_launch_flags) hipExtLaunchKernelGGL(kernel, grid, dim3(256), (unsigned)lds, st, nullptr, nullptr, g_launch_flags, g, a, pro, epi);
     else hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, g, a, pro, epi);
 }
-// tapgemm_bf16_ring_kernel: persistent, at most the resident workgroups (a multiple of 8: XCD-contiguous item ranges).  NH = 2
-// (all 128 output channels per workgroup) exists for the light epilogues only: beside 128 accumulators the BN-backward-sum
-// epilogues spill (10-46 registers), those launches run as two 64-channel slabs per pixel tile.
-template <int NHV, int EPIV, bool DBGV = false>
-void launch_bf16_ring1(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
-    auto kern = tapgemm_bf16_ring_kernel<NHV, EPIV, DBGV>;
-    const size_t ring_lds = (size_t)LB_STAGES * (LB_X_BYTES + NHV * LB_W_BYTES);
-    static bool attr_set = false;           // dynamic LDS beyond 64 KB needs the attribute, once per instantiation
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set = true;
-    }
+// tapgemm_bf16_ring_kernel: persistent, at most the resident workgroups (a multiple of 8: XCD-contiguous item ranges)
+template <int EPIV, bool DBGV = false>
+void launch_bf16_ring(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
+    auto kern = tapgemm_bf16_ring_kernel<EPIV, DBGV>;
+    const size_t ring_lds = (size_t)LB_STAGES * LB_STAGE_BYTES;
     unsigned gx = nitems;
     const unsigned res = (unsigned)resident_workgroups(kern, ring_lds);
     if (gx > res && res >= 8) gx = res & ~7u;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), ring_lds, st, g, a, pro, epi);
-}
-// tapgemm_bf16_stream_kernel: persistent, one output-channel slab per workgroup; the grid is the resident workgroups rounded
-// down to a multiple of 8 (XCDs) x slabs, or fewer when the launch has fewer (tile, slab) items
-template <int CBV, int EPIV>
-void launch_bf16_stream(unsigned ntiles, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
-    auto kern = tapgemm_bf16_stream_kernel<CBV, EPIV>;
-    const size_t lds = (size_t)g.ntaps * CBV * 4096;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set = true;
-    }
-    const unsigned nslab = (unsigned)g.Cd / 64u, unit = 8u * nslab;
-    const unsigned per = (ntiles + 7u) / 8u;                       // pixel tiles per XCD
-    unsigned gx = per * unit;                                      // one workgroup per (tile, slab) of the largest XCD range
-    const unsigned res = (unsigned)resident_workgroups(kern, lds);
-    if (gx > res && res >= unit) gx = res / unit * unit;
-    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, st, g, a, pro, epi);
 }
 template <int CBV, int EPIV>
 void launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
@@ -2048,13 +1712,6 @@ void launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const L
     const unsigned res = (unsigned)resident_workgroups(kern, lds);
     if (gx > res && res >= 8) gx = res & ~7u;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, st, g, a, pro, epi);
-}
-template <int EPIV>
-void launch_bf16_ring(int nh, unsigned ntiles, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
-    if constexpr (EPIV >= 0 && (EPIV & LF_EPI_STATS_XHAT) == 0) {
-        if (nh == 2) { launch_bf16_ring1<2, EPIV>(ntiles, st, g, a, pro, epi); return; }
-    }
-    launch_bf16_ring1<1, EPIV>(ntiles * (unsigned)(g.Cd / 64), st, g, a, pro, epi);
 }
 }  // namespace
 
@@ -2133,19 +1790,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         else hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0, false>), grid, dim3(256), 0, st, g, a, pro, epi);            \
     } while (0)
         LF_REQUIRE(g.Cs >= 8 && g.s_pix >= g.s_choff + 8, "tapgemm bf16: needs at least 8 source channels");
-#define LF_TG16F(EPIV)                                                                                                   \
-    do {                                                                                                                 \
-        if (use_lds) {                                                                                                   \
-            static bool attr_set = false;       /* dynamic LDS beyond 64 KB needs the attribute, once per instantiation */ \
-            if (!attr_set) {                                                                                             \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tapgemm_bf16_lds_kernel<EPIV>),                  \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);               \
-                attr_set = true;                                                                                         \
-            }                                                                                                            \
-            hipLaunchKernelGGL((tapgemm_bf16_lds_kernel<EPIV>), grid, dim3(256), lds_bytes, st, g, a, pro, epi);         \
-        } else                                                                                                           \
-            hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 0, true, EPIV, true>), grid, dim3(256), 0, st, g, a, pro, epi);   \
-    } while (0)
+#define LF_TG16F(EPIV) hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 0, true, EPIV, true>), grid, dim3(256), 0, st, g, a, pro, epi)
         // the 16 -> 16 channel 3-tap convolutions on bf16 tensors: tapgemm_bf16_lean_kernel
         if (a.s16 && g_bf16_lds == 4 && !a.dbg && g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0 && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 &&
             (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB) {
@@ -2168,10 +1813,10 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         }
         const bool fast16 = nt == 4 && a.s16 && pro != LF_PRO_BNRELU && g.Cs % 32 == 0 &&
                             (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB;
-        // LDS-staged form (three K-steps of operands in flight per wave): every FAST launch whose ring + tap table fit the CU
-        const size_t lds_bytes = (size_t)LB_STAGES * LB_STAGE_BYTES + LB_TAB_PER_TAP * g.ntaps;
-        const bool use_lds = g_bf16_lds && lds_bytes <= 128 * 1024;
-        // persistent ring form (tapgemm_bf16_ring_kernel): 16-pixel groups inside one image row, 64 or 128 output channels
+        // Which kernel (g_bf16_lds = 4, the shipped setting): the 3-tap convolutions of non_bottleneck_1d at 64 / 128 channels ->
+        // tapgemm_bf16_wl_kernel (whole lines); every other prologue-free launch at 64-channel output slabs whose 16-pixel groups lie
+        // in one image row (the 9-tap stride-2 convolution, the transposed-convolution phases, their gradients) ->
+        // tapgemm_bf16_ring_kernel; the rest (operand prologue, ragged widths) -> the streaming tapgemm_bf16_kernel
         const bool wl = fast16 && g_bf16_lds == 4 && !a.dbg && g.ntaps == 3 && g.Cs == g.Cd && (g.Cd == 64 || g.Cd == 128) && g.Wl % 16 == 0 &&
                         g.ssh == 1 && g.ssw == 1 && g.dsh == 1 && g.dsw == 1 && g.dah == 0 && g.daw == 0 && g.Hs == g.Hl && g.Ws == g.Wl &&
                         g.Hd == g.Hl && g.Wd == g.Wl && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0;
@@ -2193,36 +1838,14 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
             LF_CHECK_LAUNCH("tapgemm_bf16_wl");
             return 0;
         }
-        const bool ring = fast16 && (g_bf16_lds == 2 || g_bf16_lds == 4) && g.Wl % 16 == 0 && (g.Cd == 64 || g.Cd == 128);
-        const bool stream = fast16 && g_bf16_lds == 3 && !a.dbg && g.Wl % 16 == 0 && (g.Cd == 64 || g.Cd == 128) &&
-                            (g.Cs == 64 || g.Cs == 128) && (g.ntaps & 1) && (size_t)g.ntaps * (g.Cs / 32) * 4096 <= 72 * 1024;
-        if (stream) {
-            const unsigned ntiles = (unsigned)lf_cdiv(npix, PIX_PER_WG);
-#define LF_TGS(EPIV) do { if (g.Cs == 128) launch_bf16_stream<4, EPIV>(ntiles, st, g, a, pro, epi); else launch_bf16_stream<2, EPIV>(ntiles, st, g, a, pro, epi); } while (0)
-            switch (epis) {
-                case 0: LF_TGS(0); break;
-                case LF_EPI_RELU: LF_TGS(LF_EPI_RELU); break;
-                case LF_EPI_MASK: LF_TGS(LF_EPI_MASK); break;
-                case LF_EPI_ADD: LF_TGS(LF_EPI_ADD); break;
-                case LF_EPI_STATS_SQ: LF_TGS(LF_EPI_STATS_SQ); break;
-                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGS(LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
-                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGS(LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
-                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TGS(LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
-                default: LF_TGS(-1); break;
-            }
-#undef LF_TGS
-        } else
+        const bool ring = fast16 && g_bf16_lds >= 2 && g.Wl % 16 == 0 && g.Cd % 64 == 0;
+        const unsigned nitems = (unsigned)(lf_cdiv(npix, PIX_PER_WG) * (g.Cd / 64));
         if (ring && a.dbg) {        // stamps (tools/kbench.py --phases16): the plain convolution only
             LF_REQUIRE(epis == 0, "tapgemm bf16 ring: stamps are compiled into the plain convolution only");
-            const unsigned ntiles = (unsigned)lf_cdiv(npix, PIX_PER_WG);
-            if (g.Cd == 128 && g_bf16_ring_nh != 1) launch_bf16_ring1<2, 0, true>(ntiles, st, g, a, pro, epi);
-            else launch_bf16_ring1<1, 0, true>(ntiles * (unsigned)(g.Cd / 64), st, g, a, pro, epi);
+            launch_bf16_ring<0, true>(nitems, st, g, a, pro, epi);
         } else
         if (ring) {
-            const unsigned ntiles = (unsigned)lf_cdiv(npix, PIX_PER_WG);
-            // NH = 2 (all 128 output channels in one workgroup) once the launch has tiles for every resident workgroup anyway
-            const int nh = g.Cd == 128 && (g_bf16_ring_nh == 2 || (g_bf16_ring_nh == 0 && ntiles >= 768u)) ? 2 : 1;
-#define LF_TGR(EPIV) launch_bf16_ring<EPIV>(nh, ntiles, st, g, a, pro, epi)
+#define LF_TGR(EPIV) launch_bf16_ring<EPIV>(nitems, st, g, a, pro, epi)
             switch (epis) {
                 case 0: LF_TGR(0); break;
                 case LF_EPI_RELU: LF_TGR(LF_EPI_RELU); break;
@@ -2235,12 +1858,6 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
                 default: LF_TGR(-1); break;
             }
 #undef LF_TGR
-        } else
-        if (fast16 && a.dbg) {      // phase stamps (tools/kbench.py --phases16): the plain LDS-staged launch only
-            LF_REQUIRE(use_lds && epis == 0, "tapgemm bf16: phase stamps are compiled into the plain LDS-staged convolution only");
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tapgemm_bf16_lds_kernel<0, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            hipLaunchKernelGGL((tapgemm_bf16_lds_kernel<0, true>), grid, dim3(256), lds_bytes, st, g, a, pro, epi);
         } else if (fast16) {       // the bf16-tensor launches of the network at 64 output channels per workgroup
             switch (epis) {
                 case 0: LF_TG16F(0); break;

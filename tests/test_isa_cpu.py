@@ -39,7 +39,9 @@ def test_no_vgpr_spills_in_network_kernels(conv_kernels):
     hot += _select(conv_kernels, "tapgemm_lean_kernel<")
     hot += _select(conv_kernels, "tapgemm_split_kernel<")
     hot += _select(conv_kernels, "tapgemm_bf16_kernel<")
-    hot += _select(conv_kernels, "tapgemm_bf16_lds_kernel<")
+    hot += _select(conv_kernels, "tapgemm_bf16_ring_kernel<")
+    hot += _select(conv_kernels, "tapgemm_bf16_wl_kernel<")
+    hot += _select(conv_kernels, "tapgemm_bf16_lean_kernel<")
     hot += _select(conv_kernels, "tapwgrad_kernel<")
     hot += _select(conv_kernels, "tapwgrad16_kernel<")
     assert len(hot) > 100
@@ -62,9 +64,12 @@ def test_register_budgets(conv_kernels):
     # the run-time-flag forms (cold paths) take the whole register file instead of spilling: one wave per SIMD
     for name in ("tapgemm_kernel<4, 0, -1, true, false>", "tapgemm_kernel<4, 1, -1, false, false>"):
         assert by[name]["vgpr_spill"] == 0 and by[name]["vgpr"] + by[name]["agpr"] <= 512, (name, by[name])
-    # the 16-channel kernel keeps four workgroups per CU (<= 128 registers)
-    for k in _select(conv_kernels, "tapgemm_lean_kernel<"):
+    # the 16-channel kernels keep four workgroups per CU (<= 128 registers)
+    for k in _select(conv_kernels, "tapgemm_lean_kernel<") + _select(conv_kernels, "tapgemm_bf16_lean_kernel<"):
         assert k["vgpr"] <= 128, (k["name"], k["vgpr"])
+    # the bf16 LDS kernels run two workgroups per CU (<= 256 registers; their LDS budgets are checked by the launcher's occupancy query)
+    for k in _select(conv_kernels, "tapgemm_bf16_ring_kernel<") + _select(conv_kernels, "tapgemm_bf16_wl_kernel<"):
+        assert k["vgpr"] + k["agpr"] <= 256 and k["scratch"] == 0, (k["name"], k["vgpr"], k["scratch"])
     # the phase-stamp code exists only in the DBG instantiations
     dbg = [k["name"] for k in conv_kernels if k["name"].endswith(", true>") and k["name"].startswith(("tapgemm_kernel<", "tapwgrad_kernel<"))
            and k["name"].count("true>")]

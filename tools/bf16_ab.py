@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""bf16-tensor tap-GEMM: the LDS-staged kernel (round 4) against the streaming one on the same launches -- bit-identical results
-(same K order: the same MFMA sequence per accumulator) and HIP-event timing, forward (+ReLU) and data gradient (+mask).
+"""bf16-tensor tap-GEMM: the LDS-staged kernels (round 4: persistent ring, whole lines) against the streaming one on the same
+launches -- bit-identical results (same K order: the same MFMA sequence per accumulator) and HIP-event timing, forward (+ReLU) and
+data gradient (+mask).
 
     python tools/bf16_ab.py [--iters 200]
 """
@@ -49,9 +50,8 @@ def main():
             b = torch.randn(C, device="cuda")
             scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096, device="cuda")
             res, tim = {}, {}
-            # lf_debug_set_bf16_lds: bits 0-2 = 0 streaming / 1 one-tile LDS ring / 2 persistent ring / 3 register streaming / 4 whole lines; bits 3-4 = the persistent
-            # ring's output channels per workgroup (0 launcher's choice, 1 = 64-channel slabs, 2 = all 128)
-            modes = [("streaming", 0), ("LDS", 1), ("ring64", 2 | 1 << 3)] + ([("ring128", 2 | 2 << 3)] if C == 128 else []) + [("stream2", 3), ("whole-line", 4)]
+            # lf_debug_set_bf16_lds: 0 streaming kernel only / 2 the ring for every launch it takes / 4 whole-line kernel where it applies (shipped)
+            modes = [("streaming", 0), ("ring", 2), ("whole-line", 4)]
             for name, mode in modes:
                 lib.lf_debug_set_bf16_lds(mode)
                 y, gx = torch.empty_like(x), torch.empty_like(x)
