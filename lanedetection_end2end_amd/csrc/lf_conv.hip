@@ -925,15 +925,31 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
 // sub-tiles and items.  K order = tapgemm_bf16_kernel's (tap, then channel): results bit-identical.
 // ---------------------------------------------------------------------------------------
 constexpr int WL_STAGE = 64 * 128;
-template <int CB> struct WlCfg {
-    static constexpr int NT = CB / 2, KS = CB / 2, NSTEP = 3 * KS, STAGES = CB == 4 ? 6 : 8, CD = CB * 32, PIXB = CD * 2;
+template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+// Epilogue operand tensors (the data gradient's ReLU-mask source, residual gradient, BN-backward operand) come in whole lines too: by
+// LDS-DMA into tiles of the output tile's layout, issued behind the first K-step of the sub-tile they belong to and read by the
+// epilogue in the accumulator layout (8 bytes per lane from LDS instead of 32 of every 128-byte line from L2: +40 us per tensor and
+// launch at 80 x 160 x 64 images before).  The residual lands IN the output tile (each lane overwrites what it read); the other
+// two have their own tiles, which come out of the ring's depth: 2 x 80 KB per CU.
+template <int CB, int EPIC> struct WlCfg {
+    static constexpr int NT = CB / 2, KS = CB / 2, NSTEP = 3 * KS, CD = CB * 32, PIXB = CD * 2;
     static constexpr int OUT_BYTES = 64 * PIXB;
-    static constexpr size_t LDS = (size_t)STAGES * WL_STAGE + OUT_BYTES;
+    static constexpr bool ST_ADD = EPIC >= 0 && (EPIC & LF_EPI_ADD) != 0, ST_MSK = EPIC >= 0 && (EPIC & LF_EPI_MASK) != 0,
+                          ST_AUX = EPIC >= 0 && (EPIC & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) != 0 &&
+                                   !(CB == 4 && (EPIC & LF_EPI_MASKBN) != 0);          // (that variant has no registers left for it: 7 spilled)
+    static constexpr int NBUF = (ST_MSK ? 1 : 0) + (ST_AUX ? 1 : 0);                  // tiles beside the output tile
+    static constexpr int NI = OUT_BYTES / 1024 / WG_WAVES;                            // 1 KB instructions per wave and tile
+    static constexpr int NAUXI = ((ST_ADD ? 1 : 0) + NBUF) * NI;                      // staging instructions per wave and sub-tile
+    static constexpr int MAXST = CB == 4 ? 6 : 8;
+    static constexpr int FIT = (80 * 1024 - OUT_BYTES * (1 + NBUF)) / WL_STAGE;
+    static constexpr int STAGES = FIT < MAXST ? FIT : MAXST;
+    static constexpr size_t LDS = (size_t)STAGES * WL_STAGE + (size_t)OUT_BYTES * (1 + NBUF);
+    static_assert(STAGES >= 3, "ring too shallow");
 };
 
 template <int CB, int EPIC>
 __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
-    typedef WlCfg<CB> C;
+    typedef WlCfg<CB, EPIC> C;
     constexpr int NT = C::NT, KS = C::KS, NSTEP = C::NSTEP, S = C::STAGES, CD = C::CD, PIXB = C::PIXB, NCH = PIXB / 16;
     constexpr bool S16 = true;
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
@@ -951,6 +967,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lf_tap_lds;
     unsigned char* const ring = lf_tap_lds;
     unsigned char* const otile = lf_tap_lds + S * WL_STAGE;
+    unsigned char* const mtile = otile + C::OUT_BYTES;                                 // mask source (when staged)
+    unsigned char* const xtile = otile + C::OUT_BYTES * (C::ST_MSK ? 2 : 1);          // BN-backward operand (when staged)
 
     // ---- this wave's weights -> registers: [tap][32-channel k-block][16-channel output tile], the MFMA A operand
     bf16x8 wr[3][CB][NT];
@@ -1027,6 +1045,32 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
 #pragma unroll
     for (int i = 0; i < S - 1; ++i) issue();
 
+    // ---- staging of the epilogue's operand tensors: wave w carries group w of the sub-tile (NI instructions of 1 KB per tensor);
+    // instruction ii = w * NI + k is bytes ii*1024 .. +1023 of the pixel-major tile: lane -> pixel p, 16-byte slot = chunk XOR p
+    // (resources bounded by the tensor: the out-of-range offset of a group beyond it reads zeros)
+    const unsigned dbytes = (unsigned)min((long)g.N * g.Hd * g.Wd * g.d_pix * 2, (long)LF_OOB);
+    const i32x4s ra_add = make_rsrc_words(a.add_src, dbytes), ra_msk = make_rsrc_words(a.mask_src, dbytes), ra_aux = make_rsrc_words(a.aux, dbytes);
+    auto stage_tensors = [&](const RingGroups& G) __attribute__((always_inline)) {
+        if constexpr (C::NAUXI > 0) {
+            const int gn = wave == 0 ? G.n[0] : wave == 1 ? G.n[1] : wave == 2 ? G.n[2] : G.n[3];
+            const int gi = wave == 0 ? G.i[0] : wave == 1 ? G.i[1] : wave == 2 ? G.i[2] : G.i[3];
+            const int gj = wave == 0 ? G.j[0] : wave == 1 ? G.j[1] : wave == 2 ? G.j[2] : G.j[3];
+            const bool gok = wave == 0 ? G.ok[0] : wave == 1 ? G.ok[1] : wave == 2 ? G.ok[2] : G.ok[3];
+            const unsigned base = (unsigned)(((gn * g.Hd + gi) * g.Wd + gj) * g.d_pix * 2);
+            const unsigned dst0 = lds0 + (unsigned)(S * WL_STAGE + wave * C::NI * 1024);
+#pragma unroll
+            for (int k = 0; k < C::NI; ++k) {
+                const int ii = wave * C::NI + k;
+                const int p = (ii * 1024) / PIXB + (lane * 16) / PIXB, slot = ((lane * 16) % PIXB) / 16;
+                const unsigned st_lane = (unsigned)((((p & 15) * g.d_pix + g.d_choff) * 2) + ((slot ^ p) & (NCH - 1)) * 16);
+                const unsigned vo = gok ? base + st_lane : LF_OOB;                // (a whole group beyond the tensor: zeros)
+                if constexpr (C::ST_ADD) lds_dma16(ra_add, dst0 + (unsigned)(k * 1024), vo, 0u);
+                if constexpr (C::ST_MSK) lds_dma16(ra_msk, dst0 + (unsigned)(C::OUT_BYTES + k * 1024), vo, 0u);
+                if constexpr (C::ST_AUX) lds_dma16(ra_aux, dst0 + (unsigned)(C::OUT_BYTES * (C::ST_MSK ? 2 : 1) + k * 1024), vo, 0u);
+            }
+        }
+    };
+
     // epilogue constants
     const __amdgpu_buffer_rsrc_t r_dst = make_rsrc(a.dst, 0xffffffffu), r_add = make_rsrc(a.add_src, 0xffffffffu),
                                  r_msk = make_rsrc(a.mask_src, 0xffffffffu), r_aux = make_rsrc(a.aux, 0xffffffffu),
@@ -1046,18 +1090,23 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
+            RingGroups G;
+            groups_at((bx * 4u + (unsigned)sub) * 4u, g.Hl, GR, ngroups, G);
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
-                // my DMA of this step has landed (S - 2 younger steps of 2 instructions may be in flight) ...
+                // my DMA of this step has landed: exactly S - 2 younger ring steps of 2 instructions may be in flight -- plus, behind
+                // step 0, this sub-tile's staging instructions while the step's own DMA is older than they are (steps 1 .. S-1; the
+                // count must not EXCEED the younger instructions, or the wait passes early) ...
                 // ... and MY fragment reads of the step before have retired (lgkmcnt): hipcc moves that step's last MFMAs -- and the
                 // waits for their operands -- behind the barrier, and the stage is restaged right behind it: a DMA instruction whose 8
                 // pixels are all padding returns its zeros without a memory round trip and overtook those reads (wrong tiles in 1 of
                 // 3 launches at dilation 8, row width 80)
-                if constexpr (S == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+                if (s >= 1 && s <= S - 1) wait_vm_lgkm0<2 * (S - 2) + C::NAUXI>();
+                else wait_vm_lgkm0<2 * (S - 2)>();
                 __builtin_amdgcn_s_barrier();        // ... and everyone's; everyone is past the fragment reads of the step before
                 asm volatile("" ::: "memory");
                 issue();                             // S - 1 steps ahead -> the stage the previous step occupied
+                if (s == 0) stage_tensors(G);        // (everyone is past the previous sub-tile's reads of the tiles: the barrier above)
                 const unsigned char* st = ring + st_c * WL_STAGE;
                 st_c = st_c == S - 1 ? 0 : st_c + 1;
                 const int t = KS == 1 ? s : s >> 1, ks = KS == 1 ? 0 : s & 1;          // (compile-time after unrolling: wr is indexed statically)
@@ -1074,8 +1123,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
                 }
             }
             // ---- epilogue of the sub-tile: accumulator tile (n, m) = channels cobw + n*16 + kq*4 .. +3 of pixel m*16 + pl
-            RingGroups G;
-            groups_at((bx * 4u + (unsigned)sub) * 4u, g.Hl, GR, ngroups, G);
+            if constexpr (C::NAUXI > 0) {            // the staged tensors have landed: mine (the ring steps issued since are younger) ...
+                wait_vm_lgkm0<2 * (NSTEP - 1)>();
+                __builtin_amdgcn_s_barrier();        // ... and everyone's
+                asm volatile("" ::: "memory");
+            }
             // (128 channels, MASKBN + BN-backward sums: the mask's per-channel vectors are re-read from L1 per use -- held, they are the
             // 9 registers that variant would spill beside its 96 weight registers)
             constexpr bool HOISTM = !(CB == 4 && EPIC >= 0 && (EPIC & LF_EPI_MASKBN) != 0 && (EPIC & LF_EPI_STATS_XHAT) != 0);
@@ -1090,11 +1142,19 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
             for (int m = 0; m < MT; ++m) {
                 const unsigned dbase = (unsigned)(((G.n[m] * g.Hd + G.i[m]) * g.Wd + G.j[m] + pl) * g.d_pix + g.d_choff + cobw + kq * 4);
                 f32x4 la[NT], lm[NT], lx[NT], ld[NT];
+                auto tile_ld = [&](const unsigned char* tile, int n) __attribute__((always_inline)) {      // this lane's 4 channels of (m, n)
+                    const int p = m * 16 + pl, chunk = (cobw + n * 16 + kq * 4) >> 3;
+                    const uint2 q = *reinterpret_cast<const uint2*>(tile + p * PIXB + ((chunk ^ p) & (NCH - 1)) * 16 + (kq & 1) * 8);
+                    f32x4 v;
+                    v.x = __uint_as_float(q.x << 16); v.y = __uint_as_float(q.x & 0xffff0000u);
+                    v.z = __uint_as_float(q.y << 16); v.w = __uint_as_float(q.y & 0xffff0000u);
+                    return v;
+                };
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    if (epi & LF_EPI_ADD) la[n] = epi_ld<S16>(r_add, dbase + n * 16);
-                    if (epi & LF_EPI_MASK) lm[n] = epi_ld<S16>(r_msk, dbase + n * 16);
-                    if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[n] = epi_ld<S16>(r_aux, dbase + n * 16);
+                    if (epi & LF_EPI_ADD) la[n] = C::ST_ADD ? tile_ld(otile, n) : epi_ld<S16>(r_add, dbase + n * 16);
+                    if (epi & LF_EPI_MASK) lm[n] = C::ST_MSK ? tile_ld(mtile, n) : epi_ld<S16>(r_msk, dbase + n * 16);
+                    if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[n] = C::ST_AUX ? tile_ld(xtile, n) : epi_ld<S16>(r_aux, dbase + n * 16);
                     if ((epi & LF_EPI_STATS_XHAT) && a.dm) ld[n] = ldb4(r_dm, (unsigned)(G.n[m] * g.Cd + cobw + n * 16 + kq * 4) * 4u, 0u);
                 }
 #pragma unroll
@@ -1702,7 +1762,7 @@ void launch_bf16_ring(unsigned nitems, hipStream_t st, const LfTapGeom& g, const
 template <int CBV, int EPIV>
 void launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
     auto kern = tapgemm_bf16_wl_kernel<CBV, EPIV>;
-    const size_t lds = WlCfg<CBV>::LDS;
+    const size_t lds = WlCfg<CBV, EPIV>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
@@ -1819,7 +1879,8 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         // tapgemm_bf16_ring_kernel; the rest (operand prologue, ragged widths) -> the streaming tapgemm_bf16_kernel
         const bool wl = fast16 && g_bf16_lds == 4 && !a.dbg && g.ntaps == 3 && g.Cs == g.Cd && (g.Cd == 64 || g.Cd == 128) && g.Wl % 16 == 0 &&
                         g.ssh == 1 && g.ssw == 1 && g.dsh == 1 && g.dsw == 1 && g.dah == 0 && g.daw == 0 && g.Hs == g.Hl && g.Ws == g.Wl &&
-                        g.Hd == g.Hl && g.Wd == g.Wl && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0;
+                        g.Hd == g.Hl && g.Wd == g.Wl && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
+                        (long)g.N * g.Hd * g.Wd * g.d_pix * 2 < (long)LF_OOB;
         if (wl) {
             const unsigned nitems = (unsigned)lf_cdiv(npix, PIX_PER_WG);
 #define LF_TGW(EPIV) do { if (g.Cs == 128) launch_bf16_wl<4, EPIV>(nitems, st, g, a, pro, epi); else launch_bf16_wl<2, EPIV>(nitems, st, g, a, pro, epi); } while (0)

@@ -1,0 +1,54 @@
+"""Race screen of the LDS-DMA bf16 kernels (tapgemm_bf16_wl_kernel, tapgemm_bf16_ring_kernel): their rings are ordered by
+hand-counted s_waitcnt vmcnt(N) + bare s_barrier, so a wrong count shows as rare wrong tiles that come and go with shape and
+memory load, not as a failing refcheck.  Every launch of a repeat loop must equal the streaming kernel's result BIT FOR BIT (same
+K order: the same MFMA sequence per accumulator), forward (+bias, ReLU) and data gradient (+ReLU mask of a staged tensor), at the
+shapes that failed during bring-up: row width 80 (16-pixel groups straddle rows), dilation 8 (a padding tap empties a whole DMA
+instruction: it returns without a memory round trip and overtook pending fragment reads before the lgkmcnt(0) in front of the
+barrier -- 1 launch in 3 wrong), two workgroups per CU with one or two work items each."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(64, 128, 40, 80, 1, 8), (64, 128, 40, 80, 0, 4), (64, 64, 80, 160, 1, 1), (32, 128, 32, 64, 1, 16),
+                                   (3, 128, 20, 48, 1, 16), (5, 64, 12, 32, 0, 2)])
+def test_lds_dma_kernels_equal_the_streaming_kernel_on_every_launch(shape):
+    from lanedetection_end2end_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    N, C, H, W, axis, d = shape
+    torch.manual_seed(1)
+    x = torch.randn(N, H, W, C, device="cuda").bfloat16()
+    gy = torch.randn(N, H, W, C, device="cuda").bfloat16()
+    w = torch.randn(C, C, 3, device="cuda") * (2.0 / (3 * C)) ** 0.5
+    b = torch.randn(C, device="cuda")
+    scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096, device="cuda")
+
+    def run(mode):
+        lib.lf_debug_set_bf16_lds(mode)
+        y, gx = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 1, P(scratch), st), "fwd")
+        _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), P(x), P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
+        torch.cuda.synchronize()
+        return y, gx
+
+    try:
+        lib.lf_debug_set_ops_precision(2)
+        ref = run(0)
+        assert torch.isfinite(ref[0].float()).all() and torch.isfinite(ref[1].float()).all()
+        repeats = 12 if N * H * W > 100000 else 40
+        for name, mode in (("ring", 2), ("whole-line", 4)):
+            bad = []
+            for it in range(repeats):
+                y, gx = run(mode)
+                if not (torch.equal(y, ref[0]) and torch.equal(gx, ref[1])):
+                    px = ((y != ref[0]) | (gx != ref[1])).reshape(-1, C).any(1).nonzero().flatten()
+                    bad.append((it, len(px), int(px[0])))
+            assert not bad, "%s kernel, shape %r: launches that differ from the streaming kernel (launch, pixels, first pixel): %r" % (name, shape, bad[:6])
+    finally:
+        lib.lf_debug_set_ops_precision(0)
+        lib.lf_debug_set_bf16_lds(4)
