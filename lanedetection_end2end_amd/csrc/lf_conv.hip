@@ -2652,6 +2652,131 @@ __global__ __launch_bounds__(256) void tapwgrad16_kernel(const LfTapGeom g, cons
     }
 }
 
+// 16 x 16 channel weight gradient on bf16 tensors (no operand prologue): the kernel above fetches ONE bf16 per lane and
+// instruction (2-byte buffer loads, 16 of them per 16 pixels: 135 us per launch at 160 x 320 x 64 images, where the 210 MB
+// it reads take 40).  Here every wave owns a private LDS ring (no barrier in the loop):
+//  * LDS-DMA copies 32 pixels x 32 bytes of G and of X at each of the three tap positions, lane-linear (1 KB = whole lines of the
+//    NHWC tensors; a padding tap position carries the out-of-range offset and lands as zeros), three stages in flight;
+//  * the image [pixel][16 channels] is exactly the [k][n] block ds_read_b64_tr_b16 transposes: lane (channel l & 15, k-group
+//    l >> 4) receives pixels 4 (l >> 4) .. +3 of its channel -- the A / B operand of v_mfma_f32_16x16x16_bf16 with K = 16 pixels:
+//    per 16 pixels one transposing read per operand, one MFMA per tap.
+// Split over pixel ranges and reduced through LDS at the end like tapwgrad16_kernel (same partial layout).
+constexpr int W16_STAGE = 4 * 1024, W16_STAGES = 4;
+__global__ __launch_bounds__(256) void tapwgrad16_tr_kernel(const LfTapGeom g, const LfWgradArgs a, const long pps, const int write_bias) {
+    constexpr int NTAPS = 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pl = lane & 15, kq = lane >> 4;
+    const long npix = (long)g.N * g.Hl * g.Wl;
+    const long sub = (long)blockIdx.x * WG_WAVES + wave;
+    const long p_begin = sub * pps;
+    long p_end = p_begin + pps;
+    if (p_end > npix) p_end = npix;
+    const int niter = p_end > p_begin ? (int)((p_end - p_begin + 31) / 32) : 0;
+    f32x4 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) acc[t] = zero4();
+    float bsum = 0.f;
+    const i32x4s rx = make_rsrc_words(a.x, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB)),
+                 rg = make_rsrc_words(a.g, (unsigned)min((long)g.N * g.Hd * g.Wd * g.d_pix * 2, (long)LF_OOB));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lf_tap_lds + (unsigned)(wave * W16_STAGES * W16_STAGE);
+    const unsigned char* const ring = lf_tap_lds + wave * W16_STAGES * W16_STAGE;
+    const int tdh0 = g.tdh[0], tdh1 = g.tdh[1], tdh2 = g.tdh[2], tdw0 = g.tdw[0], tdw1 = g.tdw[1], tdw2 = g.tdw[2];
+    // load cursor: (image, row, column) of the next 16-pixel group (wave-uniform; Wl % 16 == 0: a group lies in one row)
+    long p_ld = p_begin;
+    int pj, pi, pn;
+    {
+        const unsigned q = niter ? (unsigned)p_begin : 0u;
+        const unsigned r = q / (unsigned)g.Wl;
+        pj = __builtin_amdgcn_readfirstlane((int)(q - r * (unsigned)g.Wl));
+        pn = __builtin_amdgcn_readfirstlane((int)(r / (unsigned)g.Hl));
+        pi = __builtin_amdgcn_readfirstlane((int)r) - pn * g.Hl;
+    }
+    const int px = (lane >> 1) & 15, half = lane & 1;         // lanes 0-31: first group of the stage, 32-63: second
+    int st_ld = 0;
+    auto issue = [&]() __attribute__((always_inline)) {
+        // the two groups of this stage
+        int gn[2], gi[2], gj[2];
+        bool gok[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            gok[q] = p_ld < p_end;
+            gn[q] = pn; gi[q] = pi; gj[q] = pj;
+            p_ld += 16;
+            pj += 16;
+            if (pj >= g.Wl) { pj = 0; if (++pi >= g.Hl) { pi = 0; ++pn; } }
+        }
+        const bool hi = lane >= 32;
+        const int n = hi ? gn[1] : gn[0], i = hi ? gi[1] : gi[0], j = (hi ? gj[1] : gj[0]) + px;
+        const bool ok = hi ? gok[1] : gok[0];
+        const unsigned dst = lds0 + (unsigned)(st_ld * W16_STAGE);
+        const unsigned go = (unsigned)((((n * g.Hd + i * g.dsh + g.dah) * g.Wd + j * g.dsw + g.daw) * g.d_pix + g.d_choff + half * 8) * 2);
+        lds_dma16(rg, dst, ok ? go : LF_OOB, 0u);
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int dh = t == 0 ? tdh0 : t == 1 ? tdh1 : tdh2, dw = t == 0 ? tdw0 : t == 1 ? tdw1 : tdw2;
+            const int sy = i * g.ssh + dh, sx = j * g.ssw + dw;
+            const bool in = ok && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            const unsigned xo = (unsigned)((((n * g.Hs + sy) * g.Ws + sx) * g.s_pix + g.s_choff + half * 8) * 2);
+            lds_dma16(rx, dst + (unsigned)((1 + t) * 1024), in ? xo : LF_OOB, 0u);
+        }
+        st_ld = st_ld == W16_STAGES - 1 ? 0 : st_ld + 1;
+    };
+#pragma unroll
+    for (int q = 0; q < W16_STAGES - 1; ++q) issue();
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+    int st_c = 0;
+    for (int it = 0; it < niter; ++it) {
+        // my DMA of this stage has landed (two younger stages of 4 instructions may be in flight); my reads of the stage that is
+        // restaged next have retired.  The ring is private to the wave: no barrier.
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        issue();
+        const unsigned char* st = ring + st_c * W16_STAGE;
+        st_c = st_c == W16_STAGES - 1 ? 0 : st_c + 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const s16x4 gv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + q * 512 + lane * 8));
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const s16x4 xv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + (1 + t) * 1024 + q * 512 + lane * 8));
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xv, gv, acc[t], 0, 0, 0);
+            }
+            bsum += __uint_as_float((unsigned)(unsigned short)gv.x << 16) + __uint_as_float((unsigned)(unsigned short)gv.y << 16) +
+                    __uint_as_float((unsigned)(unsigned short)gv.z << 16) + __uint_as_float((unsigned)(unsigned short)gv.w << 16);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing (dead) stages: nothing may land in LDS after this
+    __shared__ float red[WG_WAVES - 1][NTAPS * 4][64];
+    __shared__ float bred[WG_WAVES][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave - 1][t * 4 + e][lane] = acc[t][e];
+    }
+    bred[wave][lane] = bsum;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            float* out = a.partial + ((long)blockIdx.x * NTAPS + t) * g.Cs * g.Cd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[t][e];
+#pragma unroll
+                for (int w = 0; w < WG_WAVES - 1; ++w) v += red[w][t * 4 + e][lane];
+                out[(long)(4 * kq + e) * g.Cd + pl] = v;          // row = x-channel 4*kq+e, col = g-channel pl
+            }
+        }
+        if (write_bias && a.bias_partial) {
+            float v = bred[0][lane] + bred[1][lane] + bred[2][lane] + bred[3][lane];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0) a.bias_partial[(long)blockIdx.x * g.Cd + pl] = v;
+        }
+    }
+}
+
 struct WgradCfg { int xv, gv, xt, gt, gx, u; long pps; };
 
 WgradCfg wgrad_cfg(const LfTapGeom& g) {
@@ -2734,7 +2859,17 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
     const WgradCfg c = wgrad_cfg(g);
     const int xb = c.xt * 16, gb = c.gt * 16;
     if (g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0) {
-        if (a.s16) hipLaunchKernelGGL((tapwgrad16_kernel<3, true>), dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);
+        if (a.s16 && pro == LF_PRO_NONE && g_bf16_lds == 4 && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
+            (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB && (long)g.N * g.Hd * g.Wd * g.d_pix * 2 < (long)LF_OOB)
+        {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tapwgrad16_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(tapwgrad16_tr_kernel, dim3(c.gx), dim3(256), (size_t)WG_WAVES * W16_STAGES * W16_STAGE, st, g, a, c.pps, wb);
+        }
+        else if (a.s16) hipLaunchKernelGGL((tapwgrad16_kernel<3, true>), dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);
         else hipLaunchKernelGGL((tapwgrad16_kernel<3, false>), dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);
         LF_CHECK_LAUNCH("tapwgrad16");
         return 0;
