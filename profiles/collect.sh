@@ -45,11 +45,20 @@ DB=$(find $OUT/pmc_mfma -name '*_results.db' | head -1)
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_bf16 -o p -- python tools/bf16_ab.py --iters 3 > $OUT/pmc_bf16.log 2>&1
 DB=$(find $OUT/pmc_bf16 -name '*_results.db' | head -1)
 [ -n "$DB" ] && ( echo "# commit $COMMIT  sources digest $DIGEST"; python profiles/summarize_pmc.py "$DB" 3 ) > profiles/${TAG}_pmc_bf16_lds.txt
+# 4c. bf16 config 3 (BASELINE config 3's geometry and dtype): per-kernel trace of the step -> profiles/<tag>_bp_bf16_kernel_stats.txt;
+#     the L2 -> CU access-pattern micro-benchmark behind the whole-line kernels -> profiles/<tag>_l2_stream.txt; the three bf16 kernel
+#     forms on the same launches -> profiles/<tag>_bf16_lds_vs_streaming.txt
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace_bp16 -o bench -- python bench.py --workload bp --precision bf16 --steps 8 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-vendor-baseline > $OUT/trace_bp16.json 2> $OUT/trace_bp16.err
+DB=$(find $OUT/trace_bp16 -name '*_results.db' | head -1)
+[ -n "$DB" ] && ( echo "# commit $COMMIT  sources digest $DIGEST"; python profiles/summarize_rocpd.py "$DB" ) > profiles/${TAG}_bp_bf16_kernel_stats.txt
+[ -x tools/l2_stream ] && ( echo "# commit $COMMIT  (tools/l2_stream.hip; 204800 pixels = 52 MB, then 819200 = 210 MB)"; timeout 60 ./tools/l2_stream 204800; timeout 60 ./tools/l2_stream 819200 ) > profiles/${TAG}_l2_stream.txt 2>&1
+( echo "# commit $COMMIT  sources digest $DIGEST"; timeout 200 python tools/bf16_ab.py --iters 100 ) > profiles/${TAG}_bf16_lds_vs_streaming.txt 2>&1
 # 5. the vendor library on the kernel-level problems (torch conv2d through MIOpen) beside the HIP kernels -> profiles/<tag>_kbench_vs_miopen.txt
 timeout 240 python tools/kbench.py --iters 100 --miopen > profiles/${TAG}_kbench_vs_miopen.txt 2>&1
 # only gpurun_out/ travels back (<= 64 MiB): keep the summaries and logs, drop the databases
 mkdir -p gpurun_out/profiles_$TAG
-cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/${TAG}_pmc_bf16_lds.txt profiles/${TAG}_kbench_vs_miopen.txt profiles/traffic.json gpurun_out/profiles_$TAG/ 2>/dev/null
+cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/${TAG}_pmc_bf16_lds.txt profiles/${TAG}_kbench_vs_miopen.txt \
+   profiles/${TAG}_bp_bf16_kernel_stats.txt profiles/${TAG}_l2_stream.txt profiles/${TAG}_bf16_lds_vs_streaming.txt profiles/traffic.json gpurun_out/profiles_$TAG/ 2>/dev/null
 cp $OUT/*.log $OUT/*.err $OUT/*.json gpurun_out/profiles_$TAG/ 2>/dev/null
 rm -rf $OUT
 head -12 profiles/${TAG}_kernel_stats.txt; cat profiles/traffic.json; tail -3 gpurun_out/profiles_$TAG/*.err gpurun_out/profiles_$TAG/pmc_*.log 2>/dev/null | tail -30
