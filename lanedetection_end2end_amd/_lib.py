@@ -98,6 +98,7 @@ def _declare(lib):
         "lf_debug_set_ops_precision": (None, [I]),
         "lf_debug_conv1d_fwd_phases": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P]),
         "lf_debug_conv1d_wgrad_phases": (I, [P, P, I, I, I, I, I, I, P, P, P]),
+        "lf_debug_conv1d_fwd_pro": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P]),
     }
     for table in (sig, dbg):
         for name, (res, args) in table.items():

@@ -931,7 +931,7 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile(
 // epilogue in the accumulator layout (8 bytes per lane from LDS instead of 32 of every 128-byte line from L2: +40 us per tensor and
 // launch at 80 x 160 x 64 images before).  The residual lands IN the output tile (each lane overwrites what it read); the other
 // two have their own tiles, which come out of the ring's depth: 2 x 80 KB per CU.
-template <int CB, int EPIC> struct WlCfg {
+template <int CB, int EPIC, int PROC = 0> struct WlCfg {
     static constexpr int NT = CB / 2, KS = CB / 2, NSTEP = 3 * KS, CD = CB * 32, PIXB = CD * 2;
     static constexpr int OUT_BYTES = 64 * PIXB;
     static constexpr bool ST_ADD = EPIC >= 0 && (EPIC & LF_EPI_ADD) != 0, ST_MSK = EPIC >= 0 && (EPIC & LF_EPI_MASK) != 0,
@@ -943,13 +943,18 @@ template <int CB, int EPIC> struct WlCfg {
     static constexpr int MAXST = CB == 4 ? 6 : 8;
     static constexpr int FIT = (80 * 1024 - OUT_BYTES * (1 + NBUF)) / WL_STAGE;
     static constexpr int STAGES = FIT < MAXST ? FIT : MAXST;
-    static constexpr size_t LDS = (size_t)STAGES * WL_STAGE + (size_t)OUT_BYTES * (1 + NBUF);
+    static constexpr int TILES_END = STAGES * WL_STAGE + OUT_BYTES * (1 + NBUF);        // the prologue's scale / shift vectors live here
+    static constexpr size_t LDS = (size_t)TILES_END + (PROC ? 2 * CD * 4 : 0);
     static_assert(STAGES >= 3, "ring too shallow");
 };
 
-template <int CB, int EPIC>
+// PROC = 1 (the block's third convolution: its operand is relu(bn1(t2)), never stored): behind its own vmcnt wait and in front of
+// the step's barrier every wave transforms the 16 pixels x 64 channels IT brought in, in place in the stage (fp32 math on the
+// widened values, tapgemm_bf16_kernel's expressions: results bit-identical), so the four waves that read the fragments do not
+// each redo it; padding pixels (zeros from the DMA) are kept zero by the same column / row test that issued them.
+template <int CB, int EPIC, int PROC = 0>
 __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
-    typedef WlCfg<CB, EPIC> C;
+    typedef WlCfg<CB, EPIC, PROC> C;
     constexpr int NT = C::NT, KS = C::KS, NSTEP = C::NSTEP, S = C::STAGES, CD = C::CD, PIXB = C::PIXB, NCH = PIXB / 16;
     constexpr bool S16 = true;
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
@@ -1045,6 +1050,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
 #pragma unroll
     for (int i = 0; i < S - 1; ++i) issue();
 
+    float* const ptab = reinterpret_cast<float*>(lf_tap_lds + C::TILES_END);           // [2][CD]: scale, shift
+    if constexpr (PROC == LF_PRO_BNRELU) {
+        for (int c = threadIdx.x; c < CD; c += 256) { ptab[c] = a.pro_sc[c]; ptab[CD + c] = a.pro_sh[c]; }
+        __syncthreads();
+    }
     // ---- staging of the epilogue's operand tensors: wave w carries group w of the sub-tile (NI instructions of 1 KB per tensor);
     // instruction ii = w * NI + k is bytes ii*1024 .. +1023 of the pixel-major tile: lane -> pixel p, 16-byte slot = chunk XOR p
     // (resources bounded by the tensor: the out-of-range offset of a group beyond it reads zeros)
@@ -1103,13 +1113,42 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
                 // 3 launches at dilation 8, row width 80)
                 if (s >= 1 && s <= S - 1) wait_vm_lgkm0<2 * (S - 2) + C::NAUXI>();
                 else wait_vm_lgkm0<2 * (S - 2)>();
+                const int t = KS == 1 ? s : s >> 1, ks = KS == 1 ? 0 : s & 1;          // (compile-time after unrolling: wr is indexed statically)
+                if constexpr (PROC == LF_PRO_BNRELU) {
+                    // my part of this step's stage has landed: relu(bn(x)) on it, in place (the other waves read it behind the barrier)
+                    unsigned char* mine = ring + st_c * WL_STAGE + wave * 2048;
+                    const int tv = __builtin_amdgcn_readlane(tapv, t);
+                    const int dh = (int)(short)(tv & 0xffff), dw = tv >> 16;
+                    const int gi = wave == 0 ? G.i[0] : wave == 1 ? G.i[1] : wave == 2 ? G.i[2] : G.i[3];
+                    const int gj = wave == 0 ? G.j[0] : wave == 1 ? G.j[1] : wave == 2 ? G.j[2] : G.j[3];
+                    const bool gok = wave == 0 ? G.ok[0] : wave == 1 ? G.ok[1] : wave == 2 ? G.ok[2] : G.ok[3];
+                    const int sy = gi + dh;
+                    const bool yok = gok && sy >= 0 && sy < g.Hs;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const bool in = yok && (unsigned)(gj + dw + lane_dx[jj]) < (unsigned)g.Ws;
+                        const int c0 = ks * 64 + (((lane & 7) ^ ((jj * 4 + (lane >> 4)) & 7)) * 8);      // this lane's 8 channels
+                        u32x4v r = *reinterpret_cast<const u32x4v*>(mine + jj * 1024 + lane * 16);
+                        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ptab + c0), sc1 = *reinterpret_cast<const f32x4*>(ptab + c0 + 4),
+                                    sh0 = *reinterpret_cast<const f32x4*>(ptab + CD + c0), sh1 = *reinterpret_cast<const f32x4*>(ptab + CD + c0 + 4);
+                        f32x4 lo, hv;
+                        lo.x = __uint_as_float(r[0] << 16); lo.y = __uint_as_float(r[0] & 0xffff0000u);
+                        lo.z = __uint_as_float(r[1] << 16); lo.w = __uint_as_float(r[1] & 0xffff0000u);
+                        hv.x = __uint_as_float(r[2] << 16); hv.y = __uint_as_float(r[2] & 0xffff0000u);
+                        hv.z = __uint_as_float(r[3] << 16); hv.w = __uint_as_float(r[3] & 0xffff0000u);
+                        lo = max0(lo * sc0 + sh0); hv = max0(hv * sc1 + sh1);
+                        lo.x = in ? lo.x : 0.f; lo.y = in ? lo.y : 0.f; lo.z = in ? lo.z : 0.f; lo.w = in ? lo.w : 0.f;
+                        hv.x = in ? hv.x : 0.f; hv.y = in ? hv.y : 0.f; hv.z = in ? hv.z : 0.f; hv.w = in ? hv.w : 0.f;
+                        *reinterpret_cast<bf16x8*>(mine + jj * 1024 + lane * 16) = cvt_bf16x8(lo, hv);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my writes are in the stage
+                }
                 __builtin_amdgcn_s_barrier();        // ... and everyone's; everyone is past the fragment reads of the step before
                 asm volatile("" ::: "memory");
                 issue();                             // S - 1 steps ahead -> the stage the previous step occupied
                 if (s == 0) stage_tensors(G);        // (everyone is past the previous sub-tile's reads of the tiles: the barrier above)
                 const unsigned char* st = ring + st_c * WL_STAGE;
                 st_c = st_c == S - 1 ? 0 : st_c + 1;
-                const int t = KS == 1 ? s : s >> 1, ks = KS == 1 ? 0 : s & 1;          // (compile-time after unrolling: wr is indexed statically)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     bf16x8 xb[MT];
@@ -1759,10 +1798,10 @@ void launch_bf16_ring(unsigned nitems, hipStream_t st, const LfTapGeom& g, const
     if (gx > res && res >= 8) gx = res & ~7u;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), ring_lds, st, g, a, pro, epi);
 }
-template <int CBV, int EPIV>
+template <int CBV, int EPIV, int PROV = 0>
 void launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
-    auto kern = tapgemm_bf16_wl_kernel<CBV, EPIV>;
-    const size_t lds = WlCfg<CBV, EPIV>::LDS;
+    auto kern = tapgemm_bf16_wl_kernel<CBV, EPIV, PROV>;
+    const size_t lds = WlCfg<CBV, EPIV, PROV>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
@@ -1877,10 +1916,19 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         // tapgemm_bf16_wl_kernel (whole lines); every other prologue-free launch at 64-channel output slabs whose 16-pixel groups lie
         // in one image row (the 9-tap stride-2 convolution, the transposed-convolution phases, their gradients) ->
         // tapgemm_bf16_ring_kernel; the rest (operand prologue, ragged widths) -> the streaming tapgemm_bf16_kernel
-        const bool wl = fast16 && g_bf16_lds == 4 && !a.dbg && g.ntaps == 3 && g.Cs == g.Cd && (g.Cd == 64 || g.Cd == 128) && g.Wl % 16 == 0 &&
+        // the block's third convolution (BN+ReLU operand prologue), at 128 channels: 83 -> 60 us per launch at config 3's size; at 64
+        // channels the in-LDS transform is as long as the whole step (88 -> 91 us): those stay on the streaming kernel
+        const bool fast16p = nt == 4 && a.s16 && pro == LF_PRO_BNRELU && epi == LF_EPI_RELU && g.Cs == 128 &&
+                             (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB;
+        const bool wl = (fast16 || fast16p) && g_bf16_lds == 4 && !a.dbg && g.ntaps == 3 && g.Cs == g.Cd && (g.Cd == 64 || g.Cd == 128) && g.Wl % 16 == 0 &&
                         g.ssh == 1 && g.ssw == 1 && g.dsh == 1 && g.dsw == 1 && g.dah == 0 && g.daw == 0 && g.Hs == g.Hl && g.Ws == g.Wl &&
                         g.Hd == g.Hl && g.Wd == g.Wl && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
                         (long)g.N * g.Hd * g.Wd * g.d_pix * 2 < (long)LF_OOB;
+        if (wl && fast16p) {        // (128 channels only)
+            launch_bf16_wl<4, LF_EPI_RELU, 1>((unsigned)lf_cdiv(npix, PIX_PER_WG), st, g, a, pro, epi);
+            LF_CHECK_LAUNCH("tapgemm_bf16_wl (prologue)");
+            return 0;
+        }
         if (wl) {
             const unsigned nitems = (unsigned)lf_cdiv(npix, PIX_PER_WG);
 #define LF_TGW(EPIV) do { if (g.Cs == 128) launch_bf16_wl<4, EPIV>(nitems, st, g, a, pro, epi); else launch_bf16_wl<2, EPIV>(nitems, st, g, a, pro, epi); } while (0)

@@ -18,6 +18,10 @@ int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias
                                int axis, int dilation, float* scratch, unsigned long long* dbg, void* stream);
 /* the weight-gradient launch of lf_conv1d_bwd_weight with the same stamps (start, first operands, main loop done, partials
  * stored, HW id); returns the number of waves launched, -1 on error */
+// lf_conv1d_fwd with the BN+ReLU operand prologue and the ReLU epilogue (the third convolution of a non_bottleneck_1d block):
+// y = relu(conv1d(relu(x * sc + sh)) + bias); sc, sh: [C] fp32.  Kernel-level tests of the prologue forms (tests/test_bf16_kernels_gpu.py)
+int lf_debug_conv1d_fwd_pro(const float* x, const float* w, const float* bias, const float* sc, const float* sh, float* y, int N, int H,
+                            int W, int C, int axis, int dilation, float* scratch, void* stream);
 int lf_debug_conv1d_wgrad_phases(const float* x, const float* gy, int N, int H, int W, int C, int axis, int dilation,
                                  float* scratch, unsigned long long* dbg, void* stream);
 #ifdef __cplusplus

@@ -113,6 +113,18 @@ int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias
     return lf_tapgemm_launch(g, a, LF_PRO_NONE, 0, st);
 }
 
+int lf_debug_conv1d_fwd_pro(const float* x, const float* w, const float* bias, const float* sc, const float* sh, float* y, int N, int H,
+                            int W, int C, int axis, int dilation, float* scratch, void* stream) {
+    LF_REQUIRE(x && w && y && sc && sh && scratch, "lf_debug_conv1d_fwd_pro: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    LfTapArgs a;
+    memset(&a, 0, sizeof(a));
+    pack_conv1d(a, w, scratch, C, 3L, 3L * C, 0, st);
+    a.src = x; a.bias = bias; a.dst = y; a.pro_sc = sc; a.pro_sh = sh;
+    return lf_tapgemm_launch(g, a, LF_PRO_BNRELU, LF_EPI_RELU, st);
+}
+
 // the weight gradient of lf_conv1d_bwd_weight (no reduction) with per-wave phase timestamps; returns the number of waves
 int lf_debug_conv1d_wgrad_phases(const float* x, const float* gy, int N, int H, int W, int C, int axis, int dilation,
                                  float* scratch, unsigned long long* dbg, void* stream) {

@@ -28,25 +28,40 @@ def test_lds_dma_kernels_equal_the_streaming_kernel_on_every_launch(shape):
     b = torch.randn(C, device="cuda")
     scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096, device="cuda")
 
+    sc = torch.rand(C, device="cuda") + 0.5
+    sh = torch.randn(C, device="cuda") * 0.5          # relu(0 * sc + sh) != 0: padding must stay zero AFTER the transform
+
     def run(mode):
         lib.lf_debug_set_bf16_lds(mode)
-        y, gx = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        y, gx, yp = (torch.full_like(x, float("nan")) for _ in range(3))
         _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 1, P(scratch), st), "fwd")
         _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), P(x), P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
+        # the BN+ReLU operand prologue form (the whole-line kernel transforms the staged pixels in LDS)
+        _lib.check(lib.lf_debug_conv1d_fwd_pro(P(x), P(w), P(b), P(sc), P(sh), P(yp), N, H, W, C, axis, d, P(scratch), st), "fwd with prologue")
         torch.cuda.synchronize()
-        return y, gx
+        return y, gx, yp
 
     try:
         lib.lf_debug_set_ops_precision(2)
         ref = run(0)
-        assert torch.isfinite(ref[0].float()).all() and torch.isfinite(ref[1].float()).all()
+        assert all(torch.isfinite(r.float()).all() for r in ref)
+        # the prologue reference itself against torch (fp32 math on the bf16 values, bf16-rounded operand, fp32 accumulation)
+        import torch.nn.functional as F
+        xa = torch.relu(x.float() * sc + sh).bfloat16().double().permute(0, 3, 1, 2)
+        w4 = (w.view(C, C, 3, 1) if axis == 0 else w.view(C, C, 1, 3)).bfloat16().double()
+        pad, dil = ((d, 0), (d, 1)) if axis == 0 else ((0, d), (1, d))
+        want = torch.relu(F.conv2d(xa, w4, b.double(), padding=pad, dilation=dil)).permute(0, 2, 3, 1)
+        err = (ref[2].double() - want)
+        # (the kernel rounds relu(fma(x, sc, sh)) to bf16, torch a two-rounding multiply-add: a handful of operands land on the other side
+        # of a bf16 rounding boundary, so the comparison is in norm, not per element)
+        assert float(err.norm() / want.norm()) < 3e-3 and float(err.abs().max()) < 0.03 * float(want.abs().max()), (float(err.norm() / want.norm()), float(err.abs().max()))
         repeats = 12 if N * H * W > 100000 else 40
         for name, mode in (("ring", 2), ("whole-line", 4)):
             bad = []
             for it in range(repeats):
-                y, gx = run(mode)
-                if not (torch.equal(y, ref[0]) and torch.equal(gx, ref[1])):
-                    px = ((y != ref[0]) | (gx != ref[1])).reshape(-1, C).any(1).nonzero().flatten()
+                y, gx, yp = run(mode)
+                if not (torch.equal(y, ref[0]) and torch.equal(gx, ref[1]) and torch.equal(yp, ref[2])):
+                    px = ((y != ref[0]) | (gx != ref[1]) | (yp != ref[2])).reshape(-1, C).any(1).nonzero().flatten()
                     bad.append((it, len(px), int(px[0])))
             assert not bad, "%s kernel, shape %r: launches that differ from the streaming kernel (launch, pixels, first pixel): %r" % (name, shape, bad[:6])
     finally:

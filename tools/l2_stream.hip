@@ -7,6 +7,7 @@
 //   PAT 1: same instruction shape, but quarter-major: all 64 pixels' first quarter, then the second ...   (the LDS rings' K-steps)
 //   PAT 2: instruction = 8 pixels x 128 B  (lane -> pixel l>>3, block l&7): whole lines per instruction
 //   PAT 3: instruction = 4 pixels x 256 B  (lane -> pixel l>>4, block l&15): whole pixels per instruction
+// STORE 1 / 3 / 2: the bf16 epilogue's 8-byte stores / the fp32 epilogue's 16-byte stores of 16 pixels x 64 B / whole lines
 // hipcc -O3 --offload-arch=gfx950 tools/l2_stream.hip -o tools/l2_stream
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -73,6 +74,18 @@ __global__ __launch_bounds__(256, 2) void pull(const void* x, void* y, unsigned*
                 __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)(ob + (unsigned)(((i >> 1) * 8 + (lane >> 3)) * 256 + (i & 1) * 128 + (lane & 7) * 16)), 0, 0);
             }
         }
+        if (STORE == 3) {
+            // the fp32 epilogue's store shape: lane (pl, kq) writes 16 bytes (4 fp32 channels) of pixel m*16 + pl, channel tile n:
+            // 64 bytes of each of 16 lines per instruction
+            const unsigned ob = (tile * 256u + wave * 64) * 256u;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    u32x4v v = {acc.x + (unsigned)m, acc.y + (unsigned)n, acc.z, acc.w};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)(ob + (unsigned)((m * 16 + (lane & 15)) * 256 + n * 64 + (lane >> 4) * 16)), 0, 0);
+                }
+        }
         if (STORE == 1) {
             // the epilogue's store shape: lane (pl, kq) writes 8 bytes (4 bf16 channels) of pixel m*16 + pl, channel tile n
             const unsigned ob = (tile * 256u + wave * 64) * 256u;
@@ -125,6 +138,9 @@ int main(int argc, char** argv) {
         run<0, 2>("16 px x 64 B, consecutive + whole-line 16-byte stores", x, y, sink, npix, grid, 3);
         run<3, 2>("4 px x 256 B + whole-line 16-byte stores", x, y, sink, npix, grid, 3);
         run<2, 2>("8 px x 128 B + whole-line 16-byte stores", x, y, sink, npix, grid, 3);
+        run<0, 3>("16 px x 64 B, consecutive + 16-byte stores of 16 px x 64 B (the fp32 epilogue)", x, y, sink, npix, grid, 3);
+        run<0, 3>("16 px x 64 B, one tap + 16-byte stores of 16 px x 64 B", x, y, sink, npix, grid, 1);
+        run<0, 2>("16 px x 64 B, one tap + whole-line 16-byte stores", x, y, sink, npix, grid, 1);
     }
     return 0;
 }
