@@ -14,12 +14,19 @@
 // fp32 MFMA runs at the vector rate (157 TF), 1/16 of bf16, so one dwordx4 per operand tile per
 // 16 MFMAs (512 cycles) is far below what the load path sustains.
 //
-// Kernels in this file: tapgemm_kernel (fp32 matrix cores, operands streamed L2 -> VGPR; the 64- / 128-channel launches of the
-// tapgemm_lean_kernel (16-channel layers,
-// HBM-bound), tapgemm_bf16_kernel (precision modes bf16_mfma / bf16), tapgemm_split_kernel (modes fp32x9 / fp32x6: fp32
-// results from exact 3-way bf16 splits on the bf16 matrix cores), tapwgrad_kernel / tapwgrad16_kernel / tapwgrad_split_kernel
-// (weight gradients, split-K over pixels), the split-K reductions (one per weight gradient, or batched per backward pass)
-// and the weight-packing kernels.  They share one epilogue (LF_TAPGEMM_EPILOGUE: bias, ReLU, masks, residual, BN sums).
+// Kernels in this file:
+//   tapgemm_kernel            fp32 matrix cores, operands streamed L2 -> VGPR: the 64- / 128-channel launches of the network
+//   tapgemm_lean_kernel       16-channel layers in fp32 (HBM-bound)
+//   tapgemm_split_kernel      precision modes fp32x9 / fp32x6: fp32 results from exact 3-way bf16 splits on the bf16 matrix cores
+//   tapgemm_bf16_kernel       precision modes bf16_mfma / bf16, operands streamed into registers (operand prologue, ragged widths)
+//   tapgemm_bf16_wl_kernel    bf16 tensors, the 3-tap convolutions at 64 / 128 channels: memory touched in whole 128-byte lines
+//                             (LDS-DMA operand ring, weights in registers, LDS-transposed stores)
+//   tapgemm_bf16_ring_kernel  bf16 tensors, every other tap table: persistent LDS-DMA ring
+//   tapgemm_bf16_lean_kernel  bf16 tensors, 16 -> 16 channels (two taps per K = 32 MFMA)
+//   tapwgrad_kernel / tapwgrad16_kernel / tapwgrad16_tr_kernel / tapwgrad_split_kernel   weight gradients, split-K over pixels
+//   the split-K reductions (one per weight gradient, or batched per backward pass) and the weight-packing kernels.
+// The tap-GEMM kernels share one epilogue (LF_TAPGEMM_EPILOGUE: bias, ReLU, masks, residual, BN sums); the whole-line kernel has
+// its own (same arithmetic, output and operand tensors through LDS tiles).
 #include <stdlib.h>
 #include <string.h>
 
@@ -920,7 +927,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
 //  * W: NOT in LDS and not in the ring -- the workgroup's 64 pixels are shared by its four waves, each owning a quarter of the
 //    output channels (wave tile 64 pixels x Cd/4), so a wave's weights are 3 taps x Cs x Cd/4 = 24 KB at 128 channels: 96
 //    REGISTERS per lane, loaded once per persistent workgroup, statically indexed by the fully unrolled K loop.  The LDS
-//    is all ring (6 x 8 KB) + output tile (16 KB): two workgroups per CU with 5 K-steps each in flight.
+//    is ring (4 to 8 stages of 8 KB, by variant) + output tile + the epilogue's operand tiles (WlCfg below) = at most 80 KB: two
+//    workgroups per CU, each with its ring's depth - 1 K-steps in flight.
 // Work item = 256 pixels (the BN-statistics row of the other kernels) as four 64-pixel sub-tiles; the ring runs across
 // sub-tiles and items.  K order = tapgemm_bf16_kernel's (tap, then channel): results bit-identical.
 // ---------------------------------------------------------------------------------------

@@ -7,7 +7,8 @@ extern "C" {
 #endif
 /* 1: the split kernels also take launches below their shipped size rule (kernel-level tests at small shapes) */
 void lf_debug_set_split_any_size(int v);
-/* 0: the bf16-tensor launches take the streaming kernel instead of the LDS-staged one (A/B timing, parity of both forms) */
+/* which bf16-tensor tap-GEMM kernels run: 4 (shipped) whole-line + 16-channel kernels where they apply, else the ring; 2 the ring for
+   every launch it takes; 0 the streaming kernel only (A/B timing, bit-identity of the forms: tools/bf16_ab.py, tests/test_bf16_kernels_gpu.py) */
 void lf_debug_set_bf16_lds(int v);
 /* precision mode of the lf_conv1d_* calls: 0 fp32, 1 bf16 matrix cores on fp32 tensors, 2 bf16 matrix cores on bf16
  * tensors (x, y, gx, gy, mask_src hold bf16; w, bias, gw, gb stay fp32), 9 / 6 fp32 from 3-way split operands */
