@@ -734,7 +734,7 @@ def test_bf16_tensor_mode_kernel_parity():
         # item is partial (9600 / 2880 pixels)
         for (C, H, W, axis, d) in ((128, 16, 32, 0, 4), (64, 24, 40, 1, 2), (16, 32, 64, 1, 1), (16, 32, 64, 0, 1),
                                    (64, 6, 20, 1, 2), (128, 3, 12, 0, 1), (128, 40, 80, 1, 8), (128, 40, 80, 0, 16), (64, 20, 48, 0, 2),
-                                   (64, 20, 48, 1, 16), (16, 20, 48, 1, 2)):
+                                   (64, 20, 48, 1, 16), (16, 20, 48, 1, 2), (16, 37, 16, 0, 1), (16, 37, 16, 1, 1)):      # (37 x 16: an odd number of 16-pixel groups)
             N = 3
             torch.manual_seed(C + axis)
             x = torch.randn(N, H, W, C, device="cuda").bfloat16()
