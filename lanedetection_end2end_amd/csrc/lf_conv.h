@@ -84,6 +84,14 @@ int lf_tapwgrad_bias_rows(const LfTapGeom& g);
 int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro);
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st);
 
+// Read-once weight gradient of the 3-tap C -> C convolutions on bf16 tensors (lf_wgrad_ro.hip; C = 64, 128, stride 1, Wl % 16 == 0):
+// one workgroup owns all taps of a 64-channel x-block against every g-channel for its pixel range.  lf_tapwgrad_launch routes to it.
+bool lf_tapwgrad_ro_ok(const LfTapGeom& g, int s16);
+int lf_tapwgrad_ro_rows_bound(const LfTapGeom& g);     // partial rows at the shipped workgroup caps (buffer sizing; 0 = geometry not taken)
+int lf_tapwgrad_ro_rows(const LfTapGeom& g);           // rows the launch writes ([rows][3][C][C] fp32 + [rows][C] bias rows)
+int lf_tapwgrad_ro_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st);
+void lf_tapwgrad_ro_set(int mode, int cap64, int cap128);   // tools / A-B runs: 0 = off; workgroups per launch at 64 / 128 channels
+
 // dst[k*sk + n*sn + tapidx[t]] = sum_s partial[s][t][k][n]
 // ... and, in the same launch, bias_grad[n] (+)= sum_r bias_rows[r][n] when bias_rows != null
 int lf_wgrad_reduce_launch(const float* partial, int splits, int ntaps, int Cs, int Cd, float* grad, long sk, long sn,

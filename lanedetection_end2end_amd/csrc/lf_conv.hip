@@ -36,6 +36,7 @@
 #include <hip/hip_ext.h>
 
 #include "lf_conv.h"
+#include "lf_ldsdma.h"
 #include "lf_types.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -57,7 +58,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 __device__ __forceinline__ f32x4 ldb4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
-constexpr unsigned LF_OOB = 0xffff0000u;      // byte offset beyond every tensor the launcher admits (< 4 GiB - 64 KiB)
+// (LF_OOB, the byte offset beyond every tensor the launcher admits, lives in lf_ldsdma.h)
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 // ReLU as a signed-integer maximum of the bit patterns (negative floats are negative integers): ONE v_max_i32 per element;
 // fmaxf compiles to a canonicalising v_max_f32 v, v, v followed by the v_max_f32 with 0 -- twice the VALU work in the BN+ReLU
@@ -689,26 +690,7 @@ constexpr int LB_X_BYTES = WG_WAVES * 64 * 64;          // 16 KB
 constexpr int LB_W_BYTES = 4 * 64 * 16;                 // 4 KB
 constexpr int LB_STAGE_BYTES = LB_X_BYTES + LB_W_BYTES;
 
-// One LDS-DMA instruction: 64 lanes x 16 bytes, lane-linear at LDS byte address `lds_addr` (wave-uniform, through M0).
-// Inline asm on purpose: with the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc tracks the asynchronous LDS writes and
-// puts s_waitcnt vmcnt(0) in front of the first LDS read that may alias them -- every K-step, which drains the ring and leaves
-// ONE step in flight; __syncthreads() does the same through its release fence.  The ring is ordered by the explicit
-// s_waitcnt vmcnt(N) + bare s_barrier below instead.  (Compiler-issued waits stay correct: they can only over-wait.)
-typedef int i32x4s __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void lds_dma16(i32x4s rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    // (s_nop 0: the wait state between the SALU write of M0 and the LDS-DMA instruction that reads it -- nothing pads the inside of
-    // an asm string)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ i32x4s make_rsrc_words(const void* base, unsigned bytes) {
-    const unsigned long long ad = (unsigned long long)base;
-    i32x4s r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ad);
-    r.y = __builtin_amdgcn_readfirstlane((int)((ad >> 32) & 0xffffu));       // stride 0, no swizzle
-    r.z = (int)bytes;
-    r.w = 0x00020000;
-    return r;
-}
+// (lds_dma16, make_rsrc_words, wait_vm_lgkm0: lf_ldsdma.h)
 
 // ---------------------------------------------------------------------------------------
 // tapgemm_bf16_ring_kernel: LDS-staged bf16 tap-GEMM for ANY tap table (the 9-tap stride-2 convolution, the transposed-convolution
@@ -933,7 +915,6 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
 // sub-tiles and items.  K order = tapgemm_bf16_kernel's (tap, then channel): results bit-identical.
 // ---------------------------------------------------------------------------------------
 constexpr int WL_STAGE = 64 * 128;
-template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 // Epilogue operand tensors (the data gradient's ReLU-mask source, residual gradient, BN-backward operand) come in whole lines too: by
 // LDS-DMA into tiles of the output tile's layout, issued behind the first K-step of the sub-tile they belong to and read by the
 // epilogue in the accumulator layout (8 bytes per lane from LDS instead of 32 of every 128-byte line from L2: +40 us per tensor and
@@ -2890,10 +2871,12 @@ WgradCfg wgrad_split_cfg(const LfTapGeom& g) {
 int lf_tapwgrad_splits(const LfTapGeom& g) {
     const int a = wgrad_cfg(g).gx;
     const int b = wgrad_split_ok(g, nullptr, LF_PRO_NONE) ? wgrad_split_cfg(g).gx : 0;
-    return a > b ? a : b;                                   // sizes the partial rows for either kernel
+    const int c = lf_tapwgrad_ro_rows_bound(g);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);       // sizes the partial rows for any of the kernels
 }
 int lf_tapwgrad_bias_rows(const LfTapGeom& g) { return lf_tapwgrad_splits(g); }
 int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro) {
+    if (lf_tapwgrad_ro_ok(g, a.s16) && !a.dbg) return lf_tapwgrad_ro_rows(g);
     return wgrad_split_ok(g, &a, pro) ? wgrad_split_cfg(g).gx : wgrad_cfg(g).gx;
 }
 
@@ -2902,6 +2885,7 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
     LF_REQUIRE(g.Wl % 4 == 0, "tapwgrad: logical width %d must be a multiple of 4", g.Wl);
     LF_REQUIRE((long)g.N * g.Hs * g.Ws * g.s_pix < (long)(LF_OOB >> 2) && (long)g.N * g.Hd * g.Wd * g.d_pix < (long)(LF_OOB >> 2),
                "tapwgrad: tensor too large for 32-bit byte offsets");
+    if (lf_tapwgrad_ro_ok(g, a.s16) && !a.dbg) return lf_tapwgrad_ro_launch(g, a, pro, st);     // bf16 tensors, 3 taps, 64 / 128 channels
     const int wb = a.bias_partial != nullptr;
     if (wgrad_split_ok(g, &a, pro)) {
         LF_REQUIRE(a.split == 9 || a.split == 6, "tapwgrad: split must be 9 or 6 (got %d)", a.split);

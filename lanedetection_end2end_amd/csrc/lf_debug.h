@@ -23,6 +23,13 @@ int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias
 // y = relu(conv1d(relu(x * sc + sh)) + bias); sc, sh: [C] fp32.  Kernel-level tests of the prologue forms (tests/test_bf16_kernels_gpu.py)
 int lf_debug_conv1d_fwd_pro(const float* x, const float* w, const float* bias, const float* sc, const float* sh, float* y, int N, int H,
                             int W, int C, int axis, int dilation, float* scratch, void* stream);
+/* the read-once bf16 weight gradient (lf_wgrad_ro.hip): mode 0 = off (tapwgrad_kernel's job form takes every launch), 1 = shipped;
+ * cap64 / cap128 > 0: workgroups per launch at 64 / 128 channels (A/B runs; at most the shipped 512 / 256 the buffers are sized for) */
+void lf_debug_set_wgrad_ro(int mode, int cap64, int cap128);
+/* lf_conv1d_bwd_weight with the BN+ReLU operand prologue on x (the weight gradient of a non_bottleneck_1d block's third convolution):
+ * gw = d/dw of conv1d(relu(x * sc + sh)), gb = column sums of gy */
+int lf_debug_conv1d_wgrad_pro(const float* x, const float* gy, const float* sc, const float* sh, float* gw, float* gb, int N, int H, int W,
+                              int C, int axis, int dilation, float* scratch, void* stream);
 int lf_debug_conv1d_wgrad_phases(const float* x, const float* gy, int N, int H, int W, int C, int axis, int dilation,
                                  float* scratch, unsigned long long* dbg, void* stream);
 #ifdef __cplusplus

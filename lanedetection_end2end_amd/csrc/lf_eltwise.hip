@@ -20,22 +20,29 @@ __device__ __forceinline__ f32x4 pos4(f32x4 v, f32x4 m) {
     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f; return v;
 }
 
-// Reduce per-thread (a1,a2) over all threads sharing the same channel quad (tid % Q); thread tid < Q
-// ends up with the block totals.  256 threads, Q a power of two dividing 256.
-__device__ __forceinline__ void block_reduce_quads(f32x4& a1, f32x4& a2, int Q, float (*sm)[8]) {
+// Reduce per-thread (a1,a2) over all threads sharing the same channel group (tid % U); thread tid < U
+// ends up with the block totals.  256 threads, U a power of two dividing 256; NQ channel quads per thread.
+template <int NQ>
+__device__ __forceinline__ void block_reduce_quads(f32x4 (&a1)[NQ], f32x4 (&a2)[NQ], int U, float (*sm)[8 * NQ]) {
     const int tid = threadIdx.x;
-    sm[tid][0] = a1.x; sm[tid][1] = a1.y; sm[tid][2] = a1.z; sm[tid][3] = a1.w;
-    sm[tid][4] = a2.x; sm[tid][5] = a2.y; sm[tid][6] = a2.z; sm[tid][7] = a2.w;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        sm[tid][8 * q + 0] = a1[q].x; sm[tid][8 * q + 1] = a1[q].y; sm[tid][8 * q + 2] = a1[q].z; sm[tid][8 * q + 3] = a1[q].w;
+        sm[tid][8 * q + 4] = a2[q].x; sm[tid][8 * q + 5] = a2[q].y; sm[tid][8 * q + 6] = a2[q].z; sm[tid][8 * q + 7] = a2[q].w;
+    }
     __syncthreads();
-    for (int s = 128; s >= Q; s >>= 1) {
+    for (int s = 128; s >= U; s >>= 1) {
         if (tid < s) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sm[tid][j] += sm[tid + s][j];
+            for (int j = 0; j < 8 * NQ; ++j) sm[tid][j] += sm[tid + s][j];
         }
         __syncthreads();
     }
-    a1.x = sm[tid][0]; a1.y = sm[tid][1]; a1.z = sm[tid][2]; a1.w = sm[tid][3];
-    a2.x = sm[tid][4]; a2.y = sm[tid][5]; a2.z = sm[tid][6]; a2.w = sm[tid][7];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        a1[q].x = sm[tid][8 * q + 0]; a1[q].y = sm[tid][8 * q + 1]; a1[q].z = sm[tid][8 * q + 2]; a1[q].w = sm[tid][8 * q + 3];
+        a2[q].x = sm[tid][8 * q + 4]; a2[q].y = sm[tid][8 * q + 5]; a2[q].z = sm[tid][8 * q + 6]; a2[q].w = sm[tid][8 * q + 7];
+    }
 }
 
 struct StatParts { LfStatPart p[2]; int n; };
@@ -109,48 +116,84 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(StatParts sp, int 
     }
 }
 
-template <typename T>
+// NQ channel quads per thread (lf_ldq: 16 bytes per lane for either storage type); U = threads per pixel = C / (4 NQ)
+template <typename T, int NQ>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, const float* __restrict__ sc,
                                                     const float* __restrict__ sh, const float* __restrict__ dm,
                                                     const T* __restrict__ res, T* __restrict__ y, long units,
-                                                    int Q, long pix_per_image) {
-    const int C = Q * 4;
+                                                    int U, long pix_per_image) {
+    constexpr int V = 4 * NQ;
+    const int C = U * V;
     for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
-        const int c = (int)(u % Q) * 4;
-        f32x4 v = lf_ldv(x + u * 4) * ld4(sc + c) + ld4(sh + c);
-        if (dm) v *= ld4(dm + ((u / Q) / pix_per_image) * C + c);
-        if (res) v += lf_ldv(res + u * 4);
-        lf_stv(y + u * 4, relu4(v));
+        const int c = (int)(u % U) * V;
+        f32x4 v[NQ];
+        lf_ldq<T, NQ>(x + u * V, v);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = v[q] * ld4(sc + c + 4 * q) + ld4(sh + c + 4 * q);
+        if (dm) {
+            const float* d = dm + ((u / U) / pix_per_image) * C + c;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v[q] *= ld4(d + 4 * q);
+        }
+        if (res) {
+            f32x4 r[NQ];
+            lf_ldq<T, NQ>(res + u * V, r);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v[q] += r[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = relu4(v[q]);
+        lf_stq<T, NQ>(y + u * V, v);
     }
 }
 
-template <typename T>
+template <typename T, int NQ>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                            const T* __restrict__ t, const float* __restrict__ asc,
                                                            const float* __restrict__ ash, const float* __restrict__ dm,
-                                                           float* __restrict__ rows, long npix, int Q, long pix_per_image) {
-    const int C = Q * 4, ppi = 256 / Q;
-    const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
-    const int c = cq * 4;
+                                                           float* __restrict__ rows, long npix, int U, long pix_per_image) {
+    constexpr int V = 4 * NQ;
+    const int C = U * V, ppi = 256 / U;
+    const int cq = threadIdx.x % U, pr = threadIdx.x / U;
+    const int c = cq * V;
     (void)asc; (void)ash;
-    f32x4 a1 = z4(), a2 = z4();
+    f32x4 a1[NQ], a2[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { a1[q] = z4(); a2[q] = z4(); }
     const long per_block = ((npix + gridDim.x - 1) / gridDim.x + ppi - 1) / ppi * ppi;
     const long p0 = (long)blockIdx.x * per_block;
     long p1 = p0 + per_block;
     if (p1 > npix) p1 = npix;
     for (long p = p0 + pr; p < p1; p += ppi) {
         const long off = p * C + c;
-        f32x4 gm = lf_ldv(g + off);
-        if (y) gm = pos4(gm, lf_ldv(y + off));
-        if (dm) gm *= ld4(dm + (p / pix_per_image) * C + c);
-        a1 += gm;
-        a2 += gm * lf_ldv(t + off);          // RAW: bn_bwd_finalize_kernel applies the normalisation in fp64
+        f32x4 gm[NQ], tv[NQ];
+        lf_ldq<T, NQ>(g + off, gm);
+        lf_ldq<T, NQ>(t + off, tv);
+        if (y) {
+            f32x4 yv[NQ];
+            lf_ldq<T, NQ>(y + off, yv);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) gm[q] = pos4(gm[q], yv[q]);
+        }
+        if (dm) {
+            const float* d = dm + (p / pix_per_image) * C + c;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) gm[q] *= ld4(d + 4 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            a1[q] += gm[q];
+            a2[q] += gm[q] * tv[q];          // RAW: bn_bwd_finalize_kernel applies the normalisation in fp64
+        }
     }
-    __shared__ float sm[256][8];
-    block_reduce_quads(a1, a2, Q, sm);
-    if (threadIdx.x < Q) {
-        st4(rows + ((long)blockIdx.x * 2 + 0) * C + c, a1);
-        st4(rows + ((long)blockIdx.x * 2 + 1) * C + c, a2);
+    __shared__ float sm[256][8 * NQ];
+    block_reduce_quads<NQ>(a1, a2, U, sm);
+    if (threadIdx.x < U) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            st4(rows + ((long)blockIdx.x * 2 + 0) * C + c + 4 * q, a1[q]);
+            st4(rows + ((long)blockIdx.x * 2 + 1) * C + c + 4 * q, a2[q]);
+        }
     }
 }
 
@@ -182,90 +225,119 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int 
     }
 }
 
-template <typename T>
+template <typename T, int NQ>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                           const T* __restrict__ t, const float* __restrict__ asc,
                                                           const float* __restrict__ ash, const float* __restrict__ gamma,
                                                           const float* __restrict__ c1, const float* __restrict__ c2,
                                                           const float* __restrict__ dm, T* __restrict__ g_t,
-                                                          T* __restrict__ g_z, long units, int Q, long pix_per_image) {
-    const int C = Q * 4;
+                                                          T* __restrict__ g_z, long units, int U, long pix_per_image) {
+    constexpr int V = 4 * NQ;
+    const int C = U * V;
     for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
-        const int c = (int)(u % Q) * 4;
-        f32x4 gm = lf_ldv(g + u * 4);
-        if (y) gm = pos4(gm, lf_ldv(y + u * 4));
-        if (g_z) lf_stv(g_z + u * 4, gm);
-        if (dm) gm *= ld4(dm + ((u / Q) / pix_per_image) * C + c);
-        const f32x4 rstd = ld4(asc + c);
-        const f32x4 xh = lf_ldv(t + u * 4) * rstd + ld4(ash + c);
-        lf_stv(g_t + u * 4, ld4(gamma + c) * rstd * (gm - ld4(c1 + c) - xh * ld4(c2 + c)));
+        const int c = (int)(u % U) * V;
+        f32x4 gm[NQ], tv[NQ];
+        lf_ldq<T, NQ>(g + u * V, gm);
+        lf_ldq<T, NQ>(t + u * V, tv);
+        if (y) {
+            f32x4 yv[NQ];
+            lf_ldq<T, NQ>(y + u * V, yv);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) gm[q] = pos4(gm[q], yv[q]);
+        }
+        if (g_z) lf_stq<T, NQ>(g_z + u * V, gm);
+        if (dm) {
+            const float* d = dm + ((u / U) / pix_per_image) * C + c;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) gm[q] *= ld4(d + 4 * q);
+        }
+        f32x4 o[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 rstd = ld4(asc + c + 4 * q);
+            const f32x4 xh = tv[q] * rstd + ld4(ash + c + 4 * q);
+            o[q] = ld4(gamma + c + 4 * q) * rstd * (gm[q] - ld4(c1 + c + 4 * q) - xh * ld4(c2 + c + 4 * q));
+        }
+        lf_stq<T, NQ>(g_t + u * V, o);
     }
 }
 
 // ---- max-pool branch of DownsamplerBlock ------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int Q,
+template <typename T, int NQ>
+__global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int U,
                                                              T* __restrict__ cat, int cat_pix, int choff,
                                                              float* __restrict__ rows) {
-    const int C = Q * 4, ppi = 256 / Q, Ho = H / 2, Wo = W / 2;
-    const int cq = threadIdx.x % Q, pr = threadIdx.x / Q, c = cq * 4;
+    constexpr int V = 4 * NQ;
+    const int C = U * V, ppi = 256 / U, Ho = H / 2, Wo = W / 2;
+    const int cq = threadIdx.x % U, pr = threadIdx.x / U, c = cq * V;
     const long npix = (long)N * Ho * Wo;
     const long per_block = ((npix + gridDim.x - 1) / gridDim.x + ppi - 1) / ppi * ppi;
     const long p0 = (long)blockIdx.x * per_block;
     long p1 = p0 + per_block;
     if (p1 > npix) p1 = npix;
-    f32x4 a1 = z4(), a2 = z4();
+    f32x4 a1[NQ], a2[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { a1[q] = z4(); a2[q] = z4(); }
     for (long p = p0 + pr; p < p1; p += ppi) {
         const int ow = (int)(p % Wo);
         const long r = p / Wo;
         const int oh = (int)(r % Ho), n = (int)(r / Ho);
         const T* b = x + (((long)n * H + 2 * oh) * W + 2 * ow) * C + c;
-        f32x4 v = lf_ldv(b);
-        f32x4 u = lf_ldv(b + C);
-        v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
-        u = lf_ldv(b + (long)W * C);
-        v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
-        u = lf_ldv(b + (long)W * C + C);
-        v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
-        lf_stv(cat + p * cat_pix + choff + c, v);
-        a1 += v;
-        a2 += v * v;
+        f32x4 v[NQ], u1[NQ], u2[NQ], u3[NQ];
+        lf_ldq<T, NQ>(b, v);
+        lf_ldq<T, NQ>(b + C, u1);
+        lf_ldq<T, NQ>(b + (long)W * C, u2);
+        lf_ldq<T, NQ>(b + (long)W * C + C, u3);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(fmaxf(fmaxf(v[q][e], u1[q][e]), u2[q][e]), u3[q][e]);
+            a1[q] += v[q];
+            a2[q] += v[q] * v[q];
+        }
+        lf_stq<T, NQ>(cat + p * cat_pix + choff + c, v);
     }
-    __shared__ float sm[256][8];
-    block_reduce_quads(a1, a2, Q, sm);
-    if (rows && threadIdx.x < Q) {
-        st4(rows + ((long)blockIdx.x * 2 + 0) * C + c, a1);
-        st4(rows + ((long)blockIdx.x * 2 + 1) * C + c, a2);
+    __shared__ float sm[256][8 * NQ];
+    block_reduce_quads<NQ>(a1, a2, U, sm);
+    if (rows && threadIdx.x < U) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            st4(rows + ((long)blockIdx.x * 2 + 0) * C + c + 4 * q, a1[q]);
+            st4(rows + ((long)blockIdx.x * 2 + 1) * C + c + 4 * q, a2[q]);
+        }
     }
 }
 
-template <typename T>
+template <typename T, int NQ>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gcat, int N,
-                                                      int H, int W, int Q, int cat_pix, int choff, T* __restrict__ gx) {
-    const int C = Q * 4, Ho = H / 2, Wo = W / 2;
-    const long units = (long)N * Ho * Wo * Q;
+                                                      int H, int W, int U, int cat_pix, int choff, T* __restrict__ gx) {
+    constexpr int V = 4 * NQ;
+    const int C = U * V, Ho = H / 2, Wo = W / 2;
+    const long units = (long)N * Ho * Wo * U;
     for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
-        const int c = (int)(u % Q) * 4;
-        const long p = u / Q;
+        const int c = (int)(u % U) * V;
+        const long p = u / U;
         const int ow = (int)(p % Wo);
         const long r = p / Wo;
         const int oh = (int)(r % Ho), n = (int)(r / Ho);
         const long base = (((long)n * H + 2 * oh) * W + 2 * ow) * C + c;
         const long o1 = C, o2 = (long)W * C, o3 = (long)W * C + C;
-        const f32x4 v0 = lf_ldv(x + base), v1 = lf_ldv(x + base + o1), v2 = lf_ldv(x + base + o2), v3 = lf_ldv(x + base + o3);
-        const f32x4 g = lf_ldv(gcat + p * cat_pix + choff + c);
-        f32x4 r0 = z4(), r1 = z4(), r2 = z4(), r3 = z4();
+        f32x4 v0[NQ], v1[NQ], v2[NQ], v3[NQ], g[NQ], r0[NQ], r1[NQ], r2[NQ], r3[NQ];
+        lf_ldq<T, NQ>(x + base, v0); lf_ldq<T, NQ>(x + base + o1, v1); lf_ldq<T, NQ>(x + base + o2, v2); lf_ldq<T, NQ>(x + base + o3, v3);
+        lf_ldq<T, NQ>(gcat + p * cat_pix + choff + c, g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {   // first maximum in window scan order wins (strict >), as ATen's max_pool2d
-            int arg = 0;
-            float m = v0[e];
-            if (v1[e] > m) { m = v1[e]; arg = 1; }
-            if (v2[e] > m) { m = v2[e]; arg = 2; }
-            if (v3[e] > m) { m = v3[e]; arg = 3; }
-            r0[e] = arg == 0 ? g[e] : 0.f; r1[e] = arg == 1 ? g[e] : 0.f;
-            r2[e] = arg == 2 ? g[e] : 0.f; r3[e] = arg == 3 ? g[e] : 0.f;
-        }
-        lf_stv(gx + base, r0); lf_stv(gx + base + o1, r1); lf_stv(gx + base + o2, r2); lf_stv(gx + base + o3, r3);
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // first maximum in window scan order wins (strict >), as ATen's max_pool2d
+                int arg = 0;
+                float m = v0[q][e];
+                if (v1[q][e] > m) { m = v1[q][e]; arg = 1; }
+                if (v2[q][e] > m) { m = v2[q][e]; arg = 2; }
+                if (v3[q][e] > m) { m = v3[q][e]; arg = 3; }
+                r0[q][e] = arg == 0 ? g[q][e] : 0.f; r1[q][e] = arg == 1 ? g[q][e] : 0.f;
+                r2[q][e] = arg == 2 ? g[q][e] : 0.f; r3[q][e] = arg == 3 ? g[q][e] : 0.f;
+            }
+        lf_stq<T, NQ>(gx + base, r0); lf_stq<T, NQ>(gx + base + o1, r1); lf_stq<T, NQ>(gx + base + o2, r2); lf_stq<T, NQ>(gx + base + o3, r3);
     }
 }
 
@@ -541,10 +613,13 @@ inline int grid_for(long units, int cap) {
     return (int)g;
 }
 inline bool quad_ok(int C) { return C % 4 == 0 && 256 % (C / 4) == 0; }
+// bf16 storage with 8-channel groups (16 bytes per lane): every offset the kernels form must be a multiple of 8 elements
+inline bool oct_ok(int s16, int C) { return s16 && C % 8 == 0 && 256 % (C / 8) == 0; }
 // activation pointers travel as float* through the host code; s16 says they hold bf16 elements
 template <typename T> inline const T* as(const float* p) { return reinterpret_cast<const T*>(p); }
 template <typename T> inline T* as(float* p) { return reinterpret_cast<T*>(p); }
 #define LF_BY_STORAGE(s16, CALL_BF16, CALL_F32) do { if (s16) { CALL_BF16; } else { CALL_F32; } } while (0)
+#define LF_BY_STORAGE3(s16, oct, CALL_BF16X8, CALL_BF16, CALL_F32) do { if (oct) { CALL_BF16X8; } else if (s16) { CALL_BF16; } else { CALL_F32; } } while (0)
 
 }  // namespace
 
@@ -565,11 +640,14 @@ int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count,
 int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm, const float* res, float* y, long npix,
               int C, long pix_per_image, int s16, hipStream_t st) {
     LF_REQUIRE(C % 4 == 0, "bn_act: C %% 4");
-    const long units = npix * (C / 4);
+    const bool oct = oct_ok(s16, C);
+    const int V = oct ? 8 : 4;
+    const long units = npix * (C / V);
     const dim3 grid(grid_for(units, LF_STREAM_BLOCKS));
-    LF_BY_STORAGE(s16,
-        hipLaunchKernelGGL(bn_act_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(x), sc, sh, dm, as<lf_bf16>(res), as<lf_bf16>(y), units, C / 4, pix_per_image),
-        hipLaunchKernelGGL(bn_act_kernel<float>, grid, dim3(256), 0, st, x, sc, sh, dm, res, y, units, C / 4, pix_per_image));
+    LF_BY_STORAGE3(s16, oct,
+        hipLaunchKernelGGL((bn_act_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(x), sc, sh, dm, as<lf_bf16>(res), as<lf_bf16>(y), units, C / V, pix_per_image),
+        hipLaunchKernelGGL((bn_act_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(x), sc, sh, dm, as<lf_bf16>(res), as<lf_bf16>(y), units, C / V, pix_per_image),
+        hipLaunchKernelGGL((bn_act_kernel<float, 1>), grid, dim3(256), 0, st, x, sc, sh, dm, res, y, units, C / V, pix_per_image));
     LF_CHECK_LAUNCH("bn_act");
     return 0;
 }
@@ -580,9 +658,12 @@ int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float
                      float* rows, long npix, int C, long pix_per_image, int s16, hipStream_t st) {
     LF_REQUIRE(quad_ok(C), "bn_bwd_reduce: unsupported channel count %d", C);
     const dim3 grid(lf_bn_bwd_reduce_rows(npix));
-    LF_BY_STORAGE(s16,
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, dm, rows, npix, C / 4, pix_per_image),
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, g, y, t, asc, ash, dm, rows, npix, C / 4, pix_per_image));
+    const bool oct = oct_ok(s16, C);
+    const int V = oct ? 8 : 4;
+    LF_BY_STORAGE3(s16, oct,
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, dm, rows, npix, C / V, pix_per_image),
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, dm, rows, npix, C / V, pix_per_image),
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), grid, dim3(256), 0, st, g, y, t, asc, ash, dm, rows, npix, C / V, pix_per_image));
     LF_CHECK_LAUNCH("bn_bwd_reduce");
     return 0;
 }
@@ -604,11 +685,14 @@ int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float*
                     const float* c1, const float* c2, const float* dm, float* g_t, float* g_z, long npix, int C,
                     long pix_per_image, int s16, hipStream_t st) {
     LF_REQUIRE(C % 4 == 0, "bn_bwd_apply: C %% 4");
-    const long units = npix * (C / 4);
+    const bool oct = oct_ok(s16, C);
+    const int V = oct ? 8 : 4;
+    const long units = npix * (C / V);
     const dim3 grid(grid_for(units, LF_STREAM_BLOCKS));
-    LF_BY_STORAGE(s16,
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, gamma, c1, c2, dm, as<lf_bf16>(g_t), as<lf_bf16>(g_z), units, C / 4, pix_per_image),
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, g, y, t, asc, ash, gamma, c1, c2, dm, g_t, g_z, units, C / 4, pix_per_image));
+    LF_BY_STORAGE3(s16, oct,
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, gamma, c1, c2, dm, as<lf_bf16>(g_t), as<lf_bf16>(g_z), units, C / V, pix_per_image),
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, gamma, c1, c2, dm, as<lf_bf16>(g_t), as<lf_bf16>(g_z), units, C / V, pix_per_image),
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1>), grid, dim3(256), 0, st, g, y, t, asc, ash, gamma, c1, c2, dm, g_t, g_z, units, C / V, pix_per_image));
     LF_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
 }
@@ -620,20 +704,26 @@ int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat,
     LF_REQUIRE(quad_ok(Cin) && H % 2 == 0 && W % 2 == 0, "pool_concat: unsupported shape");
     const long npo = (long)N * (H / 2) * (W / 2);
     const dim3 grid(lf_pool_rows(npo));
-    LF_BY_STORAGE(s16,
-        hipLaunchKernelGGL(pool_concat_fwd_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(x), N, H, W, Cin / 4, as<lf_bf16>(cat), cat_pix, choff, rows),
-        hipLaunchKernelGGL(pool_concat_fwd_kernel<float>, grid, dim3(256), 0, st, x, N, H, W, Cin / 4, cat, cat_pix, choff, rows));
+    const bool oct = oct_ok(s16, Cin) && cat_pix % 8 == 0 && choff % 8 == 0;
+    const int V = oct ? 8 : 4;
+    LF_BY_STORAGE3(s16, oct,
+        hipLaunchKernelGGL((pool_concat_fwd_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(x), N, H, W, Cin / V, as<lf_bf16>(cat), cat_pix, choff, rows),
+        hipLaunchKernelGGL((pool_concat_fwd_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(x), N, H, W, Cin / V, as<lf_bf16>(cat), cat_pix, choff, rows),
+        hipLaunchKernelGGL((pool_concat_fwd_kernel<float, 1>), grid, dim3(256), 0, st, x, N, H, W, Cin / V, cat, cat_pix, choff, rows));
     LF_CHECK_LAUNCH("pool_concat_fwd");
     return 0;
 }
 
 int lf_pool_bwd(const float* x, const float* gcat, int N, int H, int W, int Cin, int cat_pix, int choff, float* gx,
                 int s16, hipStream_t st) {
-    const long units = (long)N * (H / 2) * (W / 2) * (Cin / 4);
+    const bool oct = oct_ok(s16, Cin) && cat_pix % 8 == 0 && choff % 8 == 0;
+    const int V = oct ? 8 : 4;
+    const long units = (long)N * (H / 2) * (W / 2) * (Cin / V);
     const dim3 grid(grid_for(units, 4096));
-    LF_BY_STORAGE(s16,
-        hipLaunchKernelGGL(pool_bwd_kernel<lf_bf16>, grid, dim3(256), 0, st, as<lf_bf16>(x), as<lf_bf16>(gcat), N, H, W, Cin / 4, cat_pix, choff, as<lf_bf16>(gx)),
-        hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, st, x, gcat, N, H, W, Cin / 4, cat_pix, choff, gx));
+    LF_BY_STORAGE3(s16, oct,
+        hipLaunchKernelGGL((pool_bwd_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(x), as<lf_bf16>(gcat), N, H, W, Cin / V, cat_pix, choff, as<lf_bf16>(gx)),
+        hipLaunchKernelGGL((pool_bwd_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(x), as<lf_bf16>(gcat), N, H, W, Cin / V, cat_pix, choff, as<lf_bf16>(gx)),
+        hipLaunchKernelGGL((pool_bwd_kernel<float, 1>), grid, dim3(256), 0, st, x, gcat, N, H, W, Cin / V, cat_pix, choff, gx));
     LF_CHECK_LAUNCH("pool_bwd");
     return 0;
 }

@@ -100,6 +100,8 @@ void lf_debug_set_bf16_lds(int v) { lf_tapgemm_set_bf16_lds(v); }
 // 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src then hold bf16 elements; w, bias, gw, gb stay fp32)
 void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = mode; }
 
+void lf_debug_set_wgrad_ro(int mode, int cap64, int cap128) { lf_tapwgrad_ro_set(mode, cap64, cap128); }
+
 // same as lf_conv1d_fwd with per-wave phase timestamps: dbg receives 8 uint64 per wave
 // (start, tap table built, main loop done, stores retired); waves = ceil(N*H*W/256)*4*(C/64)
 int lf_debug_conv1d_fwd_phases(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C,
@@ -170,22 +172,35 @@ int lf_conv1d_bwd_data(const float* gy, const float* w, const float* mask_src, f
     return lf_tapgemm_launch(g, a, LF_PRO_NONE, mask_src ? LF_EPI_MASK : 0, st);
 }
 
+namespace {
+int conv1d_bwd_weight(const float* x, const float* gy, const float* sc, const float* sh, float* gw, float* gb, int N, int H, int W, int C,
+                      int axis, int dilation, float* scratch, hipStream_t st) {
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    const int pro = sc ? LF_PRO_BNRELU : LF_PRO_NONE;
+    LfWgradArgs a;
+    a.x = x; a.g = gy; a.pro_sc = sc; a.pro_sh = sh; a.s16 = g_ops_bf16 == 2;
+    a.split = (g_ops_bf16 == 9 || g_ops_bf16 == 6) ? g_ops_bf16 : 0;
+    a.partial = scratch;
+    a.bias_partial = gb ? scratch + (long)lf_tapwgrad_splits(g) * 3 * C * C : nullptr;
+    int rc = lf_tapwgrad_launch(g, a, pro, st);
+    if (rc) return rc;
+    const int idx[3] = {0, 1, 2};
+    const int nsplit = lf_tapwgrad_splits_for(g, a, pro);
+    return lf_wgrad_reduce_launch(a.partial, nsplit, 3, C, C, gw, 3L, 3L * C, idx, a.bias_partial, nsplit, gb, 0, st);
+}
+}  // namespace
+
 // gw (C,C,3) and gb (C) from x and gy
 int lf_conv1d_bwd_weight(const float* x, const float* gy, float* gw, float* gb, int N, int H, int W, int C, int axis,
                          int dilation, float* scratch, void* stream) {
     LF_REQUIRE(x && gy && gw && scratch, "lf_conv1d_bwd_weight: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
-    LfWgradArgs a;
-    a.x = x; a.g = gy; a.pro_sc = nullptr; a.pro_sh = nullptr; a.s16 = g_ops_bf16 == 2;
-    a.split = (g_ops_bf16 == 9 || g_ops_bf16 == 6) ? g_ops_bf16 : 0;
-    a.partial = scratch;
-    a.bias_partial = gb ? scratch + (long)lf_tapwgrad_splits(g) * 3 * C * C : nullptr;
-    int rc = lf_tapwgrad_launch(g, a, LF_PRO_NONE, st);
-    if (rc) return rc;
-    const int idx[3] = {0, 1, 2};
-    const int nsplit = lf_tapwgrad_splits_for(g, a, LF_PRO_NONE);
-    return lf_wgrad_reduce_launch(a.partial, nsplit, 3, C, C, gw, 3L, 3L * C, idx, a.bias_partial, nsplit, gb, 0, st);
+    return conv1d_bwd_weight(x, gy, nullptr, nullptr, gw, gb, N, H, W, C, axis, dilation, scratch, (hipStream_t)stream);
+}
+
+int lf_debug_conv1d_wgrad_pro(const float* x, const float* gy, const float* sc, const float* sh, float* gw, float* gb, int N, int H, int W,
+                              int C, int axis, int dilation, float* scratch, void* stream) {
+    LF_REQUIRE(x && gy && sc && sh && gw && scratch, "lf_debug_conv1d_wgrad_pro: null pointer");
+    return conv1d_bwd_weight(x, gy, sc, sh, gw, gb, N, H, W, C, axis, dilation, scratch, (hipStream_t)stream);
 }
 
 }  // extern "C"

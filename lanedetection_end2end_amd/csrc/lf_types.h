@@ -36,3 +36,31 @@ template <typename T>
 __device__ __forceinline__ float lf_ld1(const T* p) { return (float)*p; }
 template <typename T>
 __device__ __forceinline__ void lf_st1(T* p, float v) { *p = (T)v; }
+
+// NQ channel quads per thread in one access: fp32 one quad (16 bytes), bf16 two (8 channels = 16 bytes: an 8-byte access per lane
+// touches a cache line for half of what a wave instruction can take from it and ran the bf16 BatchNorm passes at ~0.7x the fp32
+// kernels' bandwidth)
+template <typename T, int NQ>
+__device__ __forceinline__ void lf_ldq(const T* p, lf_f32x4 (&v)[NQ]) {
+    if constexpr (NQ == 1) v[0] = lf_ldv(p);
+    else {
+        static_assert(NQ == 2 && sizeof(T) == 2, "two quads per access: bf16 only");
+        const uint4 r = *reinterpret_cast<const uint4*>(p);
+        v[0].x = __uint_as_float(r.x << 16); v[0].y = __uint_as_float(r.x & 0xffff0000u);
+        v[0].z = __uint_as_float(r.y << 16); v[0].w = __uint_as_float(r.y & 0xffff0000u);
+        v[1].x = __uint_as_float(r.z << 16); v[1].y = __uint_as_float(r.z & 0xffff0000u);
+        v[1].z = __uint_as_float(r.w << 16); v[1].w = __uint_as_float(r.w & 0xffff0000u);
+    }
+}
+template <typename T, int NQ>
+__device__ __forceinline__ void lf_stq(T* p, const lf_f32x4 (&v)[NQ]) {
+    if constexpr (NQ == 1) lf_stv(p, v[0]);
+    else {
+        static_assert(NQ == 2 && sizeof(T) == 2, "two quads per access: bf16 only");
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        bf16x8_t b;
+        b[0] = (lf_bf16)v[0].x; b[1] = (lf_bf16)v[0].y; b[2] = (lf_bf16)v[0].z; b[3] = (lf_bf16)v[0].w;
+        b[4] = (lf_bf16)v[1].x; b[5] = (lf_bf16)v[1].y; b[6] = (lf_bf16)v[1].z; b[7] = (lf_bf16)v[1].w;
+        *reinterpret_cast<bf16x8_t*>(p) = b;
+    }
+}
