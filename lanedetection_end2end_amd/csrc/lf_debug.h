@@ -30,6 +30,11 @@ void lf_debug_set_wgrad_ro(int mode, int cap64, int cap128);
  * gw = d/dw of conv1d(relu(x * sc + sh)), gb = column sums of gy */
 int lf_debug_conv1d_wgrad_pro(const float* x, const float* gy, const float* sc, const float* sh, float* gw, float* gb, int N, int H, int W,
                               int C, int axis, int dilation, float* scratch, void* stream);
+/* lf_conv1d_bwd_data with the THREE-TENSOR epilogue of the network's last data gradient per block (ADD + MASK + BN-backward sums,
+ * ERFNet.py:44-60 backward): gx = (conv1d^T(gy) + add_src) * [mask_src > 0]; stats receives the per-tile partial rows
+ * [rows][2][C] = (sum gx, sum gx * aux) -- raw, as lf_bn_bwd_finalize consumes them.  Returns the number of rows, -1 on error. */
+int lf_debug_conv1d_bwd_data_epi3(const float* gy, const float* w, const float* mask_src, const float* add_src, const float* aux,
+                                  float* gx, float* stats, int N, int H, int W, int C, int axis, int dilation, float* scratch, void* stream);
 int lf_debug_conv1d_wgrad_phases(const float* x, const float* gy, int N, int H, int W, int C, int axis, int dilation,
                                  float* scratch, unsigned long long* dbg, void* stream);
 #ifdef __cplusplus

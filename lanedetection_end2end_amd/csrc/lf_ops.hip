@@ -172,6 +172,19 @@ int lf_conv1d_bwd_data(const float* gy, const float* w, const float* mask_src, f
     return lf_tapgemm_launch(g, a, LF_PRO_NONE, mask_src ? LF_EPI_MASK : 0, st);
 }
 
+int lf_debug_conv1d_bwd_data_epi3(const float* gy, const float* w, const float* mask_src, const float* add_src, const float* aux,
+                                  float* gx, float* stats, int N, int H, int W, int C, int axis, int dilation, float* scratch, void* stream) {
+    if (!(gy && w && mask_src && add_src && aux && gx && stats && scratch)) { lf_fail("lf_debug_conv1d_bwd_data_epi3: null pointer"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    LfTapArgs a;
+    memset(&a, 0, sizeof(a));
+    pack_conv1d(a, w, scratch, C, 3L * C, 3L, 1, st);
+    a.src = gy; a.dst = gx; a.mask_src = mask_src; a.add_src = add_src; a.aux = aux; a.stats = stats;
+    if (lf_tapgemm_launch(g, a, LF_PRO_NONE, LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT, st)) return -1;
+    return lf_tapgemm_stat_rows_for(g, a);
+}
+
 namespace {
 int conv1d_bwd_weight(const float* x, const float* gy, const float* sc, const float* sh, float* gw, float* gb, int N, int H, int W, int C,
                       int axis, int dilation, float* scratch, hipStream_t st) {

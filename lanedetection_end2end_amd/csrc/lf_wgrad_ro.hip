@@ -36,6 +36,9 @@ namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
 typedef __attribute__((address_space(3))) unsigned char* lds_u8_p;
@@ -63,7 +66,8 @@ __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; retur
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <int C, bool PRO>
+// PRO: 0 none, 1 BN + ReLU on x with taps along H only (the network's case: no column tests), 2 ... with taps along W
+template <int C, int PRO>
 __global__ __launch_bounds__(C * 4, C == 64 ? 2 : 1) void tapwgrad_ro_kernel(const LfTapGeom g, const LfWgradArgs a,
                                                                             const int write_bias) {
     typedef RoCfg<C> K;
@@ -212,22 +216,28 @@ __global__ __launch_bounds__(C * 4, C == 64 ? 2 : 1) void tapwgrad_ro_kernel(con
         }
     };
     // relu(bn(x)) on a transposed operand half (four pixels of this lane's channel), rounded back to bf16; pixels outside the image
-    // stay zero: (ci, cj) = row and first column of the half's group
+    // stay zero: (ci, cj) = row and first column of the half's group.  Packed arithmetic (every VALU instruction here is one more
+    // issue slot of a loop that is instruction-bound): two v_pk_fma_f32, two v_cvt_pk_bf16_f32, and the ReLU as a signed 16-bit
+    // maximum with 0 on the ROUNDED pairs (v_pk_max_i16) -- rounding is monotonic and keeps the sign, so relu(round(y)) ==
+    // round(relu(y)) bit for bit, the value the forward pass's operand prologue formed.
     auto transform = [&](s16x4 v, const int ci, const int cj, const int dh, const int dw) __attribute__((always_inline)) -> s16x4 {
         if ((unsigned)(ci + dh) >= (unsigned)g.Hl) { const s16x4 z = {0, 0, 0, 0}; return z; }    // the whole tap row is padding
         const uint2 u = __builtin_bit_cast(uint2, v);
-        f32x4 f = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)};
-        f = f * psc + psh;
-        f.x = fmaxf(f.x, 0.f); f.y = fmaxf(f.y, 0.f); f.z = fmaxf(f.z, 0.f); f.w = fmaxf(f.w, 0.f);
+        const f32x2 sc2 = {psc, psc}, sh2 = {psh, psh};
+        f32x2 lo = {bf_lo(u.x), bf_hi(u.x)}, hi = {bf_lo(u.y), bf_hi(u.y)};
+        lo = __builtin_elementwise_fma(lo, sc2, sh2);
+        hi = __builtin_elementwise_fma(hi, sc2, sh2);
+        const s16x2 z2 = {0, 0};
+        s16x2 a = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(lo, bf16x2)), z2);
+        s16x2 c = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(hi, bf16x2)), z2);
         const int c0 = cj + dw;                                          // column of the group's first pixel at this tap
-        if (c0 < 0 || c0 + 15 >= g.Wl) {                                 // edge group (wave-uniform test)
-            const int c = c0 + 4 * b;
-            f.x = (unsigned)(c + 0) < (unsigned)g.Wl ? f.x : 0.f; f.y = (unsigned)(c + 1) < (unsigned)g.Wl ? f.y : 0.f;
-            f.z = (unsigned)(c + 2) < (unsigned)g.Wl ? f.z : 0.f; f.w = (unsigned)(c + 3) < (unsigned)g.Wl ? f.w : 0.f;
+        if (PRO == 2 && (c0 < 0 || c0 + 15 >= g.Wl)) {                   // edge group (wave-uniform test)
+            const int col = c0 + 4 * b;
+            a.x = (unsigned)(col + 0) < (unsigned)g.Wl ? a.x : (short)0; a.y = (unsigned)(col + 1) < (unsigned)g.Wl ? a.y : (short)0;
+            c.x = (unsigned)(col + 2) < (unsigned)g.Wl ? c.x : (short)0; c.y = (unsigned)(col + 3) < (unsigned)g.Wl ? c.y : (short)0;
         }
-        lf_bf16x4 o;
-        o[0] = (lf_bf16)f.x; o[1] = (lf_bf16)f.y; o[2] = (lf_bf16)f.z; o[3] = (lf_bf16)f.w;
-        return __builtin_bit_cast(s16x4, o);
+        const s16x4 o = {a.x, a.y, c.x, c.y};
+        return o;
     };
     auto cat8 = [](s16x4 lo, s16x4 hi) __attribute__((always_inline)) -> bf16x8 {
         const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -341,7 +351,7 @@ int lf_tapwgrad_ro_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hip
     const int wb = (a.bias_partial != nullptr) | (g_ro_mode & 6);
     const dim3 grid((unsigned)(nsplit * (g.Cs / 64)));
     // (dynamic LDS beyond 64 KB needs the attribute; per device, checked)
-    static int attr_dev[4] = {-1, -1, -1, -1};
+    static int attr_dev[6] = {-1, -1, -1, -1, -1, -1};
     auto allow = [&](const void* k, int slot, size_t bytes) -> int {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return lf_fail("tapwgrad_ro: hipGetDevice failed");
@@ -351,13 +361,14 @@ int lf_tapwgrad_ro_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hip
         attr_dev[slot] = dev;
         return 0;
     };
-#define LF_RO(CH, PROV, SLOT)                                                                                          \
+#define LF_RO(CH, PROV, SLOT)  /* PROV: see the kernel */                                                                                          \
     do {                                                                                                               \
         if (int rc = allow(reinterpret_cast<const void*>(tapwgrad_ro_kernel<CH, PROV>), SLOT, RoCfg<CH>::LDS)) return rc; \
         hipLaunchKernelGGL((tapwgrad_ro_kernel<CH, PROV>), grid, dim3(CH * 4), RoCfg<CH>::LDS, st, g, a, wb);          \
     } while (0)
-    if (g.Cs == 64) { if (pro == LF_PRO_BNRELU) LF_RO(64, true, 0); else LF_RO(64, false, 1); }
-    else { if (pro == LF_PRO_BNRELU) LF_RO(128, true, 2); else LF_RO(128, false, 3); }
+    const bool horiz = g.tdw[0] != 0 || g.tdw[1] != 0 || g.tdw[2] != 0;
+    if (g.Cs == 64) { if (pro != LF_PRO_BNRELU) LF_RO(64, 0, 0); else if (!horiz) LF_RO(64, 1, 1); else LF_RO(64, 2, 2); }
+    else { if (pro != LF_PRO_BNRELU) LF_RO(128, 0, 3); else if (!horiz) LF_RO(128, 1, 4); else LF_RO(128, 2, 5); }
 #undef LF_RO
     LF_CHECK_LAUNCH("tapwgrad_ro");
     return 0;

@@ -948,13 +948,16 @@ def test_bf16_matrix_core_mode_network():
     net.precision = "fp32"
 
 
-def test_bf16_tensor_mode_backward_straight_through():
+@pytest.mark.parametrize("shape", [(2, 64, 128, 2), (4, 320, 640, 4)])
+def test_bf16_tensor_mode_backward_straight_through(shape):
     """Whole backward in precision mode "bf16" against the fp64 oracle evaluated straight-through at the engine's own
-    (bf16-stored) forward state: every parameter gradient -- conv weights through the bf16 weight-gradient kernel incl.
-    its BN+ReLU operand prologue, BatchNorm weights/biases through the fused epilogue sums -- agrees to bf16 accuracy
-    (relative L2 per tensor; the gradient buffers are rounded to bf16 at every layer, so errors grow ~2^-9 * sqrt(depth))."""
+    (bf16-stored) forward state: every parameter gradient -- conv weights through the bf16 weight-gradient kernels incl.
+    the BN+ReLU operand prologue, BatchNorm weights/biases through the fused epilogue sums -- agrees to bf16 accuracy
+    (relative L2 per tensor; the gradient buffers are rounded to bf16 at every layer, so errors grow ~2^-9 * sqrt(depth)).
+    (4, 320, 640, 4) = BASELINE config 3's own geometry: the shapes that select the whole-line, ring, 16-channel and read-once
+    weight-gradient kernels (row widths 80 / 160 / 320, 4 output lanes)."""
     from lanedetection_end2end_amd import _lib
-    N, H, W, Cout = 2, 64, 128, 2
+    N, H, W, Cout = shape
     net, P = build(out_channels=Cout)
     for m in net.modules():
         if isinstance(m, torch.nn.Dropout2d):
@@ -1018,4 +1021,19 @@ def test_bf16_tensor_mode_backward_straight_through():
     assert errs["decoder.output_conv.weight"] < 1e-5 and errs["decoder.output_conv.bias"] < 1e-5
     assert errs["decoder.layers.5.bn2.weight"] < 1e-2 and errs["decoder.layers.5.conv1x3_2.weight"] < 1e-2
     assert max(tail) < 0.1
-    assert float(np.median(list(errs.values()))) < 0.25 and errs[worst] < 0.5 and min(cosines.values()) > 0.9
+    # measured: median 1.4e-2 at both shapes, worst 3.2e-2 / 8.9e-2 (the stem, below 38 BatchNorm backwards), cosine >= 0.996
+    assert float(np.median(list(errs.values()))) < 0.04 and errs[worst] < 0.25 and min(cosines.values()) > 0.99
+    # The first parameter gradient BELOW every kernel kind of the bf16 backward (16-channel lean data gradient + tapwgrad16_tr:
+    # decoder.layers.5 / .4; ring kernel (transposed-conv phases): decoder.layers.3; whole-line data gradient + read-once weight
+    # gradient at 64 channels: decoder.layers.2 / .1, at 128 channels: encoder.layers.14; 9-tap stride-2: encoder.layers.6) -- with
+    # the error its depth allows: every BatchNorm backward on the way amplifies the 2^-9 rounding of the stored gradient ~10x in
+    # this test (see above), so the bound is per site, 2.5 x what was measured at BOTH shapes, and the cosine pins the mapping (a
+    # mis-scaled tap or a permuted channel block in one kernel form shows as O(1) at its site and everything below it).
+    sites = {"decoder.layers.5.conv3x1_1.weight": 0.04, "decoder.layers.4.conv1x3_2.weight": 0.015, "decoder.layers.3.conv.weight": 0.025,
+             "decoder.layers.2.conv1x3_2.weight": 0.025, "decoder.layers.2.conv3x1_2.weight": 0.025, "decoder.layers.1.conv3x1_1.weight": 0.03,
+             "decoder.layers.0.conv.weight": 0.03, "encoder.layers.14.conv1x3_2.weight": 0.03, "encoder.layers.14.conv3x1_2.weight": 0.03,
+             "encoder.layers.6.conv.weight": 0.05}      # measured (2 x 64 x 128 / 4 x 320 x 640): 0.005-0.016 at every site but the last (deeper)
+    print("   " + "  ".join("%s %.3f/%.4f" % (k.replace(".weight", ""), errs[k], cosines[k]) for k in sites if k in errs))
+    for k, bound in sites.items():
+        if k in errs:
+            assert errs[k] < bound and cosines[k] > 0.999, (k, errs[k], cosines[k])

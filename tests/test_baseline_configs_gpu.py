@@ -444,7 +444,7 @@ def _eval_chunks_equal_full_batch(model, call, x, chunk, precision, P, oracle_ch
     print("batch %d vs %d chunks of %d (%s, eval): logits %.1e of max, lane coefficients %.1e, parameter gradients vs the chunk sum %.1e"
           % (N, N // chunk, chunk, precision, worst_l, worst_b, worst_g))
     assert worst_l <= 1e-6 and worst_b <= 1e-6
-    assert worst_g <= (2e-5 if precision == "fp32" else 2e-2)     # summation order of the split-K weight gradient differs with the batch
+    assert worst_g <= 2e-5     # summation order of the split-K weight gradient differs with the batch (measured 1.0e-6, fp32 and bf16: eval mode is per image, so the rounded tensors of a chunk ARE the full batch's)
     if oracle_check:
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         torch.set_num_threads(min(os.cpu_count() or 1, 64))
@@ -461,7 +461,7 @@ def _eval_chunks_equal_full_batch(model, call, x, chunk, precision, P, oracle_ch
         if precision == "fp32":
             assert e64 <= max(1.5 * fl, 2e-6 * scale), (e64, fl)
         else:
-            assert e64 <= 3e-2 * scale, (e64, scale)            # bf16 products, fp32 accumulation, 70 layers
+            assert e64 <= 1e-2 * scale, (e64, scale)            # bf16 products, fp32 accumulation, 70 layers (measured 4.4e-3)
 
 
 def _warm_running_stats(model, call, x_small):

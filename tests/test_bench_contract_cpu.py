@@ -55,6 +55,32 @@ def test_launched_by_torch_distributed_run():
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
 
 
+def test_world_size_4_dry_run():
+    """Rank plumbing beyond two: four ranks rendezvous over gloo, every block is bracketed by the barrier on all of them, the
+    all-reduced stand-in gradient is the mean over FOUR ranks, one line comes out (the 8-GPU scaling run is the driver's: this is
+    the same code path with a CPU step)."""
+    d = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-run"])
+    assert d["n_gpus"] == 4 and d["allreduce_mean_ok"] is True
+
+
+def test_measured_path_of_bench_imports_nothing_from_the_oracle():
+    """bench.py may use oracle/ only as the checker: inside cpu_baseline_and_parity() and miopen_baseline() (both run after the
+    clock, rank 0, N = 1).  Every other function -- the measured path -- must not import the package; its synthetic inputs
+    come from the neutral synthetic_inputs module."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    allowed = {"cpu_baseline_and_parity", "miopen_baseline"}
+    for node in tree.body:
+        names = []
+        for sub in ast.walk(node):
+            if isinstance(sub, ast.ImportFrom) and (sub.module or "").split(".")[0] == "oracle":
+                names.append(sub.module)
+            if isinstance(sub, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in sub.names):
+                names.append("import")
+        if names:
+            assert isinstance(node, ast.FunctionDef) and node.name in allowed, (getattr(node, "name", node), names)
+
+
 def test_single_rank_dry_run():
     assert _run_bench(["--steps", "2", "--warmup", "1", "--dry-run"])["n_gpus"] == 1
 

@@ -67,3 +67,65 @@ def test_lds_dma_kernels_equal_the_streaming_kernel_on_every_launch(shape):
     finally:
         lib.lf_debug_set_ops_precision(0)
         lib.lf_debug_set_bf16_lds(4)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 80, 160, 1, 1), (64, 64, 80, 160, 0, 1), (16, 128, 40, 80, 0, 8), (3, 64, 20, 48, 1, 2)])
+def test_three_tensor_epilogue_whole_line_kernel(shape):
+    """The data gradient that closes a non_bottleneck_1d block's backward (ADD + MASK + BN-backward sums: three epilogue tensors staged
+    by LDS-DMA in the whole-line kernel, tapgemm_bf16_wl_kernel<2, 38, 0> at 64 channels) at config 3's own shape 64 x 64 x 80 x 160:
+    the stored values equal to the streaming kernel's bit for bit on every launch of a repeat loop, the partial sums reproduced
+    exactly from launch to launch, and both correct against
+    torch: gx = round_bf16((conv^T(gy) + add) * [mask > 0]) within half a bf16 ulp, column sums of gx and gx * aux to fp32 accuracy."""
+    import torch.nn.functional as F
+    from lanedetection_end2end_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    N, C, H, W, axis, d = shape
+    torch.manual_seed(3)
+    gy = torch.randn(N, H, W, C, device="cuda").bfloat16()
+    mask = torch.randn(N, H, W, C, device="cuda").bfloat16()
+    add = torch.randn(N, H, W, C, device="cuda").bfloat16()
+    aux = torch.randn(N, H, W, C, device="cuda").bfloat16()
+    w = torch.randn(C, C, 3, device="cuda") * (2.0 / (3 * C)) ** 0.5
+    scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096, device="cuda")
+    nrows_max = (N * H * W + 255) // 256
+
+    def run(mode):
+        lib.lf_debug_set_bf16_lds(mode)
+        gx = torch.full_like(gy, float("nan"))
+        stats = torch.full((nrows_max, 2, C), float("nan"), device="cuda")
+        rows = lib.lf_debug_conv1d_bwd_data_epi3(P(gy), P(w), P(mask), P(add), P(aux), P(gx), P(stats), N, H, W, C, axis, d, P(scratch), st)
+        assert rows > 0, lib.lf_last_error().decode()
+        torch.cuda.synchronize()
+        return gx, stats[:rows].clone()
+
+    try:
+        lib.lf_debug_set_ops_precision(2)
+        ref = run(0)
+        assert torch.isfinite(ref[0].float()).all() and torch.isfinite(ref[1]).all()
+        w4 = (w.view(C, C, 3, 1) if axis == 0 else w.view(C, C, 1, 3)).bfloat16().double()
+        pad, dil = ((d, 0), (d, 1)) if axis == 0 else ((0, d), (1, d))
+        gn = gy.double().permute(0, 3, 1, 2).contiguous()
+        want = (torch.nn.grad.conv2d_input(gn.shape, w4, gn, padding=pad, dilation=dil).permute(0, 2, 3, 1) + add.double()) * (mask.double() > 0)
+        err = (ref[0].double() - want).abs()
+        assert (err <= want.abs() * 2.0 ** -8 + 1e-6).all(), float(err.max())
+        s1 = ref[0].double().sum((0, 1, 2))
+        s2 = (ref[0].double() * aux.double()).sum((0, 1, 2))
+        got = ref[1].double().sum(0)
+        assert float((got[0] - s1).abs().max()) < 2e-5 * float(ref[0].double().abs().sum((0, 1, 2)).max())
+        assert float((got[1] - s2).abs().max()) < 2e-5 * float((ref[0].double() * aux.double()).abs().sum((0, 1, 2)).max())
+        # (the partial SUMS of the two kernels are taken in different orders -- fp32, per tile -- so they agree to rounding, not in bits;
+        # the stored values do, and every launch of the whole-line kernel must reproduce its own sums exactly)
+        first = None
+        for it in range(10 if N * H * W > 100000 else 30):
+            gx, stats = run(4)
+            assert torch.equal(gx, ref[0]), "whole-line kernel, launch %d: values differ from the streaming kernel" % it
+            first = stats if first is None else first
+            assert torch.equal(stats, first), "whole-line kernel, launch %d: partial sums differ from its first launch" % it
+        gotw = first.double().sum(0)
+        assert float((gotw[0] - s1).abs().max()) < 2e-5 * float(ref[0].double().abs().sum((0, 1, 2)).max())
+        assert float((gotw[1] - s2).abs().max()) < 2e-5 * float((ref[0].double() * aux.double()).abs().sum((0, 1, 2)).max())
+    finally:
+        lib.lf_debug_set_ops_precision(0)
+        lib.lf_debug_set_bf16_lds(4)
