@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 3
+#define LF_ABI_VERSION 4
 
 /* activation applied to the backbone logits: BEV/Networks/LSQ_layer.py:43-63 */
 enum { LF_ACT_SQUARE = 0, LF_ACT_ABS = 1, LF_ACT_RELU = 2, LF_ACT_SIGMOID = 3,
@@ -153,7 +153,7 @@ void lf_erfnet_plan_destroy(lf_erfnet_plan* plan);
  * the split kernel cannot take (other channel counts, pixel counts not a multiple of 512) and the weight gradient run
  * on the fp32 matrix cores. */
 int lf_erfnet_set_precision(const lf_erfnet_plan* plan, int mode);
-size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* plan);
+size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* plan);   /* follows the precision mode (bf16 tensors: larger partial-row regions): query it after lf_erfnet_set_precision */
 int lf_erfnet_num_params(const lf_erfnet_plan* plan);
 int lf_erfnet_num_bn(const lf_erfnet_plan* plan);
 int lf_erfnet_num_dropout(const lf_erfnet_plan* plan);
@@ -195,8 +195,13 @@ int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, vo
  * x / y / gy / gx are NCHW fp32 like the reference's tensors; head >= 0 (only with last = the layer count) appends
  * output_conv (0) / output_conv2 (1) and makes y the logits.  Only the range's parameters are read / receive gradients
  * (grads_host entries outside it are left untouched); BatchNorm running statistics of the range are updated in train mode.
- * lf_erfnet_backward_range must follow lf_erfnet_forward_range on the same workspace.  fp32-tensor precision modes only. */
+ * lf_erfnet_backward_range must follow lf_erfnet_forward_range on the same workspace.  fp32-tensor precision modes only.
+ * The workspace of a range is COMPACT (ABI 4): lf_erfnet_range_workspace_bytes(plan, first, last) = the range's own activations
+ * + the plan's globals (packed weights, statistics rows, one partial-row region, three gradient buffers), so that a loop over
+ * the blocks of a network keeps the activations of ONE network alive until backward, not one whole-network workspace per block.
+ * gx is not produced for first = 0: the image takes no gradient (as in lf_erfnet_backward). */
 int lf_erfnet_num_layers(const lf_erfnet_plan* plan);
+size_t lf_erfnet_range_workspace_bytes(const lf_erfnet_plan* plan, int first, int last);
 int lf_erfnet_layer_io(const lf_erfnet_plan* plan, int layer, int* out6_host);   /* Cin, Hin, Win, Cout, Hout, Wout */
 int lf_erfnet_forward_range(const lf_erfnet_plan* plan, int first, int last, int head, const float* x,
                             const float* const* params_host, const float* const* params_dev, float* const* running_host,
@@ -327,13 +332,17 @@ int lf_pipeline_image(const lf_pipeline_plan* plan, const uint8_t* frames, int N
                       const uint8_t* flip, float* out, void* stream);
 int lf_pipeline_label(const lf_pipeline_plan* plan, const uint8_t* labels, int N, const void* tables_dev,
                       const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon, void* stream);
-/* The same two calls reading a RESIDENT POOL of decoded frames / label maps: batch element n is pool entry sel[n] (int64 on the
- * device).  The index batch of a cached dataset (SubsetRandomSampler's draw, BEV/Dataloader/Load_Data_new.py:305-320) is gathered
- * inside the kernels instead of by a copy of N frames first. */
+/* The same two calls reading a RESIDENT POOL of decoded frames / label maps (pool_frames entries): batch element n is pool entry
+ * sel[n] (int64 on the device).  The index batch of a cached dataset (SubsetRandomSampler's draw,
+ * BEV/Dataloader/Load_Data_new.py:305-320) is gathered inside the kernels instead of by a copy of N frames first.
+ * bad_index (device int32, may be NULL): incremented once per batch element whose sel[n] lies outside [0, pool_frames); such an
+ * element reads pool entry 0 -- never out of bounds -- and the host raises from the count, as the reference's tensor indexing
+ * raises IndexError (ABI 4: pool_frames on the label call, bad_index on both). */
 int lf_pipeline_image_indexed(const lf_pipeline_plan* plan, const uint8_t* pool, long pool_frames, const int64_t* sel, int N,
-                              const void* tables_dev, const uint8_t* flip, float* out, void* stream);
-int lf_pipeline_label_indexed(const lf_pipeline_plan* plan, const uint8_t* pool, const int64_t* sel, int N, const void* tables_dev,
-                              const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon, void* stream);
+                              const void* tables_dev, const uint8_t* flip, float* out, int* bad_index, void* stream);
+int lf_pipeline_label_indexed(const lf_pipeline_plan* plan, const uint8_t* pool, long pool_frames, const int64_t* sel, int N,
+                              const void* tables_dev, const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon,
+                              int* bad_index, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Kernel-level entry points: one factorised convolution of non_bottleneck_1d

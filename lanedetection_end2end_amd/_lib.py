@@ -64,8 +64,8 @@ def _declare(lib):
         "lf_pipeline_tables_host": (I, [P, P, P, P, P, P, P, P, P]),
         "lf_pipeline_image": (I, [P, P, I, P, P, P, P]),
         "lf_pipeline_label": (I, [P, P, I, P, P, I, P, P, P, P]),
-        "lf_pipeline_image_indexed": (I, [P, P, L, P, I, P, P, P, P]),
-        "lf_pipeline_label_indexed": (I, [P, P, P, I, P, P, I, P, P, P, P]),
+        "lf_pipeline_image_indexed": (I, [P, P, L, P, I, P, P, P, P, P]),
+        "lf_pipeline_label_indexed": (I, [P, P, L, P, I, P, P, I, P, P, P, P, P]),
         "lf_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
         "lf_pointwise_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
         "lf_pointwise_scratch_floats": (L, [I, I, I, I, I]),
@@ -81,6 +81,7 @@ def _declare(lib):
         "lf_conv1d_bwd_data": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_conv1d_bwd_weight": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
         "lf_erfnet_num_layers": (I, [P]),
+        "lf_erfnet_range_workspace_bytes": (c_size_t, [P, I, I]),
         "lf_erfnet_layer_io": (I, [P, I, P]),
         "lf_erfnet_forward_range": (I, [P, I, I, I, P, P, P, P, P, I, P, P, c_size_t, P]),
         "lf_erfnet_backward_range": (I, [P, I, I, I, P, P, P, P, P, I, P, P, c_size_t, P]),

@@ -78,7 +78,8 @@ struct LfWgradArgs {
     unsigned long long* dbg = nullptr;   // tools/kbench.py --phases: 8 words per wave (start, first operands, loop done, end, HW id)
 };
 // number of k-split rows the kernel will write for this geometry
-int lf_tapwgrad_splits(const LfTapGeom& g);
+int lf_tapwgrad_splits(const LfTapGeom& g);          // upper bound over the kernels that take fp32 tensors
+int lf_tapwgrad_splits_bound(const LfTapGeom& g, int s16);   // ... by storage type: bf16 tensors add the read-once kernel's rows
 int lf_tapwgrad_bias_rows(const LfTapGeom& g);
 // rows the launch with these arguments writes (<= lf_tapwgrad_splits: the split-arithmetic kernel uses fewer, larger splits)
 int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro);

@@ -31,6 +31,8 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
+#include <tuple>
 #include <utility>
 
 #include <hip/hip_ext.h>
@@ -1751,18 +1753,37 @@ int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a) {
 }
 
 namespace {
-// Workgroups of `kernel` the whole chip holds at once (occupancy x CUs), cached per (kernel, dynamic LDS bytes).
+// Per-(device, kernel) launch state shared by the host threads of a process (one process may drive several GPUs): the occupancy
+// cache below and the "dynamic LDS beyond 64 KB allowed" attribute of the LDS-ring kernels.
+std::mutex g_launch_state_mutex;
+int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+// Workgroups of `kernel` the whole chip holds at once (occupancy x CUs), cached per (device, kernel, dynamic LDS bytes).
 template <typename K>
 int resident_workgroups(K kernel, size_t lds) {
-    static std::map<std::pair<const void*, size_t>, int> cache;
-    const std::pair<const void*, size_t> key(reinterpret_cast<const void*>(kernel), lds);
+    static std::map<std::tuple<int, const void*, size_t>, int> cache;
+    const int dev = current_device();
+    const std::tuple<int, const void*, size_t> key(dev, reinterpret_cast<const void*>(kernel), lds);
+    std::lock_guard<std::mutex> lock(g_launch_state_mutex);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    int dev = 0, cus = 0, nb = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+    int cus = 0, nb = 0;
+    if (dev < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, lds) != hipSuccess || nb < 1 || cus < 1)
         return cache[key] = 1 << 30;                 // unknown: one tile per workgroup
     return cache[key] = nb * cus;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel); false when the runtime refuses (the caller launches a
+// kernel that needs less LDS instead of failing at launch)
+bool allow_big_lds(const void* kernel, int bytes) {
+    static std::map<std::pair<int, const void*>, bool> done;
+    const std::pair<int, const void*> key(current_device(), kernel);
+    std::lock_guard<std::mutex> lock(g_launch_state_mutex);
+    auto it = done.find(key);
+    if (it != done.end()) return it->second;
+    return done[key] = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
 }
 // tapgemm_kernel walks its pixel tiles with stride gridDim.x: launch no more workgroups than are resident at once (a multiple
 // of 8 per XCD dealing), so that the tiles beyond the first round are spread one per CU by construction
@@ -1787,19 +1808,17 @@ void launch_bf16_ring(unsigned nitems, hipStream_t st, const LfTapGeom& g, const
     if (gx > res && res >= 8) gx = res & ~7u;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), ring_lds, st, g, a, pro, epi);
 }
+// false: the runtime refused the kernel's LDS budget on this device (nothing launched: the caller takes the ring / streaming kernel)
 template <int CBV, int EPIV, int PROV = 0>
-void launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
+bool launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
     auto kern = tapgemm_bf16_wl_kernel<CBV, EPIV, PROV>;
     const size_t lds = WlCfg<CBV, EPIV, PROV>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set = true;
-    }
+    if (!allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 4096)) return false;
     unsigned gx = nitems;
     const unsigned res = (unsigned)resident_workgroups(kern, lds);
     if (gx > res && res >= 8) gx = res & ~7u;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, st, g, a, pro, epi);
+    return true;
 }
 }  // namespace
 
@@ -1914,13 +1933,14 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
                         g.Hd == g.Hl && g.Wd == g.Wl && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
                         (long)g.N * g.Hd * g.Wd * g.d_pix * 2 < (long)LF_OOB;
         if (wl && fast16p) {        // (128 channels only)
-            launch_bf16_wl<4, LF_EPI_RELU, 1>((unsigned)lf_cdiv(npix, PIX_PER_WG), st, g, a, pro, epi);
-            LF_CHECK_LAUNCH("tapgemm_bf16_wl (prologue)");
-            return 0;
-        }
-        if (wl) {
+            if (launch_bf16_wl<4, LF_EPI_RELU, 1>((unsigned)lf_cdiv(npix, PIX_PER_WG), st, g, a, pro, epi)) {
+                LF_CHECK_LAUNCH("tapgemm_bf16_wl (prologue)");
+                return 0;
+            }
+        } else if (wl) {
             const unsigned nitems = (unsigned)lf_cdiv(npix, PIX_PER_WG);
-#define LF_TGW(EPIV) do { if (g.Cs == 128) launch_bf16_wl<4, EPIV>(nitems, st, g, a, pro, epi); else launch_bf16_wl<2, EPIV>(nitems, st, g, a, pro, epi); } while (0)
+            bool launched = false;
+#define LF_TGW(EPIV) do { launched = g.Cs == 128 ? launch_bf16_wl<4, EPIV>(nitems, st, g, a, pro, epi) : launch_bf16_wl<2, EPIV>(nitems, st, g, a, pro, epi); } while (0)
             switch (epis) {
                 case 0: LF_TGW(0); break;
                 case LF_EPI_RELU: LF_TGW(LF_EPI_RELU); break;
@@ -1933,8 +1953,10 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
                 default: LF_TGW(-1); break;
             }
 #undef LF_TGW
-            LF_CHECK_LAUNCH("tapgemm_bf16_wl");
-            return 0;
+            if (launched) {
+                LF_CHECK_LAUNCH("tapgemm_bf16_wl");
+                return 0;
+            }
         }
         const bool ring = fast16 && g_bf16_lds >= 2 && g.Wl % 16 == 0 && g.Cd % 64 == 0;
         const unsigned nitems = (unsigned)(lf_cdiv(npix, PIX_PER_WG) * (g.Cd / 64));
@@ -2871,8 +2893,11 @@ WgradCfg wgrad_split_cfg(const LfTapGeom& g) {
 int lf_tapwgrad_splits(const LfTapGeom& g) {
     const int a = wgrad_cfg(g).gx;
     const int b = wgrad_split_ok(g, nullptr, LF_PRO_NONE) ? wgrad_split_cfg(g).gx : 0;
-    const int c = lf_tapwgrad_ro_rows_bound(g);
-    return a > b ? (a > c ? a : c) : (b > c ? b : c);       // sizes the partial rows for any of the kernels
+    return a > b ? a : b;                                   // sizes the partial rows for either kernel on fp32 tensors
+}
+int lf_tapwgrad_splits_bound(const LfTapGeom& g, int s16) {
+    const int a = lf_tapwgrad_splits(g), c = s16 ? lf_tapwgrad_ro_rows_bound(g) : 0;
+    return a > c ? a : c;
 }
 int lf_tapwgrad_bias_rows(const LfTapGeom& g) { return lf_tapwgrad_splits(g); }
 int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro) {
@@ -2900,13 +2925,9 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
     const int xb = c.xt * 16, gb = c.gt * 16;
     if (g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0) {
         if (a.s16 && pro == LF_PRO_NONE && g_bf16_lds == 4 && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
-            (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB && (long)g.N * g.Hd * g.Wd * g.d_pix * 2 < (long)LF_OOB)
+            (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB && (long)g.N * g.Hd * g.Wd * g.d_pix * 2 < (long)LF_OOB &&
+            allow_big_lds(reinterpret_cast<const void*>(tapwgrad16_tr_kernel), 128 * 1024))      // (refused: the 2-byte-load kernel below)
         {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tapwgrad16_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                attr_set = true;
-            }
             hipLaunchKernelGGL(tapwgrad16_tr_kernel, dim3(c.gx), dim3(256), (size_t)WG_WAVES * W16_STAGES * W16_STAGE, st, g, a, c.pps, wb);
         }
         else if (a.s16) hipLaunchKernelGGL((tapwgrad16_kernel<3, true>), dim3(c.gx), dim3(256), 0, st, g, a, pro, c.pps, wb);

@@ -41,6 +41,7 @@ struct ConvRef {
 };
 struct Layer {
     int kind, Cin, Cout, Hin, Win, Hout, Wout, dil, drop_idx;
+    long reg_lo;                 // first float of this layer's own region of the workspace (its activations + BN vectors)
     long x;                      // input activation (float offset); -1 = the NCHW image
     long b[5];                   // down: cat,y | nb: t1,t2,t3,t4,out | up: c,y
     ConvRef cv[4];
@@ -61,7 +62,11 @@ struct lf_erfnet_plan {
     mutable int precision = 0;                  // lf_erfnet_set_precision
     long off_stat0, off_stat1, stat_floats;     // two scratch regions for BN partial rows
     long off_wpart, wpart_floats, off_bpart, bpart_floats;
-    long off_wpart_all, wpart_all_floats, off_bpart_all, bpart_all_floats;   // one region per weight gradient (batched reduce)
+    // one region per weight gradient (batched reduce): the LAST regions of the workspace, sized by storage type ([0] fp32
+    // tensors, [1] bf16 tensors: the read-once weight gradient writes up to 512 rows) -- lf_erfnet_workspace_bytes follows the
+    // precision mode, every other offset is independent of it
+    long off_wpart_all, wpart_all_floats[2], bpart_all_floats[2];
+    long off_globals;                           // first float behind the layers' regions
     long off_gA, off_gB, off_gC, gbuf_floats;
     long total_floats;
     long head_in;                               // activation feeding the head
@@ -173,12 +178,17 @@ void bn_alloc(LfBump& ws, BNRef& b) {
 void account_fwd_stats(lf_erfnet_plan* P, const LfTapGeom& g) {
     P->stat_floats = lf_maxl(P->stat_floats, (long)lf_tapgemm_stat_rows(g) * 2 * g.Cd);
 }
+long wneed_of(const LfTapGeom& g, int s16) { return (long)lf_tapwgrad_splits_bound(g, s16) * g.ntaps * g.Cs * g.Cd; }
+long bneed_of(const LfTapGeom& g, int s16) { return (long)lf_tapwgrad_splits_bound(g, s16) * g.Cd; }
 void account_wgrad(lf_erfnet_plan* P, const LfTapGeom& g) {
-    P->wpart_floats = lf_maxl(P->wpart_floats, (long)lf_tapwgrad_splits(g) * g.ntaps * g.Cs * g.Cd);
-    P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_tapwgrad_bias_rows(g) * g.Cd);
-    P->wpart_all_floats += (long)lf_tapwgrad_splits(g) * g.ntaps * g.Cs * g.Cd;
-    P->bpart_all_floats += (long)lf_tapwgrad_bias_rows(g) * g.Cd;
+    for (int s16 = 0; s16 < 2; ++s16) {
+        P->wpart_floats = lf_maxl(P->wpart_floats, wneed_of(g, s16));
+        P->bpart_floats = lf_maxl(P->bpart_floats, bneed_of(g, s16));
+        P->wpart_all_floats[s16] += (wneed_of(g, s16) + 63) / 64 * 64;
+        P->bpart_all_floats[s16] += (bneed_of(g, s16) + 63) / 64 * 64;
+    }
 }
+long wpart_all_end(const lf_erfnet_plan* P, int s16) { return P->off_wpart_all + P->wpart_all_floats[s16] + P->bpart_all_floats[s16]; }
 
 }  // namespace
 
@@ -197,7 +207,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     lf_erfnet_plan* P = new lf_erfnet_plan();
     P->N = N; P->H = H; P->W = W; P->Cin = in_channels; P->Cout = out_channels; P->n_heads = n_heads;
     P->packed_floats = 0; P->packed16_elems = 0; P->stat_floats = 0; P->wpart_floats = 0; P->bpart_floats = 0; P->drop_floats = 0;
-    P->wpart_all_floats = 0; P->bpart_all_floats = 0;
+    P->wpart_all_floats[0] = P->wpart_all_floats[1] = 0; P->bpart_all_floats[0] = P->bpart_all_floats[1] = 0;
     LfBump ws;
     int param = 0, bn = 0, drop = 0;
     long cur = -1;
@@ -206,7 +216,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
         Layer L;
         memset(&L, 0, sizeof(L));
         L.kind = K_DOWN; L.Cin = cin; L.Cout = cout; L.Hin = h; L.Win = w; L.Hout = h / 2; L.Wout = w / 2; L.drop_idx = -1;
-        L.x = cur;
+        L.x = cur; L.reg_lo = ws.cur;
         L.cv[0].p_w = param++; L.cv[0].p_b = param++;
         L.bn[0].p_g = param++; L.bn[0].p_b = param++; L.bn[0].idx = bn++; L.bn[0].C = cout;
         const long sz = (long)N * (h / 2) * (w / 2) * cout;
@@ -225,7 +235,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
         memset(&L, 0, sizeof(L));
         L.kind = K_NB; L.Cin = c; L.Cout = c; L.Hin = L.Hout = h; L.Win = L.Wout = w; L.dil = d;
         L.drop_idx = pdrop > 0.f ? drop++ : -1;
-        L.x = cur;
+        L.x = cur; L.reg_lo = ws.cur;
         const long sz = (long)N * h * w * c;
         for (int i = 0; i < 5; ++i) L.b[i] = ws.take(sz);
         const int axis[4] = {0, 1, 0, 1}, dil[4] = {1, 1, d, d};
@@ -246,7 +256,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
         Layer L;
         memset(&L, 0, sizeof(L));
         L.kind = K_UP; L.Cin = cin; L.Cout = cout; L.Hin = h; L.Win = w; L.Hout = 2 * h; L.Wout = 2 * w; L.drop_idx = -1;
-        L.x = cur;
+        L.x = cur; L.reg_lo = ws.cur;
         L.cv[0].p_w = param++; L.cv[0].p_b = param++;
         L.bn[0].p_g = param++; L.bn[0].p_b = param++; L.bn[0].idx = bn++; L.bn[0].C = cout;
         const long sz = (long)N * 2 * h * 2 * w * cout;
@@ -286,6 +296,7 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_stem_wgrad_rows(N, H, W) * 16);
     P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 8);
 
+    P->off_globals = ws.cur;
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
     P->off_packed = ws.take(P->packed_floats);
     P->off_packed16 = ws.take((P->packed16_elems + 1) / 2);
@@ -294,13 +305,12 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     P->off_stat1 = ws.take(P->stat_floats);
     P->off_wpart = ws.take(P->wpart_floats);
     P->off_bpart = ws.take(P->bpart_floats);
-    P->off_wpart_all = ws.take(P->wpart_all_floats);
-    P->off_bpart_all = ws.take(P->bpart_all_floats);
     P->gbuf_floats = (long)N * (H / 2) * (W / 2) * 16;          // largest activation (= N*(H/4)*(W/4)*64)
     P->off_gA = ws.take(P->gbuf_floats);
     P->off_gB = ws.take(P->gbuf_floats);
     P->off_gC = ws.take(P->gbuf_floats);
-    P->total_floats = ws.cur;
+    P->off_wpart_all = ws.cur;                                  // last: its size follows the precision mode
+    P->total_floats = wpart_all_end(P, 1);                      // (the larger of the two)
     return P;
 }
 
@@ -308,7 +318,8 @@ void lf_erfnet_plan_destroy(lf_erfnet_plan* P) {
     if (!P) return;
     delete P;
 }
-size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)P->total_floats * sizeof(float); }
+// (follows the precision mode: call it after lf_erfnet_set_precision)
+size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)wpart_all_end(P, P->precision == 2) * sizeof(float); }
 // Matrix-core precision of the convolutions and their data gradients: 0 = fp32 MFMA (default, the parity
 // path), 1 = operands rounded to bf16 in registers (v_mfma_f32_16x16x32_bf16), fp32 accumulation, fp32 tensors,
 // 2 = mode 1 + every activation / gradient tensor of the backbone stored as bf16 (half the HBM traffic; the
@@ -376,8 +387,12 @@ struct Ctx {
     mutable long wpart_used = 0, bpart_used = 0;
     mutable int last_rows = 0;           // BatchNorm partial rows the last run_gemm wrote (depends on the kernel it selected)
     mutable bool wgrad_launched = false; // the last run_wgrad put a weight-gradient kernel on the stream (not skipped: frozen weight)
-    float* at(long off) const { return ws + off; }
-    const float* packed(int pack) const { return ws + P->off_packed + P->packs[pack].dst_off; }
+    // A RANGE of layers may run on a compact workspace (lf_erfnet_range_workspace_bytes): its layers' regions [lo, hi) followed by
+    // the globals [cut, ...) -- the full workspace is the case lo = 0, hi = cut.
+    long lo = 0, hi = 0, cut = 0;
+    bool no_batch = false;               // compact workspace: no per-weight-gradient partial regions, every reduction immediately
+    float* at(long off) const { return off < cut ? ws + (off - lo) : ws + (hi - lo) + (off - cut); }
+    const float* packed(int pack) const { return at(P->off_packed + P->packs[pack].dst_off); }
 };
 
 double gemm_flops(const LfTapGeom& g) { return 2.0 * (double)g.N * g.Hl * g.Wl * g.Cs * g.Cd * g.ntaps; }
@@ -406,10 +421,10 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
     extra.s16 = c.s16;
     if (c.P->precision == 1 || c.P->precision == 2)
-        extra.wp16 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed16) + c.P->packs[op.pack].dst16_off;
+        extra.wp16 = reinterpret_cast<const unsigned short*>(c.at(c.P->off_packed16)) + c.P->packs[op.pack].dst16_off;
     if (c.P->precision >= 3) {      // fp32 from split operands on the bf16 matrix cores (9 or 6 partial products)
         extra.split = c.P->precision == 3 ? 9 : 6;
-        extra.wp48 = reinterpret_cast<const unsigned short*>(c.ws + c.P->off_packed48) + 3 * c.P->packs[op.pack].dst16_off;
+        extra.wp48 = reinterpret_cast<const unsigned short*>(c.at(c.P->off_packed48)) + 3 * c.P->packs[op.pack].dst16_off;
     }
     c.last_rows = lf_tapgemm_stat_rows_for(op.geom, extra);
     ProfScope ps(c, 0, op.geom, epi | (pro << 8), c.st);
@@ -513,12 +528,12 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     a.split = P->precision == 3 ? 9 : (P->precision == 4 ? 6 : 0);
     // Batched mode (default): this weight gradient keeps its partial rows in its own region and its reduction joins the
     // one launch at the end of the pass.  Immediate mode: the transposed-conv phases (their bias rows accumulate in order).
-    const long wneed = (long)lf_tapwgrad_splits(op.geom) * op.geom.ntaps * op.geom.Cs * op.geom.Cd;
-    const long bneed = (long)lf_tapwgrad_bias_rows(op.geom) * op.geom.Cd;
-    const bool batched = !bias_accumulate && !batch_off &&
-                         c.wpart_used + wneed <= P->wpart_all_floats && c.bpart_used + bneed <= P->bpart_all_floats;
+    const long wneed = (wneed_of(op.geom, c.s16) + 63) / 64 * 64, bneed = (bneed_of(op.geom, c.s16) + 63) / 64 * 64;
+    const bool batched = !bias_accumulate && !batch_off && !c.no_batch &&
+                         c.wpart_used + wneed <= P->wpart_all_floats[c.s16] && c.bpart_used + bneed <= P->bpart_all_floats[c.s16];
+    const long off_bpart_all = P->off_wpart_all + P->wpart_all_floats[c.s16];
     a.partial = batched ? c.at(P->off_wpart_all + c.wpart_used) : c.at(P->off_wpart);
-    a.bias_partial = c.grads[cv.p_b] ? (batched ? c.at(P->off_bpart_all + c.bpart_used) : c.at(P->off_bpart)) : nullptr;
+    a.bias_partial = c.grads[cv.p_b] ? (batched ? c.at(off_bpart_all + c.bpart_used) : c.at(P->off_bpart)) : nullptr;
     {
         ProfScope ps(c, 1, op.geom, 0, ws);
         LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, ws));
@@ -868,6 +883,19 @@ int nchw_to_nhwc(const float* src, float* dst, int N, int H, int W, int C, hipSt
     return 0;
 }
 long layer_out_offset(const Layer& L) { return L.kind == K_NB ? L.b[4] : L.b[1]; }
+// The part of the workspace layers [first, last) touch: the input slot of `first` (the previous layer's output) through the end of
+// `last - 1`'s region, and the globals behind the layers (packed weights, statistics rows, ONE partial-row region, the three
+// gradient buffers) -- not the other layers' activations and not the per-weight-gradient partial regions of the full pass.
+void range_span(const lf_erfnet_plan* P, int first, int last, long* lo, long* hi) {
+    const Layer& Lf = P->layers[first];
+    *lo = first > 0 ? (Lf.x < Lf.reg_lo ? Lf.x : Lf.reg_lo) : Lf.reg_lo;
+    *hi = last < (int)P->layers.size() ? P->layers[last].reg_lo : P->off_globals;
+}
+void compact(Ctx& c, int first, int last) {
+    range_span(c.P, first, last, &c.lo, &c.hi);
+    c.cut = c.P->off_globals;
+    c.no_batch = true;
+}
 int check_range(const lf_erfnet_plan* P, int first, int last, int head, const char* who) {
     LF_REQUIRE(P && first >= 0 && last > first && last <= (int)P->layers.size(), "%s: bad layer range [%d, %d)", who, first, last);
     LF_REQUIRE(head < 0 || (last == (int)P->layers.size() && head < P->n_heads), "%s: the head follows the last layer only", who);
@@ -879,6 +907,15 @@ int check_range(const lf_erfnet_plan* P, int first, int last, int head, const ch
 extern "C" {
 
 int lf_erfnet_num_layers(const lf_erfnet_plan* P) { return (int)P->layers.size(); }
+// Bytes of the COMPACT workspace lf_erfnet_forward_range / _backward_range run layers [first, last) on: the range's own activations
+// + the globals.  (A loop over the blocks of a network -- `for l in net.encoder.layers: x = l(x)` -- keeps one such workspace per
+// block until its backward: together the activations of ONE network, not one whole-network workspace per block.)
+size_t lf_erfnet_range_workspace_bytes(const lf_erfnet_plan* P, int first, int last) {
+    if (!P || first < 0 || last <= first || last > (int)P->layers.size()) return 0;
+    long lo, hi;
+    range_span(P, first, last, &lo, &hi);
+    return (size_t)((hi - lo) + (P->off_wpart_all - P->off_globals)) * sizeof(float);
+}
 // out6 = {Cin, Hin, Win, Cout, Hout, Wout} of a layer (module order: 0 = encoder.initial_block, 1.. = encoder.layers, then decoder.layers)
 int lf_erfnet_layer_io(const lf_erfnet_plan* P, int layer, int* out6) {
     LF_REQUIRE(P && out6 && layer >= 0 && layer < (int)P->layers.size(), "lf_erfnet_layer_io: layer %d out of range", layer);
@@ -894,8 +931,9 @@ int lf_erfnet_forward_range(const lf_erfnet_plan* P, int first, int last, int he
                             const float* dropmask, int training, float* y, void* workspace, size_t workspace_bytes, void* stream) {
     LF_TRY(check_range(P, first, last, head, "lf_erfnet_forward_range"));
     LF_REQUIRE(x && y && params_host && params_dev && running_host && workspace, "lf_erfnet_forward_range: null pointer");
-    LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_forward_range: workspace too small");
+    LF_REQUIRE(workspace_bytes >= lf_erfnet_range_workspace_bytes(P, first, last), "lf_erfnet_forward_range: workspace too small");
     Ctx c{P, (float*)workspace, params_host, nullptr, running_host, dropmask, training, (hipStream_t)stream};
+    compact(c, first, last);
     LF_TRY(upload_and_pack(c, params_dev));
     const Layer& Lf = P->layers[first];
     if (first > 0) LF_TRY(nchw_to_nhwc(x, c.at(Lf.x), P->N, Lf.Hin, Lf.Win, Lf.Cin, c.st));
@@ -915,8 +953,9 @@ int lf_erfnet_backward_range(const lf_erfnet_plan* P, int first, int last, int h
                              float* gx, void* workspace, size_t workspace_bytes, void* stream) {
     LF_TRY(check_range(P, first, last, head, "lf_erfnet_backward_range"));
     LF_REQUIRE(x && gy && params_host && grads_host && workspace, "lf_erfnet_backward_range: null pointer");
-    LF_REQUIRE(workspace_bytes >= lf_erfnet_workspace_bytes(P), "lf_erfnet_backward_range: workspace too small");
+    LF_REQUIRE(workspace_bytes >= lf_erfnet_range_workspace_bytes(P, first, last), "lf_erfnet_backward_range: workspace too small");
     Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, training, (hipStream_t)stream};
+    compact(c, first, last);
     float *gA = c.at(P->off_gA), *gB = c.at(P->off_gB), *gC = c.at(P->off_gC);
     const Layer& Ll = P->layers[last - 1];
     if (head >= 0) {

@@ -228,11 +228,13 @@ int lf_linear_bwd(const float* x, const float* w, const float* y, const float* g
     return 0;
 }
 
-// Segmentation-mode fit input: logits (N,C,H,W) NCHW -> maps (N,L,H,W), L = C - 1 lanes (2 or 4); zero_rows masked rows;
+// Segmentation-mode fit input: logits (N,C,H,W) NCHW -> maps (N,L,H,W), L lanes (normally C - 1: 2 or 4); zero_rows masked rows;
 // gt_line (N,L) fp32 device flags or NULL (BP only: "prevent singular matrix").  See the file header.
 int lf_seg_maps(const float* logits, const float* gt_line, float* maps, int N, int C, int L, int H, int W, int zero_rows,
                 void* stream) {
-    LF_REQUIRE(logits && maps && N > 0 && C >= 2 && L >= 1 && L < C && H > 0 && W > 0 && zero_rows >= 0 && zero_rows <= H,
+    // (L >= C is allowed: a net built with out_channels == lanes and called with end_to_end=False -- the lanes beyond C - 1 never win
+    // the arg-max and come out all zero, as in the reference's statement sequence)
+    LF_REQUIRE(logits && maps && N > 0 && C >= 1 && L >= 1 && H > 0 && W > 0 && zero_rows >= 0 && zero_rows <= H,
                "lf_seg_maps: bad arguments (N=%d C=%d L=%d H=%d W=%d zero_rows=%d)", N, C, L, H, W, zero_rows);
     const long P = (long)H * W;
     hipLaunchKernelGGL(seg_maps_kernel, dim3(lf_cdiv(P, 256), N), dim3(256), 0, (hipStream_t)stream, logits, gt_line, maps, N, C, L,

@@ -142,7 +142,8 @@ int lf_debug_conv1d_wgrad_phases(const float* x, const float* gy, int N, int H, 
 long lf_conv1d_scratch_floats(int N, int H, int W, int C) {
     const LfTapGeom g = conv1d_geom(N, H, W, C, 0, 1);
     long a = 8L * C * C;        // fp32-packed weights + their 3-piece bf16 split (4.5 C^2 floats)
-    long b = (long)lf_tapwgrad_splits(g) * 3 * C * C + (long)lf_tapwgrad_bias_rows(g) * C;
+    const long rows = lf_tapwgrad_splits_bound(g, 1);          // either storage type
+    long b = rows * 3 * C * C + rows * C;
     return a > b ? a : b;
 }
 
@@ -194,7 +195,7 @@ int conv1d_bwd_weight(const float* x, const float* gy, const float* sc, const fl
     a.x = x; a.g = gy; a.pro_sc = sc; a.pro_sh = sh; a.s16 = g_ops_bf16 == 2;
     a.split = (g_ops_bf16 == 9 || g_ops_bf16 == 6) ? g_ops_bf16 : 0;
     a.partial = scratch;
-    a.bias_partial = gb ? scratch + (long)lf_tapwgrad_splits(g) * 3 * C * C : nullptr;
+    a.bias_partial = gb ? scratch + (long)lf_tapwgrad_splits_bound(g, 1) * 3 * C * C : nullptr;
     int rc = lf_tapwgrad_launch(g, a, pro, st);
     if (rc) return rc;
     const int idx[3] = {0, 1, 2};

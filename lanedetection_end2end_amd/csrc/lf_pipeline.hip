@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
                                                              int crop_top, const int* __restrict__ tables, int oh, int ow,
                                                              int ksx, int ksy, int TILE_H, int TILE_W, int max_rows, int in_stride,
                                                              const uint8_t* __restrict__ flip, float* __restrict__ out,
-                                                             const int64_t* __restrict__ sel) {
+                                                             const int64_t* __restrict__ sel, long pool_frames, int* __restrict__ bad_index) {
     extern __shared__ uint8_t smem[];
     const int h_stride = TILE_W * 3;
     int* s_shift = reinterpret_cast<int*>(smem);                                  // [max_rows + 1] byte shift of each staged row
@@ -125,10 +125,17 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
     const int r0 = T.by[2 * ty0], r1 = T.by[2 * (ty0 + th - 1)] + T.by[2 * (ty0 + th - 1) + 1];
     const int c0 = T.bx[2 * tx0], c1 = T.bx[2 * (tx0 + tw - 1)] + T.bx[2 * (tx0 + tw - 1) + 1];
     const int nr = r1 - r0, ncb = (c1 - c0) * 3;
+    // sel: batch element n reads frame sel[n] of a resident pool.  An index outside the pool (the reference's tensor indexing raises
+    // IndexError) is COUNTED -- the host raises from the count, lf_pipeline.py -- and reads frame 0 here instead of someone else's memory.
+    long frame = sel ? sel[n] : n;
+    if (frame < 0 || frame >= pool_frames) {
+        if (bad_index && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(bad_index, 1);
+        frame = 0;
+    }
     for (int r = wave; r < nr; r += 4) {
         // sel: batch element n reads frame sel[n] of a resident pool (the gather of a cached dataset's index batch happens here,
         // not in a separate 88 MB copy)
-        const size_t g0 = (((size_t)(sel ? sel[n] : n) * Hin + crop_top + r0 + r) * Win + c0) * 3;
+        const size_t g0 = (((size_t)frame * Hin + crop_top + r0 + r) * Win + c0) * 3;
         const int sh = (int)(g0 & 3);
         const size_t a0 = g0 - sh;
         const int nd = (sh + ncb + 3) >> 2;
@@ -205,10 +212,15 @@ __global__ __launch_bounds__(256) void label_kernel(const uint8_t* __restrict__ 
                                                    const int* __restrict__ tables, int oh, int ow, int ksx, int ksy,
                                                    const uint8_t* __restrict__ flip, int mode,
                                                    const int64_t* __restrict__ lut, int64_t* __restrict__ out,
-                                                   const int64_t* __restrict__ sel) {
+                                                   const int64_t* __restrict__ sel, long pool_frames, int* __restrict__ bad_index) {
     const Tables T = table_ptrs(tables, oh, ow, ksx, ksy);
     const int n = blockIdx.z, y = blockIdx.y;
-    const uint8_t* row = labels + ((size_t)(sel ? sel[n] : n) * Hin + crop_top + T.nty[y]) * Win;
+    long frame = sel ? sel[n] : n;
+    if (frame < 0 || frame >= pool_frames) {          // counted for the host (IndexError), never dereferenced
+        if (bad_index && blockIdx.x == 0 && y == 0 && threadIdx.x == 0) atomicAdd(bad_index, 1);
+        frame = 0;
+    }
+    const uint8_t* row = labels + ((size_t)frame * Hin + crop_top + T.nty[y]) * Win;
     const bool fl = flip && flip[n];
     for (int x = blockIdx.x * 256 + threadIdx.x; x < ow; x += gridDim.x * 256) {
         const int u = row[T.ntx[x]];                      // unflipped label at (y, x)
@@ -322,14 +334,14 @@ int lf_pipeline_tables_host(const lf_pipeline_plan* P, int* ksx, int* ksy, int* 
 // frames (N, Hin, Win, 3) uint8 HWC (what the image decoder produces); flip (N) uint8 or NULL;
 // out (N, 3, out_h, out_w) fp32 in [0, 1].
 static int pipeline_image(const lf_pipeline_plan* P, const uint8_t* frames, long pool_frames, const int64_t* sel, int N,
-                          const void* tables_dev, const uint8_t* flip, float* out, void* stream) {
+                          const void* tables_dev, const uint8_t* flip, float* out, int* bad_index, void* stream) {
     LF_REQUIRE(P && frames && tables_dev && out && N > 0 && pool_frames > 0, "lf_pipeline_image: bad arguments");
     const dim3 grid(lf_cdiv(P->out_w, P->tile_w), lf_cdiv(P->out_h, P->tile_h), N);
     const size_t total = (size_t)pool_frames * P->Hin * P->Win * 3;
 #define LF_RESIZE_LAUNCH(KX, KY)                                                                                              \
     hipLaunchKernelGGL((resize_bilinear_kernel<KX, KY>), grid, dim3(256), P->lds_bytes, (hipStream_t)stream, frames, total,   \
                        P->Hin, P->Win, P->crop_top, (const int*)tables_dev, P->out_h, P->out_w, P->ksx, P->ksy, P->tile_h,    \
-                       P->tile_w, P->max_rows, P->in_stride, flip, out, sel)
+                       P->tile_w, P->max_rows, P->in_stride, flip, out, sel, pool_frames, bad_index)
     if (P->ksx == 7 && P->ksy == 7) LF_RESIZE_LAUNCH(7, 7);          // 640x1280 -> 256x512 (x2.5)
     else if (P->ksx == 5 && P->ksy == 5) LF_RESIZE_LAUNCH(5, 5);     // -> 320x640 (x2), 512x1024 (x1.25)
     else LF_RESIZE_LAUNCH(0, 0);
@@ -337,12 +349,12 @@ static int pipeline_image(const lf_pipeline_plan* P, const uint8_t* frames, long
     LF_CHECK_LAUNCH("lf_pipeline_image");
     return 0;
 }
-static int pipeline_label(const lf_pipeline_plan* P, const uint8_t* labels, const int64_t* sel, int N, const void* tables_dev,
-                          const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon, void* stream) {
-    LF_REQUIRE(P && labels && tables_dev && lut && out && N > 0, "lf_pipeline_label: bad arguments");
+static int pipeline_label(const lf_pipeline_plan* P, const uint8_t* labels, long pool_frames, const int64_t* sel, int N, const void* tables_dev,
+                          const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon, int* bad_index, void* stream) {
+    LF_REQUIRE(P && labels && tables_dev && lut && out && N > 0 && pool_frames > 0, "lf_pipeline_label: bad arguments");
     const dim3 grid(lf_cdiv(P->out_w, 256), P->out_h, N);
     hipLaunchKernelGGL(label_kernel, grid, dim3(256), 0, (hipStream_t)stream, labels, P->Hin, P->Win, P->crop_top,
-                       (const int*)tables_dev, P->out_h, P->out_w, P->ksx, P->ksy, flip, mode, lut, out, sel);
+                       (const int*)tables_dev, P->out_h, P->out_w, P->ksx, P->ksy, flip, mode, lut, out, sel, pool_frames, bad_index);
     if (horizon)
         hipLaunchKernelGGL(horizon_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, out, P->out_h, P->out_w, horizon);
     LF_CHECK_LAUNCH("lf_pipeline_label");
@@ -353,26 +365,30 @@ static int pipeline_label(const lf_pipeline_plan* P, const uint8_t* labels, cons
 // out (N, 3, out_h, out_w) fp32 in [0, 1].
 int lf_pipeline_image(const lf_pipeline_plan* P, const uint8_t* frames, int N, const void* tables_dev, const uint8_t* flip,
                       float* out, void* stream) {
-    return pipeline_image(P, frames, N, nullptr, N, tables_dev, flip, out, stream);
+    return pipeline_image(P, frames, N, nullptr, N, tables_dev, flip, out, nullptr, stream);
 }
 // The same from a RESIDENT POOL of decoded frames (pool_frames, Hin, Win, 3): batch element n is frame sel[n] (int64 on the
 // device) -- the index batch of a cached dataset is gathered inside the resize kernel instead of by a copy of N frames first.
+// bad_index (device int, may be NULL): incremented once per batch element whose sel[n] lies outside [0, pool_frames); such an
+// element reads pool entry 0 (never out of bounds) and the caller raises from the count (the reference's tensor indexing raises
+// IndexError).
 int lf_pipeline_image_indexed(const lf_pipeline_plan* P, const uint8_t* pool, long pool_frames, const int64_t* sel, int N,
-                              const void* tables_dev, const uint8_t* flip, float* out, void* stream) {
+                              const void* tables_dev, const uint8_t* flip, float* out, int* bad_index, void* stream) {
     LF_REQUIRE(sel, "lf_pipeline_image_indexed: null index");
-    return pipeline_image(P, pool, pool_frames, sel, N, tables_dev, flip, out, stream);
+    return pipeline_image(P, pool, pool_frames, sel, N, tables_dev, flip, out, bad_index, stream);
 }
 
 // labels (N, Hin, Win) uint8 palette indices; lut (256) int64 = (ToTensor(v) * 255).long(); out (N, 1, out_h, out_w)
 // int64; horizon (N, out_h) fp32 or NULL.  mode: see label_kernel.
 int lf_pipeline_label(const lf_pipeline_plan* P, const uint8_t* labels, int N, const void* tables_dev, const uint8_t* flip,
                       int mode, const int64_t* lut, int64_t* out, float* horizon, void* stream) {
-    return pipeline_label(P, labels, nullptr, N, tables_dev, flip, mode, lut, out, horizon, stream);
+    return pipeline_label(P, labels, N, nullptr, N, tables_dev, flip, mode, lut, out, horizon, nullptr, stream);
 }
-int lf_pipeline_label_indexed(const lf_pipeline_plan* P, const uint8_t* pool, const int64_t* sel, int N, const void* tables_dev,
-                              const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon, void* stream) {
+int lf_pipeline_label_indexed(const lf_pipeline_plan* P, const uint8_t* pool, long pool_frames, const int64_t* sel, int N,
+                              const void* tables_dev, const uint8_t* flip, int mode, const int64_t* lut, int64_t* out, float* horizon,
+                              int* bad_index, void* stream) {
     LF_REQUIRE(sel, "lf_pipeline_label_indexed: null index");
-    return pipeline_label(P, pool, sel, N, tables_dev, flip, mode, lut, out, horizon, stream);
+    return pipeline_label(P, pool, pool_frames, sel, N, tables_dev, flip, mode, lut, out, horizon, bad_index, stream);
 }
 
 }  // extern "C"

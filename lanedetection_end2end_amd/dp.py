@@ -26,6 +26,11 @@ def broadcast_parameters(module, src=0, group=None):
 
 TAIL = 8          # trailing fp32 slots of the flat bucket reserved for the reducer (signature of the active parameter set)
 HASH_MODS = (31, 61, 64)      # small moduli: h and h^2 (<= 3969) and their means stay exact to ~1e-3 in fp32 under any rounding
+# The signature check is sound up to this many ranks: the disagreement threshold below shrinks like 1 / (2 world) while the fp32
+# error of mean(h^2) under RCCL's pre-scaled AVG grows like 3969 * 2^-24 * (1 + log2 world) -- 3.4e-3 against a threshold of 7.7e-3
+# at 64 ranks, equal near 100.  north_star is one node of 8 GPUs; beyond 64 the reducer refuses to start rather
+# than raise spuriously mid-run.
+MAX_WORLD = 64
 
 
 def signature_disagrees(tail, world):
@@ -70,6 +75,9 @@ class FlatGradAllReduce:
         all-reduce then runs in place on it, without flatten / unflatten copies."""
         self.params = list(params)
         self.group = group
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > MAX_WORLD:
+            raise ValueError("FlatGradAllReduce: %d ranks; the in-band signature check is sound up to %d (dp.MAX_WORLD)"
+                             % (dist.get_world_size(group), MAX_WORLD))
         self.active = None
         self.flat_provider = flat_provider
         self.strict = strict

@@ -185,7 +185,10 @@ class _BackboneFn(torch.autograd.Function):
         lib = _lib.load()
         N, H, W = plan.shape
         dev = x.device
-        ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+        ctx.precision = _PRECISIONS[net.precision]
+        _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
+        ctx.ws_bytes = lib.lf_erfnet_workspace_bytes(plan.handle)      # follows the precision mode (partial-row regions of the bf16 weight gradient)
+        ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=dev)
         # head = -1: encoder only (only_encode=True): no decoder launches, no logits
         logits = (torch.empty(N, net.out_channels + head, H, W, dtype=torch.float32, device=dev) if head >= 0 else
                   torch.empty(0, dtype=torch.float32, device=dev))
@@ -194,12 +197,10 @@ class _BackboneFn(torch.autograd.Function):
             assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
         host = net._ptrs.get("params", params)
         devarr = net._device_ptr_table(params)
-        ctx.precision = _PRECISIONS[net.precision]
-        _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         running = net._ptrs.get("running", net._running_buffers())
         _lib.check(lib.lf_erfnet_forward(plan.handle, _lib.ptr(x), host, _lib.ptr(devarr), running,
                                          _lib.ptr(dropmask), int(training), head, _lib.ptr(logits) if head >= 0 else None,
-                                         _lib.ptr(ws), plan.ws_bytes, _lib.stream()), "lf_erfnet_forward")
+                                         _lib.ptr(ws), ctx.ws_bytes, _lib.stream()), "lf_erfnet_forward")
         ctx.set_materialize_grads(False)
         if head < 0:
             ctx.mark_non_differentiable(logits)
@@ -263,7 +264,7 @@ class _BackboneFn(torch.autograd.Function):
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         _lib.check(lib.lf_erfnet_backward(plan.handle, _lib.ptr(ctx.x), _lib.ptr(glogits), _lib.ptr(genc),
                                           ctx.net._ptrs.get("params", params), ctx.net._ptrs.get("grads", grads), _lib.ptr(ctx.dropmask), ctx.training,
-                                          ctx.head, _lib.ptr(ctx.ws), plan.ws_bytes, _lib.stream()), "lf_erfnet_backward")
+                                          ctx.head, _lib.ptr(ctx.ws), ctx.ws_bytes, _lib.stream()), "lf_erfnet_backward")
         ctx.ws = None
         return (None, None, None, None, None, None) + tuple(grads)
 
@@ -302,7 +303,11 @@ class _PointwiseFn(torch.autograd.Function):
 
 
 class _RangeFn(torch.autograd.Function):
-    """Layers [first, last) of the plan (+ optional head) on an NCHW tensor: lf_erfnet_forward_range / _backward_range."""
+    """Layers [first, last) of the plan (+ optional head) on an NCHW tensor: lf_erfnet_forward_range / _backward_range.
+
+    The call owns a COMPACT workspace (the range's activations + the plan's globals, ``lf_erfnet_range_workspace_bytes``) until its
+    backward: ``for l in net.encoder.layers: x = l(x)`` keeps the activations of one network, not a whole-network workspace per
+    block.  With ``first == 0`` the input is the image and receives no gradient (``gx`` is None), as in the full pass."""
 
     @staticmethod
     def forward(ctx, net, plan, x, first, last, head, training, dropmask, *params):
@@ -311,7 +316,8 @@ class _RangeFn(torch.autograd.Function):
         io = (ctypes.c_int * 6)()
         _lib.check(lib.lf_erfnet_layer_io(plan.handle, last - 1, io), "lf_erfnet_layer_io")
         oshape = (N, net.out_channels + head, H, W) if head >= 0 else (N, io[3], io[4], io[5])
-        ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=x.device)
+        ctx.ws_bytes = lib.lf_erfnet_range_workspace_bytes(plan.handle, first, last)
+        ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=x.device)
         y = torch.empty(oshape, dtype=torch.float32, device=x.device)
         params = [p.detach() for p in params]
         host = net._ptrs.get("params", params)
@@ -320,7 +326,7 @@ class _RangeFn(torch.autograd.Function):
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
         running = net._ptrs.get("running", net._running_buffers())
         _lib.check(lib.lf_erfnet_forward_range(plan.handle, first, last, head, _lib.ptr(x), host, _lib.ptr(devarr), running,
-                                               _lib.ptr(dropmask), int(training), _lib.ptr(y), _lib.ptr(ws), plan.ws_bytes,
+                                               _lib.ptr(dropmask), int(training), _lib.ptr(y), _lib.ptr(ws), ctx.ws_bytes,
                                                _lib.stream()), "lf_erfnet_forward_range")
         ctx.set_materialize_grads(False)
         ctx.net, ctx.plan, ctx.cfg, ctx.ws, ctx.x, ctx.dropmask, ctx.params = net, plan, (first, last, head), ws, x, dropmask, params
@@ -341,7 +347,7 @@ class _RangeFn(torch.autograd.Function):
         _lib.check(lib.lf_erfnet_set_precision(ctx.plan.handle, ctx.precision), "lf_erfnet_set_precision")
         _lib.check(lib.lf_erfnet_backward_range(ctx.plan.handle, first, last, head, _lib.ptr(ctx.x), _lib.ptr(gy),
                                                 _ptr_array(ctx.params), _ptr_array(grads), _lib.ptr(ctx.dropmask), ctx.training,
-                                                _lib.ptr(gx), _lib.ptr(ctx.ws), ctx.plan.ws_bytes, _lib.stream()),
+                                                _lib.ptr(gx), _lib.ptr(ctx.ws), ctx.ws_bytes, _lib.stream()),
                    "lf_erfnet_backward_range")
         ctx.ws = None
         return (None, None, gx, None, None, None, None, None) + tuple(grads)

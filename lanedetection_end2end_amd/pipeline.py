@@ -33,6 +33,20 @@ class InputPipeline:
         self.mode = (1 if (tree == "bev" or nclasses < 3) else 0) | (2 if tree == "bp" else 0)
         self._tables = None
         self._lut = None
+        # Out-of-pool indices (``index`` form): the kernels count them on the device and read pool entry 0 instead; the count of
+        # call k is copied to pinned memory right behind its kernels (``_lib.DeferredRead``) and inspected at the START of call
+        # k + 1 or by flush() -- IndexError like the reference's tensor indexing, one call late, without a host sync per step.
+        self._bad = None
+        self._pending = None
+
+    def flush(self):
+        """Raise now if the previous indexed call saw an index outside the pool."""
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            n = int(pend[0].get()[0])
+            if n:
+                self._bad.zero_()
+                raise IndexError("InputPipeline: %d index value(s) outside the pool of %d frames" % (n, pend[1]))
 
     def __del__(self):
         try:
@@ -76,8 +90,11 @@ class InputPipeline:
         sel = None
         N = pool
         if index is not None:
+            self.flush()
             sel = index.to(device=dev, dtype=torch.int64).contiguous()
             N = sel.numel()
+            if self._bad is None or self._bad.device != dev:
+                self._bad = torch.zeros(1, dtype=torch.int32, device=dev)
         fl = None if flip is None else flip.to(device=dev, dtype=torch.uint8).contiguous()
         frames_u8 = frames_u8.contiguous()
         image = torch.empty(N, 3, R, 2 * R, dtype=torch.float32, device=dev)
@@ -86,7 +103,8 @@ class InputPipeline:
                                              _lib.ptr(image), _lib.stream()), "lf_pipeline_image")
         else:
             _lib.check(lib.lf_pipeline_image_indexed(self.handle, _lib.ptr(frames_u8), pool, _lib.ptr(sel), N, _lib.ptr(tables),
-                                                     _lib.ptr(fl), _lib.ptr(image), _lib.stream()), "lf_pipeline_image_indexed")
+                                                     _lib.ptr(fl), _lib.ptr(image), _lib.ptr(self._bad), _lib.stream()),
+                       "lf_pipeline_image_indexed")
         gt = horizon = None
         if labels_u8 is not None:
             assert labels_u8.shape == (pool, H, W) and labels_u8.dtype == torch.uint8
@@ -99,9 +117,11 @@ class InputPipeline:
                                                  self.mode, _lib.ptr(lut), _lib.ptr(gt), _lib.ptr(horizon), _lib.stream()),
                            "lf_pipeline_label")
             else:
-                _lib.check(lib.lf_pipeline_label_indexed(self.handle, _lib.ptr(labels_u8), _lib.ptr(sel), N, _lib.ptr(tables),
+                _lib.check(lib.lf_pipeline_label_indexed(self.handle, _lib.ptr(labels_u8), pool, _lib.ptr(sel), N, _lib.ptr(tables),
                                                          _lib.ptr(fl), self.mode, _lib.ptr(lut), _lib.ptr(gt), _lib.ptr(horizon),
-                                                         _lib.stream()), "lf_pipeline_label_indexed")
+                                                         None, _lib.stream()), "lf_pipeline_label_indexed")
+        if sel is not None:
+            self._pending = (_lib.DeferredRead(self._bad), pool)      # (the image kernel counted: the label kernel sees the same indices)
         return image, gt, horizon
 
 

@@ -231,3 +231,88 @@ def test_bp_main_loop_body(bp_tree_on_path, clas, nclasses):
     assert np.isfinite(losses.sum) and np.isfinite(losses_skip.sum) and np.isfinite(rmse_metric.sum)
     assert not torch.equal(model.net.encoder.initial_block.conv.weight.detach(), w0)       # the optimizer moved the weights
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("end_to_end", [True, False])
+def test_bev_validate_body(bev_tree_on_path, end_to_end):
+    """BEV/main.py:362-501, validate(): ``model.eval()`` under ``torch.no_grad()``, the loader's 7-tuples, ``model(input,
+    args.end_to_end)`` inside the ``except RuntimeError: continue`` guard, ``criterion`` per lane (end-to-end) or
+    ``criterion_seg(output_net, gt)`` + the area metric (segmentation mode), the exact-area metric on ``.cpu()`` copies through
+    ``polynomial(...).trapezoidal(...)``, ``AverageMeter`` updates from ``.item()`` -- statement by statement on the mirror's import
+    names.  Checked against the fp64 oracle in the same mode (eval: running statistics) and for what eval mode promises: no
+    gradient graph, running statistics and ``num_batches_tracked`` untouched, a second pass bit-identical."""
+    Net = importlib.import_module("Networks.LSQ_layer").Net
+    Loss_crit = importlib.import_module("Loss_crit")
+    define_loss_crit, polynomial = Loss_crit.define_loss_crit, Loss_crit.polynomial
+    from oracle import e2e_oracle, erfnet_oracle
+    N, R = 2, 64
+    args = Namespace(batch_size=N, nclasses=2, resize=R, end_to_end=end_to_end, mod="erfnet", layers=18, channels_in=3, pretrained=False,
+                     pool=True, activation_layer="square", no_cuda=False, order=2, reg_ls=0.0, use_cholesky=False,
+                     mask_percentage=0.3, clas=False, loss_policy="area", weight_funct="none", weight_seg=30, evaluate=True, print_freq=1)
+    torch.manual_seed(5)
+    model = Net(args).cuda()
+    criterion, criterion_seg = define_loss_crit(args)
+    rng = np.random.default_rng(21)
+    # non-trivial running statistics: one train-mode step first (what a checkpoint carries into validate())
+    model.train()
+    with torch.no_grad():
+        model(torch.from_numpy(inputs.images(N, R, 2 * R, seed=700)).cuda(), True)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def loader(nbatches):                                                  # the 7-tuple of the validation loader (main.py:378)
+        for i in range(nbatches):
+            yield (torch.from_numpy(inputs.images(N, R, 2 * R, seed=710 + i)),
+                   torch.from_numpy(rng.integers(0, 3, (N, 1, R, 2 * R))), torch.from_numpy(inputs.bev_gt_params(N, seed=720 + i)),
+                   torch.arange(N) + i * N, torch.from_numpy(rng.integers(0, 3, (N, 4))),
+                   torch.from_numpy((rng.uniform(0, 1, (N, R)) > 0.5).astype(np.float32)), list(range(i * N, (i + 1) * N)))
+
+    def validate():
+        losses, avg_area, avg_trapezium_rule = AverageMeter(), AverageMeter(), AverageMeter()
+        model.eval()                                                        # main.py:373
+        seen = []
+        with torch.no_grad():                                               # main.py:376
+            for i, (input, gt, params, idx, gt_line, gt_horizon, index) in enumerate(loader(3)):
+                if not args.no_cuda:
+                    input, params = input.cuda(non_blocking=True), params.cuda(non_blocking=True)
+                    input = input.float()
+                gt0, gt1, gt2, gt3 = params[:, 0, :], params[:, 1, :], params[:, 2, :], params[:, 3, :]
+                try:                                                        # main.py:386-392
+                    beta0, beta1, beta2, beta3, weightmap_zeros, M, output_net, outputs_line, outputs_horizon = model(input, args.end_to_end)
+                except RuntimeError as e:
+                    print("Batch with idx {} skipped due to singular matrix".format(idx.numpy()), e)
+                    continue
+                if args.end_to_end:                                         # main.py:395-396
+                    loss = criterion(beta0, gt0) + criterion(beta1, gt1)
+                else:                                                       # main.py:412-416
+                    gt = gt.cuda(non_blocking=True)
+                    loss = criterion_seg(output_net, gt)
+                    area = criterion(beta0, gt0) + criterion(beta1, gt1)
+                    avg_area.update(area.item(), input.size(0))
+                gt_left_lines = polynomial(gt0.cpu())                       # main.py:437-445
+                gt_right_lines = polynomial(gt1.cpu())
+                pred_left_lines = polynomial(beta0.cpu())
+                pred_right_lines = polynomial(beta1.cpu())
+                trap_left = pred_left_lines.trapezoidal(gt_left_lines)
+                trap_right = pred_right_lines.trapezoidal(gt_right_lines)
+                avg_trapezium_rule.update(((trap_left + trap_right) / 2).mean().item(), input.size(0))
+                losses.update(loss.item(), input.size(0))
+                assert not loss.requires_grad and not output_net.requires_grad and beta0.grad_fn is None
+                seen.append((input.cpu(), params.cpu().numpy(), torch.stack([beta0, beta1], 1)[..., 0].cpu().numpy(), loss.item(),
+                             output_net.cpu(), gt if not args.end_to_end else None))
+        return losses, avg_area, avg_trapezium_rule, seen
+
+    l1, a1, t1, seen = validate()
+    assert l1.count == 3 * N and np.isfinite(l1.sum) and np.isfinite(t1.sum) and (end_to_end or np.isfinite(a1.sum))
+    # eval mode leaves the model untouched
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    l2, _, t2, seen2 = validate()
+    assert l2.sum == l1.sum and t2.sum == t1.sum and all(np.array_equal(u[2], v[2]) for u, v in zip(seen, seen2))
+    # against the CPU oracle in eval mode: logits of every batch, coefficients / loss where the fit is end to end
+    P = {k: v.detach().cpu() for k, v in model.net.state_dict().items()}
+    for x, params, beta, loss, logits, gt in seen:
+        o = e2e_oracle.bev_step(x, P, params, torch.float64, R, training=False)
+        scale = np.abs(o["logits"]).max()
+        assert np.abs(logits.double().numpy() - o["logits"]).max() <= 2e-5 * scale
+        if end_to_end:
+            assert e2e_oracle.relerr(beta, o["beta"]) <= 1e-5 and abs(loss - o["loss"]) <= 1e-5 * abs(o["loss"])

@@ -109,3 +109,25 @@ def test_pipeline_indexed_pool_equals_gather_then_pipeline(frames):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         assert (a[2] is None and b[2] is None) or torch.equal(a[2], b[2])
         assert a[0].shape == (6, 3, R, 2 * R)
+
+
+def test_pipeline_index_outside_the_pool_raises(frames):
+    """An index outside the resident pool -- stale, negative, >= pool -- must not read foreign memory: the kernels count it and read
+    pool entry 0 instead, the host raises IndexError (as the reference's tensor indexing does) at the next call or at flush(),
+    without a host sync in the step itself."""
+    from lanedetection_end2end_amd.pipeline import InputPipeline
+    pool_f = torch.from_numpy(np.stack([frames[0][0], frames[1][0]])).cuda()
+    pool_l = torch.from_numpy(np.stack([frames[0][1], frames[1][1]])).cuda()
+    pipe = InputPipeline(64, tree="bev", nclasses=2)
+    good = pipe(pool_f, pool_l, None, index=torch.tensor([1, 0], device="cuda"))
+    pipe.flush()                                                     # nothing pending
+    out = pipe(pool_f, pool_l, None, index=torch.tensor([1, 2, -1, 0], device="cuda"))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0]).all()
+    assert torch.equal(out[0][1], good[0][1]) and torch.equal(out[0][2], good[0][1])      # the bad entries read pool entry 0
+    assert torch.equal(out[0][0], good[0][0]) and torch.equal(out[1][3], good[1][1])
+    with pytest.raises(IndexError, match="2 index value"):
+        pipe(pool_f, pool_l, None, index=torch.tensor([0, 1], device="cuda"))
+    ok = pipe(pool_f, pool_l, None, index=torch.tensor([0, 1], device="cuda"))                  # the counter was reset
+    pipe.flush()
+    assert torch.equal(ok[0][0], good[0][1])
