@@ -252,7 +252,6 @@ def test_bev_validate_body(bev_tree_on_path, end_to_end):
     torch.manual_seed(5)
     model = Net(args).cuda()
     criterion, criterion_seg = define_loss_crit(args)
-    rng = np.random.default_rng(21)
     # non-trivial running statistics: one train-mode step first (what a checkpoint carries into validate())
     model.train()
     with torch.no_grad():
@@ -260,6 +259,7 @@ def test_bev_validate_body(bev_tree_on_path, end_to_end):
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
 
     def loader(nbatches):                                                  # the 7-tuple of the validation loader (main.py:378)
+        rng = np.random.default_rng(21)                                    # the same batches on every pass
         for i in range(nbatches):
             yield (torch.from_numpy(inputs.images(N, R, 2 * R, seed=710 + i)),
                    torch.from_numpy(rng.integers(0, 3, (N, 1, R, 2 * R))), torch.from_numpy(inputs.bev_gt_params(N, seed=720 + i)),
