@@ -39,6 +39,7 @@ PEAK_HBM = 8.0e12                   # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s 
 # rocprofv3 --pmc passes (FETCH_SIZE doubled for 16 B/lane streaming reads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE)
 # together with the commit it was measured at; None when the file is missing
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+TRAFFIC_STEP_FILE = os.path.join(ROOT, "profiles", "traffic_step.json")
 CALIBRATION_FILE = os.path.join(ROOT, "profiles", "cpu_port_calibration.json")
 TIMED_BLOCKS = 5                    # the timed region = at least TIMED_BLOCKS blocks of --steps steps each; the median block is reported
 TIMED_REGION_S = 6.5                # ... and enough blocks to span this many seconds (an outside sampler with a 5 s period sees the GPU busy)
@@ -90,6 +91,25 @@ def _sources_digest():
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def _algorithmic_bytes(csv_path, esz, psteps):
+    """Algorithmic HBM bytes per step of the two matrix-core families, from the engine's per-launch records (family, Cs, Cd, npix,
+    epilogue flags): a convolution / data gradient reads its source once and writes its destination once, plus one read per
+    epilogue tensor (ReLU-mask source, residual, BatchNorm-backward operand); a weight gradient reads x and g once."""
+    try:
+        rows = [l.strip().split(",") for l in open(csv_path)][1:]
+    except OSError:
+        return None
+    out = {"tapgemm": 0.0, "tapwgrad": 0.0}
+    for fam, layer, Cs, Cd, ntaps, npix, epi, us, tf in rows:
+        fam, Cs, Cd, npix, epi = int(fam), int(Cs), int(Cd), int(npix), int(epi) & 0xff
+        if fam == 0:
+            extra = bin(epi & (2 | 4)).count("1") + (1 if epi & (16 | 32) else 0)      # MASK, ADD; one aux tensor for MASKBN / XHAT
+            out["tapgemm"] += npix * (Cs + Cd * (1 + extra)) * esz
+        else:
+            out["tapwgrad"] += npix * (Cs + Cd) * esz
+    return {k: int(v / psteps) for k, v in out.items()}
 
 
 def _load_json(path):
@@ -419,6 +439,8 @@ def main():
                          "gloo, the barrier-bracketed timing loop around a CPU stand-in step (the flat 8.25 MB gradient all-reduce), "
                          "one JSON line from rank 0; measures nothing")
     ap.add_argument("--no-dropout", action="store_true", help="disable Dropout2d (parity-style run)")
+    ap.add_argument("--no-extras", action="store_true", help="the timed region and the roofline steps only: no fp32x9 leg, no "
+                    "baselines (counter passes: profiles/collect.sh, every launch of the run belongs to the measured step)")
     ap.add_argument("--precision", choices=["fp32", "bf16_mfma", "bf16", "fp32x9", "fp32x6"], default="fp32",
                     help="fp32 (default = the BASELINE headline); bf16_mfma = conv operands rounded to bf16, fp32 accumulation "
                          "and fp32 tensors; bf16 = bf16 matrix cores and bf16 activation/gradient tensors (config 3; not "
@@ -584,10 +606,14 @@ def main():
             step(reduce=False)     # rank 0 only: no collective here, the other ranks are already at the final barrier
         torch.cuda.synchronize()
         buf = (ctypes.c_double * 6)()
-        lib.lf_erfnet_profile_read(plan.handle, ctypes.cast(buf, ctypes.c_void_p), os.environ.get("LF_PROFILE_CSV", "").encode() or None)
+        import tempfile
+        csv_path = os.environ.get("LF_PROFILE_CSV", "") or os.path.join(tempfile.gettempdir(), "lf_profile_%d.csv" % os.getpid())
+        lib.lf_erfnet_profile_read(plan.handle, ctypes.cast(buf, ctypes.c_void_p), csv_path.encode())
         lib.lf_erfnet_profile(plan.handle, 0)
+        alg_bytes = _algorithmic_bytes(csv_path, 2 if a.precision == "bf16" else 4, psteps)
         fam = [dict(ms=buf[i * 3], flops=buf[i * 3 + 1], launches=buf[i * 3 + 2]) for i in range(2)]
         traffic = _load_json(TRAFFIC_FILE)
+        tstep = (_load_json(TRAFFIC_STEP_FILE) or {}).get("%s_%s_b%d" % (a.workload, a.precision, B))
         names = ["tapgemm_kernel (conv forward + data gradient)", "tapwgrad_kernel (weight gradient)"]
         dom = 0 if fam[0]["ms"] >= fam[1]["ms"] else 1
         d = fam[dom]
@@ -602,11 +628,29 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4),
                     # HBM-side bytes per launch of the family's representative launch (128-channel 3-tap conv, batch 32:
                     # 33.5 MB in + 33.5 MB out algorithmic) from the committed PMC summary (profiles/collect.sh)
-                    "traffic": (traffic or {}).get(("tapgemm", "tapwgrad")[dom], {}).get("bytes_per_launch")
-                    if (a.workload == "bev" and a.precision == "fp32" and B == 32) else None,
+                    # HBM-side bytes per launch: the family's launch-weighted MEAN over the whole step when the step counters exist
+                    # (traffic_step below), else the representative kbench launch of profiles/traffic.json
+                    "traffic": (int(tstep["families"][("conv forward + data gradient (tap-GEMM kernels)", "weight gradient (+ its reductions)")[dom]]["bytes_per_step"] /
+                                    max(d["launches"] / psteps, 1)) if tstep and tstep.get("families") else
+                                (traffic or {}).get(("tapgemm", "tapwgrad")[dom], {}).get("bytes_per_launch")
+                                if (a.workload == "bev" and a.precision == "fp32" and B == 32) else None),
                     "traffic_source": None if traffic is None else {"file": "profiles/traffic.json", "commit": traffic.get("commit"),
                                                                      "measured_on_these_sources": traffic.get("sources_digest") == _sources_digest(),
                                                                      "algorithmic_bytes_per_launch": traffic.get("algorithmic_bytes_per_launch")},
+                    # whole-step HBM-side bytes from counters (two rocprofv3 --pmc passes over this very command with --no-extras;
+                    # profiles/summarize_traffic_step.py): per kernel family, beside the algorithmic bytes of the same launches
+                    # (per launch: source + destination + every epilogue tensor, once each, from the engine's own launch records)
+                    "traffic_step": None if tstep is None else {
+                        "file": "profiles/traffic_step.json", "commit": tstep.get("commit"),
+                        "measured_on_these_sources": tstep.get("sources_digest") == _sources_digest(),
+                        "traffic_measured_bytes_per_step": tstep.get("total_bytes_per_step"),
+                        "families": {k: {"measured_bytes_per_step": v["bytes_per_step"], "launches_per_step": v["launches_per_step"]}
+                                     for k, v in tstep.get("families", {}).items()},
+                        "algorithmic_bytes_per_step": alg_bytes,
+                        "measured_over_algorithmic": {
+                            "conv forward + data gradient": round(tstep["families"]["conv forward + data gradient (tap-GEMM kernels)"]["bytes_per_step"] / max(alg_bytes["tapgemm"], 1), 3),
+                            "weight gradient": round(tstep["families"]["weight gradient (+ its reductions)"]["bytes_per_step"] / max(alg_bytes["tapwgrad"], 1), 3)}
+                        if alg_bytes and "conv forward + data gradient (tap-GEMM kernels)" in tstep.get("families", {}) else None},
                     "avg_launch_us": round(1e3 * d["ms"] / max(d["launches"], 1), 2),
                     "launches_per_step": d["launches"] / psteps,
                     "families": {names[i]: {"ms_per_step": round(fam[i]["ms"] / psteps, 3),
@@ -642,13 +686,18 @@ def main():
             # activation written once and read back twice (next layer's operand / backward's mask + weight-gradient operand)
             # plus the gradient ping-pong at the same volume: 6 x the bytes of the tensors a backward needs
             lib2 = _lib.load()
-            act_bytes = lib2.lf_erfnet_workspace_bytes(model.net._plan(B, R, 2 * R).handle) * (0.5 if a.precision == "bf16" else 1.0)
+            act_bytes = lib2.lf_erfnet_activation_floats(model.net._plan(B, R, 2 * R).handle) * (2 if a.precision == "bf16" else 4)
             hb = 6.0 * act_bytes / (dt / a.steps)
             out["roofline_hbm"] = {"bound": "hbm", "achieved": round(hb / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                    "frac": round(hb / PEAK_HBM, 4),
                                    "algorithmic_bytes_per_step": int(6.0 * act_bytes),
-                                   "note": "6 x the saved-activation bytes of the plan (DESIGN.md 5)"}
-        if world == 1 and a.precision == "fp32":
+                                   "note": "6 x the bytes of the activations a backward needs (the layers' own tensors: no scratch, "
+                                           "no partial rows): each written once, read by the next layer and twice by backward, plus "
+                                           "the gradient ping-pong at the same volume (DESIGN.md 5)",
+                                   # HBM-side bytes of the step from counters (profiles/traffic_step.json) and the rate they imply
+                                   "traffic_measured_bytes_per_step": None if tstep is None else tstep.get("total_bytes_per_step"),
+                                   "measured_rate_GBps": None if tstep is None else round(tstep["total_bytes_per_step"] / (dt / a.steps) / 1e9, 1)}
+        if world == 1 and a.precision == "fp32" and not a.no_extras:
             # not the headline: the same step with the 64- / 128-channel conv products formed on the bf16 matrix cores
             # from exact 3-way splits of both fp32 operands (all 9 partial products, fp32 accumulation)
             model.net.precision = "fp32x9"
@@ -666,11 +715,11 @@ def main():
                                     "note": "same workload, precision mode fp32x9 (fp32 tensors and accumulation, exact "
                                             "products via bf16 x3 splits on the bf16 matrix cores; weight gradient on the "
                                             "fp32 cores); parity tests hold it to the fp32 tolerances"}
-        if world == 1 and not a.no_vendor_baseline and a.workload == "bev":
+        if world == 1 and not a.no_vendor_baseline and not a.no_extras and a.workload == "bev":
             out["miopen_baseline"] = miopen_baseline(B, R, tune=a.vendor_tune)
             if out["miopen_baseline"].get("value"):
                 out["miopen_baseline"]["hip_over_miopen"] = round(ips / out["miopen_baseline"]["value"], 2)
-        if world == 1 and not a.no_cpu_baseline and a.workload == "bev":
+        if world == 1 and not a.no_cpu_baseline and not a.no_extras and a.workload == "bev":
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(a.precision)
     if world > 1:
         dist.barrier()

@@ -154,6 +154,7 @@ void lf_erfnet_plan_destroy(lf_erfnet_plan* plan);
  * on the fp32 matrix cores. */
 int lf_erfnet_set_precision(const lf_erfnet_plan* plan, int mode);
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* plan);   /* follows the precision mode (bf16 tensors: larger partial-row regions): query it after lf_erfnet_set_precision */
+long lf_erfnet_activation_floats(const lf_erfnet_plan* plan);   /* elements of the saved activations (all layers): bench.py's HBM roofline */
 int lf_erfnet_num_params(const lf_erfnet_plan* plan);
 int lf_erfnet_num_bn(const lf_erfnet_plan* plan);
 int lf_erfnet_num_dropout(const lf_erfnet_plan* plan);

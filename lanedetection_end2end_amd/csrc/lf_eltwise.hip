@@ -58,10 +58,23 @@ __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, doub
         const LfStatPart& q = sp.p[k];
         const int cc = c0 - q.ch_off;
         if (cc < 0 || cc >= q.C) continue;
-        for (int r = threadIdx.x; r < q.nrows; r += 256) {
-            const f32x4 a = ld4(q.rows + ((long)r * 2 + 0) * q.C + cc), b = ld4(q.rows + ((long)r * 2 + 1) * q.C + cc);
-            s1[0] += (double)a.x; s1[1] += (double)a.y; s1[2] += (double)a.z; s1[3] += (double)a.w;
-            s2[0] += (double)b.x; s2[1] += (double)b.y; s2[2] += (double)b.z; s2[3] += (double)b.w;
+        // four rows = eight 16-byte loads requested before the first add: the kernel is ONE memory round trip per loop trip (rows
+        // written by the previous launch: L2 / Infinity Cache, ~1 us), and at config 3's 3200 rows the two-load form made 13 of them
+        // -- 12 us per BatchNorm, 0.9 ms per step.  Rows beyond the count re-read row 0 and are skipped by a scalar-free select.
+        for (int r0 = threadIdx.x; r0 < q.nrows; r0 += 4 * 256) {
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * 256 < q.nrows ? r0 + u * 256 : 0;
+                a[u] = ld4(q.rows + ((long)r * 2 + 0) * q.C + cc);
+                b[u] = ld4(q.rows + ((long)r * 2 + 1) * q.C + cc);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r0 + u * 256 >= q.nrows) break;
+                s1[0] += (double)a[u].x; s1[1] += (double)a[u].y; s1[2] += (double)a[u].z; s1[3] += (double)a[u].w;
+                s2[0] += (double)b[u].x; s2[1] += (double)b[u].y; s2[2] += (double)b[u].z; s2[3] += (double)b[u].w;
+            }
         }
     }
     __shared__ double sm[4][8];
@@ -341,139 +354,6 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
     }
 }
 
-// ---- stem --------------------------------------------------------------------------------
-// Compile-time channel count: the 3x3xCIN patch lives in registers, the (16-CIN) x 9*CIN weights are read
-// as LDS broadcasts in a fully unrolled FMA nest (runtime loop bounds made this kernel 5x slower).
-constexpr int STEM_MAXCIN = 4;
-template <int CIN, typename T>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, int N, int H, int W,
-                                                      const float* __restrict__ w, const float* __restrict__ b,
-                                                      T* __restrict__ cat, float* __restrict__ rows) {
-    constexpr int Cc = 16 - CIN, KK = CIN * 9;
-    const int Ho = H / 2, Wo = W / 2;
-    __shared__ float sw[Cc * KK + 16];
-    for (int i = threadIdx.x; i < Cc * KK; i += 256) sw[i] = w[i];
-    for (int i = threadIdx.x; i < Cc; i += 256) sw[Cc * KK + i] = b[i];
-    __syncthreads();
-    const long npix = (long)N * Ho * Wo;
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    float out[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) out[i] = 0.f;
-    const bool valid = p < npix;
-    if (valid) {
-        const int ow = (int)(p % Wo);
-        const long r = p / Wo;
-        const int oh = (int)(r % Ho), n = (int)(r / Ho);
-        float patch[KK];
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-            const float* pl = img + ((long)n * CIN + ci) * H * W;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
-                    const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
-                    const float v = pl[(long)min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)];
-                    patch[ci * 9 + kh * 3 + kw] = in ? v : 0.f;
-                }
-        }
-#pragma unroll
-        for (int co = 0; co < Cc; ++co) {
-            float s = sw[Cc * KK + co];
-#pragma unroll
-            for (int j = 0; j < KK; ++j) s = fmaf(patch[j], sw[co * KK + j], s);
-            out[co] = s;
-        }
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)   // pool window = patch taps (1,1),(1,2),(2,1),(2,2)
-            out[Cc + ci] = fmaxf(fmaxf(patch[ci * 9 + 4], patch[ci * 9 + 5]), fmaxf(patch[ci * 9 + 7], patch[ci * 9 + 8]));
-        T* o = cat + p * 16;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = {out[q * 4], out[q * 4 + 1], out[q * 4 + 2], out[q * 4 + 3]};
-            lf_stv(o + q * 4, v);
-        }
-    }
-    if (rows) {
-        __shared__ float red[4][32];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = valid ? out[i] : 0.f;
-            const float s1 = lf_wave_sum(v), s2 = lf_wave_sum(v * v);
-            if (lane == 0) { red[wave][i] = s1; red[wave][16 + i] = s2; }
-        }
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-            rows[((long)blockIdx.x * 2 + (threadIdx.x >> 4)) * 16 + (threadIdx.x & 15)] = s;
-        }
-    }
-}
-
-// dW[co][ci][kh][kw] partial rows.  blockIdx.y = group of up to 4 output channels: the patch is loaded once per
-// pixel and group (4x instead of 13x), 4*9*CIN + 4 accumulators per thread.
-template <int CIN, typename T>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ gcat, int N,
-                                                        int H, int W, float* __restrict__ wrows, float* __restrict__ brows) {
-    constexpr int Cc = 16 - CIN, KK = CIN * 9, G = 4;
-    const int Ho = H / 2, Wo = W / 2, co0 = blockIdx.y * G;
-    const long npix = (long)N * Ho * Wo;
-    float acc[G][KK], bacc[G];
-#pragma unroll
-    for (int c = 0; c < G; ++c) {
-        bacc[c] = 0.f;
-#pragma unroll
-        for (int j = 0; j < KK; ++j) acc[c][j] = 0.f;
-    }
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-        const f32x4 gq = lf_ldv(gcat + p * 16 + co0);          // channels co0..co0+3 (pool channels are never used)
-        const float gv[G] = {gq.x, gq.y, gq.z, gq.w};
-        const int ow = (int)(p % Wo);
-        const long r = p / Wo;
-        const int oh = (int)(r % Ho), n = (int)(r / Ho);
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-            const float* pl = img + ((long)n * CIN + ci) * H * W;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
-                    const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
-                    const float xv = in ? pl[(long)min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)] : 0.f;
-#pragma unroll
-                    for (int c = 0; c < G; ++c) acc[c][ci * 9 + kh * 3 + kw] = fmaf(gv[c], xv, acc[c][ci * 9 + kh * 3 + kw]);
-                }
-        }
-#pragma unroll
-        for (int c = 0; c < G; ++c) bacc[c] += gv[c];
-    }
-    __shared__ float red[4][G * (KK + 1)];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < G; ++c) {
-#pragma unroll
-        for (int j = 0; j < KK; ++j) {
-            const float s = lf_wave_sum(acc[c][j]);
-            if (lane == 0) red[wave][c * (KK + 1) + j] = s;
-        }
-        const float sb = lf_wave_sum(bacc[c]);
-        if (lane == 0) red[wave][c * (KK + 1) + KK] = sb;
-    }
-    __syncthreads();
-    if (threadIdx.x < G * (KK + 1)) {
-        const int c = threadIdx.x / (KK + 1), j = threadIdx.x % (KK + 1), co = co0 + c;
-        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (co < Cc) {
-            if (j < KK) wrows[((long)blockIdx.x * Cc + co) * KK + j] = v;
-            else brows[(long)blockIdx.x * Cc + co] = v;
-        }
-    }
-}
-
 // ---- head: ConvTranspose2d(16, K, 2, stride=2), weight (16,K,2,2) -------------------------
 constexpr int HEAD_MAXK = 8;
 template <typename T>
@@ -540,65 +420,6 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
             f32x4 v = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
             lf_stv(gx + p * 16 + q * 4, v);
         }
-    }
-}
-
-// blockIdx.y = input-channel quad; rows[(b*16 + ci)*K*4 + k*4 + ab]
-template <int K, typename T>
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ gout,
-                                                        float* __restrict__ wrows, float* __restrict__ brows, int N, int h,
-                                                        int wd) {
-    const int cq = blockIdx.y;
-    float acc[4][K * 4];
-    float bacc[K];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int j = 0; j < K * 4; ++j) acc[c][j] = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) bacc[k] = 0.f;
-    const long npix = (long)N * h * wd;
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-        const int j = (int)(p % wd);
-        const long r = p / wd;
-        const int i = (int)(r % h), n = (int)(r / h);
-        const f32x4 xv = lf_ldv(x + p * 16 + cq * 4);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float* gp = gout + (((long)n * K + k) * (2 * h) + 2 * i) * (2 * wd) + 2 * j;
-            const float2 g0 = *reinterpret_cast<const float2*>(gp);
-            const float2 g1 = *reinterpret_cast<const float2*>(gp + 2 * wd);
-            const float gv[4] = {g0.x, g0.y, g1.x, g1.y};
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int ab = 0; ab < 4; ++ab) acc[c][k * 4 + ab] = fmaf(xv[c], gv[ab], acc[c][k * 4 + ab]);
-            bacc[k] += (g0.x + g0.y) + (g1.x + g1.y);
-        }
-    }
-    __shared__ float red[4][4 * K * 4 + K];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int j = 0; j < K * 4; ++j) {
-            const float s = lf_wave_sum(acc[c][j]);
-            if (lane == 0) red[wave][c * K * 4 + j] = s;
-        }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const float s = lf_wave_sum(bacc[k]);
-        if (lane == 0) red[wave][4 * K * 4 + k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4 * K * 4) {
-        const int c = threadIdx.x / (K * 4), j = threadIdx.x % (K * 4);
-        wrows[((long)blockIdx.x * 16 + cq * 4 + c) * (K * 4) + j] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    }
-    if (cq == 0 && threadIdx.x < K) {
-        const int j = 4 * K * 4 + threadIdx.x;
-        brows[(long)blockIdx.x * K + threadIdx.x] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
     }
 }
 
@@ -728,46 +549,6 @@ int lf_pool_bwd(const float* x, const float* gcat, int N, int H, int W, int Cin,
     return 0;
 }
 
-int lf_stem_rows(int N, int H, int W) { return lf_cdiv((long)N * (H / 2) * (W / 2), 256); }
-
-int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, const float* b, float* cat, float* rows,
-                int s16, hipStream_t st) {
-    LF_REQUIRE(Cin >= 1 && Cin <= STEM_MAXCIN, "stem: in_channels %d not in 1..%d", Cin, STEM_MAXCIN);
-    LF_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: odd image size");
-    const dim3 grid(lf_stem_rows(N, H, W));
-    switch (Cin) {
-        case 1: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_fwd_kernel<1, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows),
-                                   hipLaunchKernelGGL((stem_fwd_kernel<1, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows)); break;
-        case 2: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_fwd_kernel<2, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows),
-                                   hipLaunchKernelGGL((stem_fwd_kernel<2, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows)); break;
-        case 3: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_fwd_kernel<3, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows),
-                                   hipLaunchKernelGGL((stem_fwd_kernel<3, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows)); break;
-        default: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_fwd_kernel<4, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows),
-                                   hipLaunchKernelGGL((stem_fwd_kernel<4, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows)); break;
-    }
-    LF_CHECK_LAUNCH("stem_fwd");
-    return 0;
-}
-
-int lf_stem_wgrad_rows(int N, int H, int W) { return grid_for((long)N * (H / 2) * (W / 2), 256); }
-
-int lf_stem_wgrad(const float* img, const float* gcat, int N, int Cin, int H, int W, float* wrows, float* brows,
-                  int s16, hipStream_t st) {
-    const dim3 grid(lf_stem_wgrad_rows(N, H, W), (16 - Cin + 3) / 4);
-    switch (Cin) {
-        case 1: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_wgrad_kernel<1, lf_bf16>), grid, dim3(256), 0, st, img, as<lf_bf16>(gcat), N, H, W, wrows, brows),
-                                   hipLaunchKernelGGL((stem_wgrad_kernel<1, float>), grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows)); break;
-        case 2: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_wgrad_kernel<2, lf_bf16>), grid, dim3(256), 0, st, img, as<lf_bf16>(gcat), N, H, W, wrows, brows),
-                                   hipLaunchKernelGGL((stem_wgrad_kernel<2, float>), grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows)); break;
-        case 3: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_wgrad_kernel<3, lf_bf16>), grid, dim3(256), 0, st, img, as<lf_bf16>(gcat), N, H, W, wrows, brows),
-                                   hipLaunchKernelGGL((stem_wgrad_kernel<3, float>), grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows)); break;
-        default: LF_BY_STORAGE(s16, hipLaunchKernelGGL((stem_wgrad_kernel<4, lf_bf16>), grid, dim3(256), 0, st, img, as<lf_bf16>(gcat), N, H, W, wrows, brows),
-                                   hipLaunchKernelGGL((stem_wgrad_kernel<4, float>), grid, dim3(256), 0, st, img, gcat, N, H, W, wrows, brows)); break;
-    }
-    LF_CHECK_LAUNCH("stem_wgrad");
-    return 0;
-}
-
 int lf_head_fwd(const float* x, const float* w, const float* b, float* out, int N, int h, int w_, int K, int s16,
                 hipStream_t st) {
     LF_REQUIRE(K >= 1 && K <= HEAD_MAXK, "head: out_channels %d not in 1..%d", K, HEAD_MAXK);
@@ -786,26 +567,6 @@ int lf_head_bwd_data(const float* gout, const float* w, float* gx, int N, int h,
         hipLaunchKernelGGL(head_bwd_data_kernel<lf_bf16>, grid, dim3(256), 0, st, gout, w, as<lf_bf16>(gx), N, h, w_, K),
         hipLaunchKernelGGL(head_bwd_data_kernel<float>, grid, dim3(256), 0, st, gout, w, gx, N, h, w_, K));
     LF_CHECK_LAUNCH("head_bwd_data");
-    return 0;
-}
-
-int lf_head_wgrad_rows(int N, int h, int w_) { return grid_for((long)N * h * w_, 512); }
-
-int lf_head_wgrad(const float* x, const float* gout, float* wrows, float* brows, int N, int h, int w_, int K,
-                  int s16, hipStream_t st) {
-    dim3 grid(lf_head_wgrad_rows(N, h, w_), 4);
-#define LF_HW(KK) LF_BY_STORAGE(s16, hipLaunchKernelGGL((head_wgrad_kernel<KK, lf_bf16>), grid, dim3(256), 0, st, as<lf_bf16>(x), gout, wrows, brows, N, h, w_), \
-                                hipLaunchKernelGGL((head_wgrad_kernel<KK, float>), grid, dim3(256), 0, st, x, gout, wrows, brows, N, h, w_))
-    switch (K) {
-        case 1: LF_HW(1); break;
-        case 2: LF_HW(2); break;
-        case 3: LF_HW(3); break;
-        case 4: LF_HW(4); break;
-        case 5: LF_HW(5); break;
-        default: return lf_fail("head_wgrad: out_channels %d not in 1..5", K);
-    }
-#undef LF_HW
-    LF_CHECK_LAUNCH("head_wgrad");
     return 0;
 }
 

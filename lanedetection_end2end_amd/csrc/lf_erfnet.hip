@@ -295,6 +295,10 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     P->wpart_floats = lf_maxl(P->wpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 16 * 5 * 4);
     P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_stem_wgrad_rows(N, H, W) * 16);
     P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_head_wgrad_rows(N, H / 2, W / 2) * 8);
+    for (int s16 = 0; s16 < 2; ++s16) {       // ... and their own regions beside the convolutions', so that their row sums join the batched reduction
+        P->wpart_all_floats[s16] += ((long)lf_stem_wgrad_rows(N, H, W) * 16 * 36 + 63) / 64 * 64 + ((long)lf_head_wgrad_rows(N, H / 2, W / 2) * 16 * 5 * 4 + 63) / 64 * 64;
+        P->bpart_all_floats[s16] += ((long)lf_stem_wgrad_rows(N, H, W) * 16 + 63) / 64 * 64 + ((long)lf_head_wgrad_rows(N, H / 2, W / 2) * 8 + 63) / 64 * 64;
+    }
 
     P->off_globals = ws.cur;
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
@@ -332,6 +336,9 @@ int lf_erfnet_set_precision(const lf_erfnet_plan* P, int mode) {
     P->precision = mode;
     return 0;
 }
+// floats of the layers' own regions: every activation tensor a backward needs (+ a few per-channel vectors) -- what bench.py's
+// HBM roofline counts, independent of scratch regions (packed weights, statistics rows, partial rows, gradient ping-pong)
+long lf_erfnet_activation_floats(const lf_erfnet_plan* P) { return P->off_globals; }
 int lf_erfnet_num_params(const lf_erfnet_plan* P) { return P->n_params; }
 int lf_erfnet_num_bn(const lf_erfnet_plan* P) { return P->n_bn; }
 // Dropout2d keep-masks: one (N, C) fp32 block per non_bottleneck_1d with p > 0, in module order;
@@ -558,6 +565,35 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     return 0;
 }
 
+// Partial rows of the stem / head weight gradients: rows_w [rows][nw] -> gw, rows_b [rows][nb] -> gb (plain column sums).  Batched
+// mode: the rows live in their own regions and the sums join the reduction launch at the end of the pass (they were four 12 us
+// launches of a handful of workgroups each); compact / exhausted workspace: summed on the spot from the shared region.
+struct RowSums { float* wrows; float* brows; bool batched; };
+RowSums row_sum_regions(const Ctx& c, long wneed, long bneed) {
+    const lf_erfnet_plan* P = c.P;
+    wneed = (wneed + 63) / 64 * 64; bneed = (bneed + 63) / 64 * 64;
+    const bool batched = !c.no_batch && c.wpart_used + wneed <= P->wpart_all_floats[c.s16] && c.bpart_used + bneed <= P->bpart_all_floats[c.s16];
+    RowSums r;
+    r.batched = batched;
+    r.wrows = batched ? c.at(P->off_wpart_all + c.wpart_used) : c.at(P->off_wpart);
+    r.brows = batched ? c.at(P->off_wpart_all + P->wpart_all_floats[c.s16] + c.bpart_used) : c.at(P->off_bpart);
+    if (batched) { c.wpart_used += wneed; c.bpart_used += bneed; }
+    return r;
+}
+int row_sums_finish(const Ctx& c, const RowSums& r, int rows, int nw, float* gw, int nb, float* gb) {
+    if (!r.batched) {
+        LF_TRY(lf_rows_reduce_launch(r.wrows, rows, nw, gw, 0, c.st));
+        if (gb) LF_TRY(lf_rows_reduce_launch(r.brows, rows, nb, gb, 0, c.st));
+        return 0;
+    }
+    LfReduceJob j;
+    memset(&j, 0, sizeof(j));
+    j.partial = r.wrows; j.grad = gw; j.sk = 0; j.sn = 1; j.splits = rows; j.ntaps = 1; j.Cs = 1; j.Cd = nw;      // grad[n] = sum_r rows[r][n]
+    c.reduce_jobs.push_back(j);
+    if (gb) { j.partial = r.brows; j.grad = gb; j.Cd = nb; c.reduce_jobs.push_back(j); }
+    return 0;
+}
+
 int bn_bwd_finalize(const Ctx& c, const BNRef& b, const LfStatPart* parts, int nparts, double count) {
     // parameter gradients go straight to bn.weight.grad / bn.bias.grad; c1/c2 stay in the workspace
     if (!c.grads[b.p_g] || !c.grads[b.p_b]) return lf_fail("erfnet backward: BatchNorm weight/bias must both require grad");
@@ -691,10 +727,9 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             // stem: weight gradient only (the image needs no gradient)
             const int Cc = 16 - L.Cin, rows = lf_stem_wgrad_rows(N, L.Hin, L.Win);
             if (c.grads[L.cv[0].p_w]) {
-                LF_TRY(lf_stem_wgrad(img, X, N, L.Cin, L.Hin, L.Win, c.at(P->off_wpart), c.at(P->off_bpart), c.s16, c.st));
-                LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, Cc * L.Cin * 9, c.grads[L.cv[0].p_w], 0, c.st));
-                if (c.grads[L.cv[0].p_b])
-                    LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, Cc, c.grads[L.cv[0].p_b], 0, c.st));
+                const RowSums rs = row_sum_regions(c, (long)rows * Cc * L.Cin * 9, (long)rows * Cc);
+                LF_TRY(lf_stem_wgrad(img, X, N, L.Cin, L.Hin, L.Win, rs.wrows, rs.brows, c.s16, c.st));
+                LF_TRY(row_sums_finish(c, rs, rows, Cc * L.Cin * 9, c.grads[L.cv[0].p_w], Cc, c.grads[L.cv[0].p_b]));
             }
             out = F;
         } else {
@@ -787,9 +822,9 @@ int lf_erfnet_backward(const lf_erfnet_plan* P, const float* img, const float* g
     const int pw = P->p_head_w[head], pb = P->p_head_b[head];
     if (grads_host[pw]) {
         const int rows = lf_head_wgrad_rows(P->N, h, w);
-        LF_TRY(lf_head_wgrad(c.at(P->head_in), grad_logits, c.at(P->off_wpart), c.at(P->off_bpart), P->N, h, w, K, c.s16, c.st));
-        LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, 16 * K * 4, grads_host[pw], 0, c.st));
-        if (grads_host[pb]) LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, K, grads_host[pb], 0, c.st));
+        const RowSums rs = row_sum_regions(c, (long)rows * 16 * K * 4, (long)rows * K);
+        LF_TRY(lf_head_wgrad(c.at(P->head_in), grad_logits, rs.wrows, rs.brows, P->N, h, w, K, c.s16, c.st));
+        LF_TRY(row_sums_finish(c, rs, rows, 16 * K * 4, grads_host[pw], K, grads_host[pb]));
     }
     LF_TRY(lf_head_bwd_data(grad_logits, params_host[pw], gA, P->N, h, w, K, c.s16, c.st));
     LF_TRY(backward_layers(c, img, gA, gB, gC, (int)P->layers.size()));
@@ -963,9 +998,9 @@ int lf_erfnet_backward_range(const lf_erfnet_plan* P, int first, int last, int h
         const int pw = P->p_head_w[head], pb = P->p_head_b[head];
         if (grads_host[pw]) {
             const int rows = lf_head_wgrad_rows(P->N, h, w);
-            LF_TRY(lf_head_wgrad(c.at(P->head_in), gy, c.at(P->off_wpart), c.at(P->off_bpart), P->N, h, w, K, 0, c.st));
-            LF_TRY(lf_rows_reduce_launch(c.at(P->off_wpart), rows, 16 * K * 4, grads_host[pw], 0, c.st));
-            if (grads_host[pb]) LF_TRY(lf_rows_reduce_launch(c.at(P->off_bpart), rows, K, grads_host[pb], 0, c.st));
+            const RowSums rs = row_sum_regions(c, (long)rows * 16 * K * 4, (long)rows * K);
+            LF_TRY(lf_head_wgrad(c.at(P->head_in), gy, rs.wrows, rs.brows, P->N, h, w, K, 0, c.st));
+            LF_TRY(row_sums_finish(c, rs, rows, 16 * K * 4, grads_host[pw], K, grads_host[pb]));
         }
         LF_TRY(lf_head_bwd_data(gy, params_host[pw], gA, P->N, h, w, K, 0, c.st));
     } else {

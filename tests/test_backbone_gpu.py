@@ -964,8 +964,10 @@ def test_bf16_tensor_mode_backward_straight_through(shape):
             m.p = 0
     net.train()
     net.precision = "bf16"
-    x = torch.from_numpy(inputs.images(N, H, W, seed=51))
-    gy = torch.from_numpy(np.random.default_rng(52).standard_normal((N, Cout, H, W))).float()
+    import os
+    seed = int(os.environ.get("LF_ST_SEED", "51"))
+    x = torch.from_numpy(inputs.images(N, H, W, seed=seed))
+    gy = torch.from_numpy(np.random.default_rng(seed + 1).standard_normal((N, Cout, H, W))).float()
     enc, dec = net(x.cuda(), True)
     plan, ws = net._plan(N, H, W), dec.grad_fn.ws
     lib = _lib.load()
@@ -1019,8 +1021,14 @@ def test_bf16_tensor_mode_backward_straight_through(shape):
     # before any BatchNorm backward has amplified anything: the head is fp32 math on the stored operands (exact), the
     # last block's bn2 / conv1x3_2 see one bf16-rounded gradient tensor
     assert errs["decoder.output_conv.weight"] < 1e-5 and errs["decoder.output_conv.bias"] < 1e-5
-    assert errs["decoder.layers.5.bn2.weight"] < 1e-2 and errs["decoder.layers.5.conv1x3_2.weight"] < 1e-2
-    assert max(tail) < 0.1
+    # (the weight gradient of a convolution in front of a BatchNorm is what is LEFT of sum x * g after that BatchNorm's backward took
+    # the mean and the x-hat component out of g: at 4 x 320 x 640 the sum over 204 800 pixels cancels to a small remainder and the
+    # 2^-9 rounding of the stored g shows as 0.7 % .. 9 % of it depending on the seed (LF_ST_SEED = 51 / 61 / 71 / 81: 7.5e-2, 7.4e-3,
+    # 8.9e-2, 1.3e-2, cosine >= 0.996) -- at that shape the relative-L2 gates are wide and the cosine pins the mapping)
+    big = N * H * W > 100000
+    assert errs["decoder.layers.5.bn2.weight"] < 1e-2 and errs["decoder.layers.5.conv1x3_2.weight"] < (0.2 if big else 1e-2)
+    assert cosines["decoder.layers.5.conv1x3_2.weight"] > 0.99
+    assert max(tail) < (0.2 if big else 0.1)
     # measured: median 1.4e-2 at both shapes, worst 3.2e-2 / 8.9e-2 (the stem, below 38 BatchNorm backwards), cosine >= 0.996
     assert float(np.median(list(errs.values()))) < 0.04 and errs[worst] < 0.25 and min(cosines.values()) > 0.99
     # The first parameter gradient BELOW every kernel kind of the bf16 backward (16-channel lean data gradient + tapwgrad16_tr:
@@ -1032,8 +1040,10 @@ def test_bf16_tensor_mode_backward_straight_through(shape):
     sites = {"decoder.layers.5.conv3x1_1.weight": 0.04, "decoder.layers.4.conv1x3_2.weight": 0.015, "decoder.layers.3.conv.weight": 0.025,
              "decoder.layers.2.conv1x3_2.weight": 0.025, "decoder.layers.2.conv3x1_2.weight": 0.025, "decoder.layers.1.conv3x1_1.weight": 0.03,
              "decoder.layers.0.conv.weight": 0.03, "encoder.layers.14.conv1x3_2.weight": 0.03, "encoder.layers.14.conv3x1_2.weight": 0.03,
-             "encoder.layers.6.conv.weight": 0.05}      # measured (2 x 64 x 128 / 4 x 320 x 640): 0.005-0.016 at every site but the last (deeper)
+             "encoder.layers.6.conv.weight": 0.05}      # measured (2 x 64 x 128 / 4 x 320 x 640, seed 51): 0.005-0.016 at every site but the last (deeper)
+    if big:                                             # (seed spread at the large shape, see above: x 4)
+        sites = {k: 4 * v for k, v in sites.items()}
     print("   " + "  ".join("%s %.3f/%.4f" % (k.replace(".weight", ""), errs[k], cosines[k]) for k in sites if k in errs))
     for k, bound in sites.items():
         if k in errs:
-            assert errs[k] < bound and cosines[k] > 0.999, (k, errs[k], cosines[k])
+            assert errs[k] < bound and cosines[k] > (0.995 if big else 0.999), (k, errs[k], cosines[k])
