@@ -47,10 +47,13 @@ __device__ __forceinline__ void block_reduce_quads(f32x4 (&a1)[NQ], f32x4 (&a2)[
 
 struct StatParts { LfStatPart p[2]; int n; };
 
-// Column sums of the partial rows for the 4 channels c0..c0+3 by one 256-thread block: thread t takes rows t, t + 256, ... as
+// Column sums of the partial rows for the 4 channels c0..c0+3 by one FIN_THREADS-thread block: thread t takes rows t, t + FIN_THREADS, ... as
 // 16-byte loads (independent: all in flight at once), fp64 accumulation, wave shuffle + 4-slot LDS combine, fixed order.
 // (The first version -- 16 channels x 64 row groups per 1024-thread block, scalar loads, a 64-step serial combine -- ran on 4-8
 // workgroups: 7 us for a kernel that is pure latency.)
+// (1024 threads since round 5: the launches are a handful of workgroups -- C / 4 -- whose time is the number of memory round trips a
+// thread makes; config 3's 16-channel layers have 12 800 rows: 27 us per BatchNorm with 256 threads)
+constexpr int FIN_THREADS = 1024;
 __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, double (&s1)[4], double (&s2)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
@@ -61,23 +64,26 @@ __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, doub
         // four rows = eight 16-byte loads requested before the first add: the kernel is ONE memory round trip per loop trip (rows
         // written by the previous launch: L2 / Infinity Cache, ~1 us), and at config 3's 3200 rows the two-load form made 13 of them
         // -- 12 us per BatchNorm, 0.9 ms per step.  Rows beyond the count re-read row 0 and are skipped by a scalar-free select.
-        for (int r0 = threadIdx.x; r0 < q.nrows; r0 += 4 * 256) {
+        for (int r0 = threadIdx.x; r0 < q.nrows; r0 += 4 * FIN_THREADS) {
             f32x4 a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * 256 < q.nrows ? r0 + u * 256 : 0;
+                const int r = r0 + u * FIN_THREADS < q.nrows ? r0 + u * FIN_THREADS : 0;
                 a[u] = ld4(q.rows + ((long)r * 2 + 0) * q.C + cc);
                 b[u] = ld4(q.rows + ((long)r * 2 + 1) * q.C + cc);
             }
+            asm volatile("" ::: "memory");      // all eight requests are out before the first add (with a `break` in the sum loop hipcc
+                                                // fused the two loops back into load, load, wait, add: one round trip per row)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (r0 + u * 256 >= q.nrows) break;
-                s1[0] += (double)a[u].x; s1[1] += (double)a[u].y; s1[2] += (double)a[u].z; s1[3] += (double)a[u].w;
-                s2[0] += (double)b[u].x; s2[1] += (double)b[u].y; s2[2] += (double)b[u].z; s2[3] += (double)b[u].w;
+                const bool v = r0 + u * FIN_THREADS < q.nrows;  // a row beyond the count adds +0.0
+                s1[0] += v ? (double)a[u].x : 0.0; s1[1] += v ? (double)a[u].y : 0.0; s1[2] += v ? (double)a[u].z : 0.0; s1[3] += v ? (double)a[u].w : 0.0;
+                s2[0] += v ? (double)b[u].x : 0.0; s2[1] += v ? (double)b[u].y : 0.0; s2[2] += v ? (double)b[u].z : 0.0; s2[3] += v ? (double)b[u].w : 0.0;
             }
         }
     }
-    __shared__ double sm[4][8];
+    constexpr int NWV = FIN_THREADS / 64;
+    __shared__ double sm[NWV][8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -90,10 +96,15 @@ __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, doub
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { s1[i] = (sm[0][i] + sm[1][i]) + (sm[2][i] + sm[3][i]); s2[i] = (sm[0][4 + i] + sm[1][4 + i]) + (sm[2][4 + i] + sm[3][4 + i]); }
+    for (int i = 0; i < 4; ++i) {          // fixed order: deterministic
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) { a += sm[k][i]; b += sm[k][4 + i]; }
+        s1[i] = a; s2[i] = b;
+    }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ rmean, float* __restrict__ rvar,
                                                             float momentum, float eps, int training,
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // terms of the data gradient vanish (c1 = c2 = 0); the parameter gradients are the same sums.
 // (mean_scale = 1 / count in training mode, 0 in eval mode -- decided on the host: a run-time `training ? :` in here made hipcc
 // unroll the final sum into 128 registers + 564 bytes of scratch, 19 us per launch instead of 6)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(StatParts sp, int C, double mean_scale, const float* __restrict__ asc,
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(StatParts sp, int C, double mean_scale, const float* __restrict__ asc,
                                                             const float* __restrict__ ash, float* __restrict__ c1,
                                                             float* __restrict__ c2, float* __restrict__ ggamma,
                                                             float* __restrict__ gbeta) {
@@ -452,7 +463,7 @@ int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count,
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
     for (int i = 0; i < nparts; ++i) LF_REQUIRE(parts[i].C % 4 == 0 && parts[i].ch_off % 4 == 0, "bn_finalize: channel ranges must be multiples of 4");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(lf_cdiv(C, 4)), dim3(256), 0, st, sp, C, count, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(lf_cdiv(C, 4)), dim3(FIN_THREADS), 0, st, sp, C, count, gamma, beta,
                        running_mean, running_var, momentum, eps, training, scale, shift, asc, ash);
     LF_CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
@@ -496,7 +507,7 @@ int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count,
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
     for (int i = 0; i < nparts; ++i) LF_REQUIRE(parts[i].C % 4 == 0 && parts[i].ch_off % 4 == 0, "bn_bwd_finalize: channel ranges must be multiples of 4");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 4)), dim3(256), 0, st, sp, C, training ? 1.0 / count : 0.0, asc, ash,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 4)), dim3(FIN_THREADS), 0, st, sp, C, training ? 1.0 / count : 0.0, asc, ash,
                        c1, c2, ggamma, gbeta);
     LF_CHECK_LAUNCH("bn_bwd_finalize");
     return 0;
