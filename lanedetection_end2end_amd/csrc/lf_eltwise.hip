@@ -51,9 +51,10 @@ struct StatParts { LfStatPart p[2]; int n; };
 // 16-byte loads (independent: all in flight at once), fp64 accumulation, wave shuffle + 4-slot LDS combine, fixed order.
 // (The first version -- 16 channels x 64 row groups per 1024-thread block, scalar loads, a 64-step serial combine -- ran on 4-8
 // workgroups: 7 us for a kernel that is pure latency.)
-// (1024 threads since round 5: the launches are a handful of workgroups -- C / 4 -- whose time is the number of memory round trips a
-// thread makes; config 3's 16-channel layers have 12 800 rows: 27 us per BatchNorm with 256 threads)
-constexpr int FIN_THREADS = 1024;
+// (256 threads.  1024 were measured in round 5 -- four times the rows in flight per workgroup -- and are SLOWER: 9.7 vs 7.1 us at
+// batch 32, 14.1 vs 12.0 at config 3: the kernel's time is its launch, one or two memory round trips and the fp64 shuffle /
+// combine / divide tail that every wave runs, not the row loop)
+constexpr int FIN_THREADS = 256;
 __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, double (&s1)[4], double (&s2)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s1[i] = 0.0; s2[i] = 0.0; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round's profile evidence from HEAD on a 1-GPU MI355X box (run through gpurun from the repo root):
 #
-#     bash tools/stamp_head.sh && gpurun --timeout 900 -- 'bash profiles/collect.sh r4'        (every step runs under its own `timeout`)
+#     bash tools/stamp_head.sh && gpurun --timeout 1500 -- 'bash profiles/collect.sh r5'       (every step runs under its own `timeout`)
 #
 # 1. rocprofv3 --kernel-trace --stats of the exact bench command       -> profiles/<tag>_kernel_stats.txt
 # 2. two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain other than --kernel-trace) over one
@@ -13,7 +13,7 @@
 # 4. a matrix-pipe pass (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) over the bench -> profiles/<tag>_pmc_bench.txt
 # Everything is written under gpurun_out/ first (scratch) and the summaries are copied to profiles/ by this script; commit them.
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
@@ -28,7 +28,7 @@ case "$STAMP" in
   *) echo "collect.sh: refusing to write profiles: .git_head says '$STAMP', this tree's digest is $DIGEST (run tools/stamp_head.sh on a clean tree first)"; exit 1 ;;
 esac
 
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 16 --warmup 4 --min-seconds 1 --no-cpu-baseline --no-vendor-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 16 --warmup 4 --min-seconds 1 --no-extras > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 DB=$(find $OUT/trace -name '*_results.db' | head -1)
 ( echo "# commit $COMMIT  sources digest $DIGEST (sha256 of csrc/*.hip csrc/*.h bench.py, first 16 hex)"; python profiles/summarize_rocpd.py "$DB" ) > profiles/${TAG}_kernel_stats.txt
 
@@ -36,6 +36,18 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 120 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1
 done
 python profiles/summarize_traffic.py $OUT $TAG "$COMMIT" "$DIGEST"
+# 3b. (round 5) HBM-side bytes of the WHOLE step, per kernel family: FETCH_SIZE and WRITE_SIZE in separate passes over the bench
+#     command itself (--no-extras: every launch of the run belongs to the measured step), the fp32 headline and bf16 config 3
+#     -> profiles/traffic_step.json (bench.py: roofline.traffic_step, roofline.traffic = the family's launch-weighted mean)
+for W in "bev fp32 32" "bp bf16 64"; do
+  set -- $W
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace -d $OUT/step_$1_$C -o p -- python bench.py --workload $1 --precision $2 --steps 2 --warmup 1 --min-seconds 0 --no-extras > $OUT/step_$1_$C.json 2> $OUT/step_$1_$C.err
+  done
+  F=$(find $OUT/step_$1_FETCH_SIZE -name '*_results.db' | head -1); Wd=$(find $OUT/step_$1_WRITE_SIZE -name '*_results.db' | head -1)
+  [ -n "$F" ] && [ -n "$Wd" ] && python profiles/summarize_traffic_step.py "$F" "$Wd" "$1_$2_b$3" "$COMMIT" "$DIGEST" | tee -a $OUT/traffic_step.log
+done
+set -- $TAG
 
 timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-vendor-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
 DB=$(find $OUT/pmc_mfma -name '*_results.db' | head -1)
@@ -53,12 +65,16 @@ DB=$(find $OUT/trace_bp16 -name '*_results.db' | head -1)
 [ -n "$DB" ] && ( echo "# commit $COMMIT  sources digest $DIGEST"; python profiles/summarize_rocpd.py "$DB" ) > profiles/${TAG}_bp_bf16_kernel_stats.txt
 [ -x tools/l2_stream ] && ( echo "# commit $COMMIT  (tools/l2_stream.hip; 204800 pixels = 52 MB, then 819200 = 210 MB)"; timeout 60 ./tools/l2_stream 204800; timeout 60 ./tools/l2_stream 819200 ) > profiles/${TAG}_l2_stream.txt 2>&1
 ( echo "# commit $COMMIT  sources digest $DIGEST"; timeout 200 python tools/bf16_ab.py --iters 100 ) > profiles/${TAG}_bf16_lds_vs_streaming.txt 2>&1
+# 4d. (round 5) the read-once bf16 weight gradient against the job form on the same launches; the ticket-finalise micro-benchmark
+( echo "# commit $COMMIT  sources digest $DIGEST (tools/wgrad_ro_ab.py: lf_conv1d_bwd_weight incl. the split-K reduction, HIP events)"; timeout 200 python tools/wgrad_ro_ab.py --iters 100 ) > profiles/${TAG}_wgrad_ro_vs_job_form.txt 2>&1
+[ -x tools/ticket_tail ] && ( echo "# commit $COMMIT  (tools/ticket_tail.hip: BatchNorm finalise as a dependent launch vs inside the producing launch by ticket)"; timeout 60 ./tools/ticket_tail ) > profiles/${TAG}_ticket_tail.txt 2>&1
 # 5. the vendor library on the kernel-level problems (torch conv2d through MIOpen) beside the HIP kernels -> profiles/<tag>_kbench_vs_miopen.txt
 timeout 240 python tools/kbench.py --iters 100 --miopen > profiles/${TAG}_kbench_vs_miopen.txt 2>&1
 # only gpurun_out/ travels back (<= 64 MiB): keep the summaries and logs, drop the databases
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/${TAG}_pmc_bf16_lds.txt profiles/${TAG}_kbench_vs_miopen.txt \
-   profiles/${TAG}_bp_bf16_kernel_stats.txt profiles/${TAG}_l2_stream.txt profiles/${TAG}_bf16_lds_vs_streaming.txt profiles/traffic.json gpurun_out/profiles_$TAG/ 2>/dev/null
+   profiles/${TAG}_bp_bf16_kernel_stats.txt profiles/${TAG}_l2_stream.txt profiles/${TAG}_bf16_lds_vs_streaming.txt profiles/traffic.json profiles/traffic_step.json \
+   profiles/${TAG}_wgrad_ro_vs_job_form.txt profiles/${TAG}_ticket_tail.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 cp $OUT/*.log $OUT/*.err $OUT/*.json gpurun_out/profiles_$TAG/ 2>/dev/null
 rm -rf $OUT
 head -12 profiles/${TAG}_kernel_stats.txt; cat profiles/traffic.json; tail -3 gpurun_out/profiles_$TAG/*.err gpurun_out/profiles_$TAG/pmc_*.log 2>/dev/null | tail -30
