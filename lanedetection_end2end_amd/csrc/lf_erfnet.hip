@@ -523,9 +523,13 @@ int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
     return 0;
 }
 
+// The four sub-pixel phases of a transposed convolution have ONE bias gradient: in batched mode their bias partial rows are laid
+// end to end (the phases' own bias regions are adjacent) and summed by the last phase's reduction job
+struct BiasChain { float* base = nullptr; int rows = 0; int phase = 0; };
+
 // weight + bias gradient of one forward-geometry GEMM
 int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x, const float* g, const float* pro_sc,
-              const float* pro_sh, int bias_accumulate, bool batch_off = false) {
+              const float* pro_sh, int bias_accumulate, bool batch_off = false, BiasChain* chain = nullptr) {
     const lf_erfnet_plan* P = c.P;
     c.wgrad_launched = false;
     if (!c.grads[cv.p_w]) return 0;
@@ -534,13 +538,19 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh; a.s16 = c.s16;
     a.split = P->precision == 3 ? 9 : (P->precision == 4 ? 6 : 0);
     // Batched mode (default): this weight gradient keeps its partial rows in its own region and its reduction joins the
-    // one launch at the end of the pass.  Immediate mode: the transposed-conv phases (their bias rows accumulate in order).
+    // one launch at the end of the pass.  Immediate mode (compact workspaces): summed on the spot from the shared region; the
+    // transposed-conv phases' bias rows then accumulate in order.
     const long wneed = (wneed_of(op.geom, c.s16) + 63) / 64 * 64, bneed = (bneed_of(op.geom, c.s16) + 63) / 64 * 64;
     const bool batched = !bias_accumulate && !batch_off && !c.no_batch &&
                          c.wpart_used + wneed <= P->wpart_all_floats[c.s16] && c.bpart_used + bneed <= P->bpart_all_floats[c.s16];
     const long off_bpart_all = P->off_wpart_all + P->wpart_all_floats[c.s16];
     a.partial = batched ? c.at(P->off_wpart_all + c.wpart_used) : c.at(P->off_wpart);
     a.bias_partial = c.grads[cv.p_b] ? (batched ? c.at(off_bpart_all + c.bpart_used) : c.at(P->off_bpart)) : nullptr;
+    if (chain) {
+        if (!batched) return lf_fail("erfnet backward: a chained weight gradient does not fit its partial-row regions");
+        if (chain->phase == 0) chain->base = c.at(off_bpart_all + c.bpart_used);
+        if (a.bias_partial) a.bias_partial = chain->base + (long)chain->rows * op.geom.Cd;
+    }
     {
         ProfScope ps(c, 1, op.geom, 0, ws);
         LF_TRY(lf_tapwgrad_launch(op.geom, a, pro_sc ? LF_PRO_BNRELU : LF_PRO_NONE, ws));
@@ -555,6 +565,13 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
         j.partial = a.partial; j.grad = c.grads[cv.p_w]; j.bias_rows = a.bias_partial; j.bias_grad = c.grads[cv.p_b];
         j.sk = e.sk; j.sn = e.sn; j.splits = nsplit; j.ntaps = op.geom.ntaps; j.Cs = op.geom.Cs; j.Cd = op.geom.Cd;
         j.n_bias_rows = nsplit;
+        if (chain) {
+            chain->rows += nsplit;
+            const bool last = ++chain->phase == 4;
+            j.bias_rows = (last && a.bias_partial) ? chain->base : nullptr;
+            j.n_bias_rows = chain->rows;
+            if (!last) j.bias_grad = nullptr;
+        }
         for (int t = 0; t < op.geom.ntaps; ++t) j.tapidx[t] = e.tapidx[t];
         c.reduce_jobs.push_back(j);
         return 0;
@@ -711,8 +728,19 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             out = F;
             if (can_prep) { prepped = true; prep_rows = c.last_rows; }
         } else if (L.kind == K_UP) {
-            for (int ph = 0; ph < 4; ++ph)
-                LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, ph > 0, true));
+            // (the four phases' reductions join the batched launch when their regions fit: eight 6 us launches per step, each
+            // between two dependent weight-gradient launches, otherwise)
+            long wsum = 0, bsum = 0;
+            for (int ph = 0; ph < 4; ++ph) {
+                wsum += (wneed_of(L.cv[0].fph[ph].geom, c.s16) + 63) / 64 * 64;
+                bsum += (bneed_of(L.cv[0].fph[ph].geom, c.s16) + 63) / 64 * 64;
+            }
+            const bool chained = !c.no_batch && c.wpart_used + wsum <= P->wpart_all_floats[c.s16] && c.bpart_used + bsum <= P->bpart_all_floats[c.s16];
+            BiasChain bc;
+            for (int ph = 0; ph < 4; ++ph) {
+                if (chained) LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, 0, false, &bc));
+                else LF_TRY(run_wgrad(c, L.cv[0].fph[ph], L.cv[0], c.at(L.x), X, nullptr, nullptr, ph > 0, true));
+            }
             LfTapArgs a = lf_no_args();
             int epi = 0;
             if (c.g_enc && L.x == lf_erfnet_encoder_offset(P)) {   // gradient of the --clas heads joins here

@@ -96,6 +96,7 @@ extern "C" {
 
 void lf_debug_set_split_any_size(int v) { lf_tapgemm_set_split_any_size(v); }
 void lf_debug_set_bf16_lds(int v) { lf_tapgemm_set_bf16_lds(v); }
+void lf_debug_set_lean_p(int v) { lf_tapgemm_set_lean_p(v); }
 // precision mode of the kernel-level conv1d calls below (tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32 tensors,
 // 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src then hold bf16 elements; w, bias, gw, gb stay fp32)
 void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = mode; }
@@ -184,6 +185,23 @@ int lf_debug_conv1d_bwd_data_epi3(const float* gy, const float* w, const float* 
     a.src = gy; a.dst = gx; a.mask_src = mask_src; a.add_src = add_src; a.aux = aux; a.stats = stats;
     if (lf_tapgemm_launch(g, a, LF_PRO_NONE, LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT, st)) return -1;
     return lf_tapgemm_stat_rows_for(g, a);
+}
+
+// one tap-GEMM launch with any of the network's epilogue flag sets (LF_EPI_*, lf_conv.h); transposed = 1: data-gradient weights.
+// Tensors a flag does not name may be null.  Returns the number of statistics rows written (0 without a STATS flag), -1 on error.
+int lf_debug_conv1d_epi(const float* src, const float* w, const float* bias, float* dst, int transposed, int epi, const float* mask_src,
+                        const float* add_src, const float* aux, const float* msc, const float* msh, float* stats, int N, int H, int W, int C,
+                        int axis, int dilation, float* scratch, void* stream) {
+    if (!(src && w && dst && scratch)) { lf_fail("lf_debug_conv1d_epi: null pointer"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const LfTapGeom g = conv1d_geom(N, H, W, C, axis, dilation);
+    LfTapArgs a;
+    memset(&a, 0, sizeof(a));
+    if (transposed) pack_conv1d(a, w, scratch, C, 3L * C, 3L, 1, st);
+    else pack_conv1d(a, w, scratch, C, 3L, 3L * C, 0, st);
+    a.src = src; a.dst = dst; a.bias = bias; a.mask_src = mask_src; a.add_src = add_src; a.aux = aux; a.msc = msc; a.msh = msh; a.stats = stats;
+    if (lf_tapgemm_launch(g, a, LF_PRO_NONE, epi, st)) return -1;
+    return (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) ? lf_tapgemm_stat_rows_for(g, a) : 0;
 }
 
 namespace {
