@@ -59,7 +59,6 @@ struct LfTapArgs {
 
 void lf_tapgemm_set_split_any_size(int v);
 void lf_tapgemm_set_bf16_lds(int v);
-void lf_tapgemm_set_lean_p(int v);        // tools / tests: 0 = no persistent 16-channel kernel, 1 = shipped, 2 = its two-register-set variant
 int lf_tapgemm_stat_rows(const LfTapGeom& g);                          // upper bound over the kernels (buffer sizing)
 int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a);  // rows the launch with these arguments writes
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);

@@ -129,9 +129,6 @@ __device__ __forceinline__ float sum16(float v) {
 #define LF_EPI_ONE_TILE false  /* tapgemm_kernel: true for the per-lane-row form of the three-tensor epilogue (one register short) */
 #define LF_EPI_TID threadIdx.x  /* tapgemm_kernel: its per-tile laundered copy */
 #define LF_EPI_ROW1 false      /* tapgemm_kernel: its ROW1 (a wave's 64 pixels in one image row) */
-#define LF_EPI_SYNC __syncthreads()   /* tapgemm_lean_p_kernel: an LDS-only barrier (its next tile's loads stay in flight) */
-#define LF_EPI_BIAS(co) (a.bias ? ldb4(r_bias, (co) * 4u, 0u) : zero4())   /* tapgemm_lean_p_kernel: loaded once per workgroup life */
-#define LF_EPI_STAT_STORE(idx, v) a.stats[idx] = (v)   /* tapgemm_lean_p_kernel: buffer-addressed (no 64-bit address pair held across its tile loop) */
 #define LF_TAPGEMM_EPILOGUE \
     /* Pixel-tile outer, channel-tile inner: the loads of one operand tensor issued back to back cover one pixel's     \
      * contiguous channel run, so every cache line is touched once while it is hot (the channel-tile-outer order        \
@@ -150,13 +147,12 @@ __device__ __forceinline__ float sum16(float v) {
                                  r_msk = make_rsrc(a.mask_src, 0xffffffffu), r_aux = make_rsrc(a.aux, 0xffffffffu), \
                                  r_bias = make_rsrc(a.bias, 0xffffffffu), r_msc = make_rsrc(a.msc, 0xffffffffu), \
                                  r_msh = make_rsrc(a.msh, 0xffffffffu), r_dm = make_rsrc(a.dm, 0xffffffffu); \
-    (void)r_bias; \
     f32x4 s1[NT], s2[NT], bs[NOBIAS ? 1 : NT], hv[HOISTV ? NT : 1][2]; \
 _Pragma("unroll") \
     for (int n = 0; n < NT; ++n) { \
         const int co = cob + n * 16 + kq * 4; \
         s1[n] = zero4(); s2[n] = zero4(); \
-        if constexpr (!NOBIAS) bs[n] = LF_EPI_BIAS(co); \
+        if constexpr (!NOBIAS) bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4(); \
         if (HOISTV) { \
             if (HOISTM && (epi & LF_EPI_MASKBN)) { hv[n][0] = ldb4(r_msc, co * 4u, 0u); hv[n][1] = ldb4(r_msh, co * 4u, 0u); } \
         } \
@@ -218,13 +214,13 @@ _Pragma("unroll") \
                 d[0] = r1.x; d[1] = r1.y; d[2] = r1.z; d[3] = r1.w; d[4] = r2.x; d[5] = r2.y; d[6] = r2.z; d[7] = r2.w; \
             } \
         } \
-        LF_EPI_SYNC; \
+        __syncthreads(); \
         if ((LF_EPI_TID & 255) < NT * 4 * 8) { \
             const int tg = LF_EPI_TID >> 8, tt = LF_EPI_TID & 255; \
             const int j = tt & 7, q = (tt >> 3) & 3, n = tt >> 5; \
             const float v = sred[tg][0][n][q][j] + sred[tg][1][n][q][j] + sred[tg][2][n][q][j] + sred[tg][3][n][q][j]; \
             const int co = cob + n * 16 + q * 4 + (j & 3); \
-            LF_EPI_STAT_STORE((((long)bx * LF_EPI_GROUPS + tg) * 2 + (j >> 2)) * g.Cd + co, v); \
+            a.stats[(((long)bx * LF_EPI_GROUPS + tg) * 2 + (j >> 2)) * g.Cd + co] = v; \
         } \
     } \
 
@@ -1719,141 +1715,6 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
     LF_TAPGEMM_EPILOGUE
 }
 
-// ---------------------------------------------------------------------------------------
-// tapgemm_lean_p_kernel: the plain 16 -> 16 channel 3-tap convolutions (stride 1, rows of whole 64-pixel groups) as PERSISTENT
-// workgroups.  tapgemm_lean_kernel runs them as 4096 short-lived workgroups whose waves all request, multiply and store at the
-// same time: 31-37 us per launch whether the launch moves 134 or 201 MB (and whether or not it comes out of the Infinity
-// Cache), where the bytes take 21-25 us.  Here a workgroup walks 256-pixel tiles inside its XCD's contiguous tile range
-// (interleaved with its neighbours: concurrently processed tiles are adjacent rows, the taps' re-reads stay in that XCD's L2),
-// keeps the 3 x 16 x 16 weights in 12 registers for its whole life, derives a tile's addresses from three scalars (image, row,
-// first column: one per-lane add and select per 16-pixel group) and requests the NEXT tile's operands before this tile's
-// epilogue (DB: before this tile's MFMAs, into a second register set).  Arithmetic, summation order and the statistics rows
-// (one per 256-pixel tile, row = tile index) are tapgemm_lean_kernel's: results are bit-identical (tests/test_lean_gpu.py).
-// ---------------------------------------------------------------------------------------
-#undef LF_EPI_SYNC
-#define LF_EPI_SYNC asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#undef LF_EPI_BIAS
-#define LF_EPI_BIAS(co) bias_pre      /* (a load inside the tile loop would sit behind the next tile's operand loads: vmcnt(0) before the stores) */
-#undef LF_EPI_STAT_STORE
-#define LF_EPI_STAT_STORE(idx, v) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_stats, (int)((unsigned)(idx) * 4u), 0, 0)
-template <int PROC, int EPIC, int MODE>      // MODE 1: one operand register set, 4 workgroups per CU; 2: two sets (DB), 2 per CU; 3: one set, 3 per CU
-__global__ __launch_bounds__(256, MODE == 1 ? 4 : MODE) void tapgemm_lean_p_kernel(const LfTapGeom g, const LfTapArgs a, const int ntiles) {
-    constexpr int NT = 1, cob = 0, epi = EPIC;
-    constexpr bool S16 = false, HOISTV = true, DB = MODE == 2;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int pl = lane & 15, kq = lane >> 4;
-    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
-    const unsigned t_hi = (unsigned)(((unsigned long long)(xcd + 1u) * (unsigned)ntiles) >> 3);
-    unsigned tile = (unsigned)(((unsigned long long)xcd * (unsigned)ntiles) >> 3) + slot;
-    if (tile >= t_hi) return;                                   // (workgroup-uniform)
-    const __amdgpu_buffer_rsrc_t rwl = make_rsrc(a.wp, 0xffffffffu),
-                                 rxl = make_rsrc(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 4, (long)LF_OOB));
-    f32x4 w3[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) w3[t] = ldb4(rwl, (unsigned)(kq * 16 + pl) * 16u, (unsigned)(t * 16 * 64));
-    f32x4 sc = zero4(), sh = zero4();
-    if constexpr (PROC == LF_PRO_BNRELU) { sc = ldg4(a.pro_sc + kq * 4); sh = ldg4(a.pro_sh + kq * 4); }
-    const f32x4 bias_pre = a.bias ? ldb4(make_rsrc(a.bias, 0xffffffffu), (unsigned)kq * 16u, 0u) : zero4();
-    const __amdgpu_buffer_rsrc_t r_stats = make_rsrc(a.stats, 0xffffffffu);
-    (void)r_stats;
-    const unsigned lbase = (unsigned)((pl * g.s_pix + g.s_choff + kq * 4) * 4);      // this lane's 16 bytes inside a 16-pixel group
-    // (image, row, first column) of this wave's 64 pixels of a tile: wave-uniform
-    auto coords = [&](unsigned tl, int& n, int& i, int& j0) {
-        const unsigned p0 = tl * (unsigned)PIX_PER_WG + (unsigned)wave * (MT * 16);
-        const unsigned r = p0 / (unsigned)g.Wl;
-        j0 = (int)(p0 - r * (unsigned)g.Wl);
-        n = (int)(r / (unsigned)g.Hl);
-        i = (int)(r - (unsigned)n * (unsigned)g.Hl);
-    };
-    // all 12 operand loads of a tile; a tap position outside the image is the out-of-range offset (reads 0.0f)
-    auto issue = [&](f32x4 (&x)[3][MT], int n, int i, int j0) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int sy = i + g.tdh[t];
-            const bool rowok = (unsigned)sy < (unsigned)g.Hs;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int sxs = j0 + m * 16 + g.tdw[t];
-                const bool in = rowok && (unsigned)(sxs + pl) < (unsigned)g.Ws;
-                const unsigned S = (unsigned)(((n * g.Hs + sy) * g.Ws + sxs) * g.s_pix) * 4u;     // (wraps for a tap outside: not used then)
-                x[t][m] = ldb4(rxl, in ? lbase + S : LF_OOB, 0u);
-            }
-        }
-    };
-    int n, i, j0;
-    coords(tile, n, i, j0);
-    f32x4 xa[3][MT], xb[DB ? 3 : 1][MT];
-    issue(xa, n, i, j0);
-#define LF_LEANP_STEP(XC, XN)                                                                                              \
-    {                                                                                                                      \
-        const bool more = tile + per < t_hi;                                                                               \
-        int n2 = n, i2 = i, j2 = j0;                                                                                       \
-        if (more) coords(tile + per, n2, i2, j2);                                                                          \
-        if (DB && more) issue(XN, n2, i2, j2);                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        f32x4 acc[NT][MT];                                                                                                 \
-        _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                                    \
-            if constexpr (PROC == LF_PRO_BNRELU) {      /* relu(bn(x)); padding is zero AFTER the transform */              \
-                const int sy = i + g.tdh[t];                                                                               \
-                const bool rowok = (unsigned)sy < (unsigned)g.Hs;                                                          \
-                _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                           \
-                    const bool in = rowok && (unsigned)(j0 + m * 16 + g.tdw[t] + pl) < (unsigned)g.Ws;                     \
-                    f32x4 v = max0(XC[t][m] * sc + sh);                                                                    \
-                    v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;                \
-                    XC[t][m] = v;                                                                                          \
-                }                                                                                                          \
-            }                                                                                                              \
-            /* one fma chain per TAP (16 products), the three summed afterwards: tapgemm_lean_kernel's order */            \
-            f32x4 part[MT];                                                                                                \
-            _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                                                               \
-                _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                             \
-                    part[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[t][s4], XC[t][m][s4], s4 ? part[m] : zero4(), 0, 0, 0); \
-            _Pragma("unroll") for (int m = 0; m < MT; ++m) acc[0][m] = t ? acc[0][m] + part[m] : part[m];                  \
-            /* (taps 0 + 1 are summed before tap 2's chain starts: with all three chains' results live the MODE 1 form   \
-             * spills at its 128-register budget; the matrix pipe's bubble belongs to the SIMD's other waves) */           \
-            if (t == 1) { _Pragma("unroll") for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(acc[0][m])); }             \
-        }                                                                                                                  \
-        /* (the fences keep hipcc from hoisting these loads above the MFMAs, where they would need a second register set) */ \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        if (!DB && more) issue(XC, n2, i2, j2);         /* the operand registers are free: the next tile's loads fly during the epilogue */ \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        {                                                                                                                  \
-            const unsigned bx = tile;                                                                                      \
-            int pn[MT], pi[MT], pj[MT];                                                                                    \
-            bool pv[MT];                                                                                                   \
-            _Pragma("unroll") for (int m = 0; m < MT; ++m) { pn[m] = n; pi[m] = i; pj[m] = j0 + m * 16 + pl; pv[m] = true; } \
-            LF_TAPGEMM_EPILOGUE                                                                                            \
-            __builtin_amdgcn_s_setprio(0);                                                                                 \
-        }                                                                                                                  \
-        n = n2; i = i2; j0 = j2; tile += per;                                                                              \
-    }
-    if constexpr (DB) {
-        while (true) {
-            LF_LEANP_STEP(xa, xb)
-            if (tile >= t_hi) break;
-            LF_LEANP_STEP(xb, xa)
-            if (tile >= t_hi) break;
-        }
-    } else {
-        while (true) {
-            LF_LEANP_STEP(xa, xa)
-            if (tile >= t_hi) break;
-            // the statistics staging array is read by wave 0 behind the epilogue's barrier: a second one before anybody writes it again
-            // (the two-set form expands the step twice: two arrays, a wave one barrier ahead never writes what a slower one still reads)
-            if constexpr ((EPIC & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0) LF_EPI_SYNC;
-        }
-    }
-#undef LF_LEANP_STEP
-}
-#undef LF_EPI_SYNC
-#define LF_EPI_SYNC __syncthreads()
-#undef LF_EPI_BIAS
-#define LF_EPI_BIAS(co) (a.bias ? ldb4(r_bias, (co) * 4u, 0u) : zero4())
-#undef LF_EPI_STAT_STORE
-#define LF_EPI_STAT_STORE(idx, v) a.stats[idx] = (v)
-
-int g_lean_p = 1;              // tools / tests only: 0 = tapgemm_lean_kernel for every 16-channel launch, 1 = the persistent form where it applies
-                               // (shipped), 2 = its two-register-set variant
 int g_split_any_size = 0;      // kernel-level tests only: let the split kernel take launches below its shipped size rule
 int g_bf16_lds = 4;            // tools / A-B runs only: 4 = whole-line + 16-channel kernels where they apply, else the ring (shipped); 2 = the ring
                                // for every launch it takes; 0 = the streaming bf16 kernel only
@@ -1870,7 +1731,6 @@ int pick_nt(int Cd) {
 
 void lf_tapgemm_set_split_any_size(int v) { g_split_any_size = v; }
 void lf_tapgemm_set_bf16_lds(int v) { g_bf16_lds = v; }
-void lf_tapgemm_set_lean_p(int v) { g_lean_p = v; }
 
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
 // workgroups (its two 4-wave groups each own one 256-pixel statistics row), 16-byte aligned pixels
@@ -1959,25 +1819,6 @@ bool launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const L
     if (gx > res && res >= 8) gx = res & ~7u;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, st, g, a, pro, epi);
     return true;
-}
-// tapgemm_lean_p_kernel: persistent; every XCD's tile range is dealt to gridDim.x / 8 workgroups, as many as are resident at once
-// and then as few as give every workgroup the same number of tiles (4096 tiles on 768 slots: 688 workgroups of 6 would leave the
-// last round a sixth full -- the rule picks the grid, the kernel takes any)
-template <int PROV, int EPIV>
-void launch_lean_p(unsigned ntiles, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a) {
-    auto go = [&](auto kern) {
-        const unsigned res = (unsigned)resident_workgroups(kern, 0);
-        const unsigned per_x = ntiles / 8;
-        unsigned wg_x = res / 8 < per_x ? res / 8 : per_x;
-        if (wg_x < 1) wg_x = 1;
-        const unsigned tpw = (per_x + wg_x - 1) / wg_x;
-        wg_x = (per_x + tpw - 1) / tpw;
-        if (g_launch_flags) hipExtLaunchKernelGGL(kern, dim3(wg_x * 8), dim3(256), 0, st, nullptr, nullptr, g_launch_flags, g, a, (int)ntiles);
-        else hipLaunchKernelGGL(kern, dim3(wg_x * 8), dim3(256), 0, st, g, a, (int)ntiles);
-    };
-    if (g_lean_p == 2) go(tapgemm_lean_p_kernel<PROV, EPIV, 2>);
-    else if (g_lean_p == 3) go(tapgemm_lean_p_kernel<PROV, EPIV, 3>);
-    else go(tapgemm_lean_p_kernel<PROV, EPIV, 1>);
 }
 }  // namespace
 
@@ -2190,25 +2031,6 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         case 2: LF_TG(2); break;
         default:
             {
-                // the plain 16 -> 16 channel 3-tap convolutions (20 launches per step): persistent workgroups
-                if (g_lean_p && g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.ssh == 1 && g.ssw == 1 && (g.Wl & 63) == 0 &&
-                    npix % PIX_PER_WG == 0 && npix / PIX_PER_WG >= 8 && (pro == LF_PRO_NONE || epi == LF_EPI_RELU)) {
-                    const unsigned ntiles = (unsigned)(npix / PIX_PER_WG);
-                    bool taken = true;
-                    if (pro == LF_PRO_BNRELU) launch_lean_p<1, LF_EPI_RELU>(ntiles, st, g, a);
-                    else switch (epis) {
-                        case 0: launch_lean_p<0, 0>(ntiles, st, g, a); break;
-                        case LF_EPI_RELU: launch_lean_p<0, LF_EPI_RELU>(ntiles, st, g, a); break;
-                        case LF_EPI_MASK: launch_lean_p<0, LF_EPI_MASK>(ntiles, st, g, a); break;
-                        case LF_EPI_ADD: launch_lean_p<0, LF_EPI_ADD>(ntiles, st, g, a); break;
-                        case LF_EPI_STATS_SQ: launch_lean_p<0, LF_EPI_STATS_SQ>(ntiles, st, g, a); break;
-                        case LF_EPI_MASK | LF_EPI_STATS_XHAT: launch_lean_p<0, LF_EPI_MASK | LF_EPI_STATS_XHAT>(ntiles, st, g, a); break;
-                        case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: launch_lean_p<0, LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT>(ntiles, st, g, a); break;
-                        case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: launch_lean_p<0, LF_EPI_MASKBN | LF_EPI_STATS_XHAT>(ntiles, st, g, a); break;
-                        default: taken = false; break;
-                    }
-                    if (taken) break;
-                }
 #define LF_LEAN(PROV, EPIV) hipLaunchKernelGGL((tapgemm_lean_kernel<1, PROV, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi)
                 if (pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) LF_LEAN(1, LF_EPI_RELU);
                 else if (pro == LF_PRO_BNRELU) LF_LEAN(1, -1);

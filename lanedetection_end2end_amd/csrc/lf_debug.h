@@ -10,8 +10,6 @@ void lf_debug_set_split_any_size(int v);
 /* which bf16-tensor tap-GEMM kernels run: 4 (shipped) whole-line + 16-channel kernels where they apply, else the ring; 2 the ring for
    every launch it takes; 0 the streaming kernel only (A/B timing, bit-identity of the forms: tools/bf16_ab.py, tests/test_bf16_kernels_gpu.py) */
 void lf_debug_set_bf16_lds(int v);
-/* the plain fp32 16 -> 16 channel convolutions: 0 tapgemm_lean_kernel for all of them; 1 (shipped) persistent workgroups where they apply; 2 their two-register-set variant */
-void lf_debug_set_lean_p(int v);
 /* precision mode of the lf_conv1d_* calls: 0 fp32, 1 bf16 matrix cores on fp32 tensors, 2 bf16 matrix cores on bf16
  * tensors (x, y, gx, gy, mask_src hold bf16; w, bias, gw, gb stay fp32), 9 / 6 fp32 from 3-way split operands */
 void lf_debug_set_ops_precision(int mode);
@@ -39,7 +37,7 @@ int lf_debug_conv1d_bwd_data_epi3(const float* gy, const float* w, const float* 
                                   float* gx, float* stats, int N, int H, int W, int C, int axis, int dilation, float* scratch, void* stream);
 /* one convolution launch with any epilogue flag set of csrc/lf_conv.h (1 ReLU, 2 mask by mask_src > 0, 4 + add_src, 8 BN forward sums,
  * 16 mask by aux * msc + msh > 0, 32 BN-backward sums over aux); transposed = 1: the data gradient's weights.  Returns the number of
- * statistics rows written ([rows][2][C]), 0 without a sums flag, -1 on error.  (tests/test_lean_gpu.py, tools/lean_ab.py) */
+ * statistics rows written ([rows][2][C]), 0 without a sums flag, -1 on error.  (tests/test_lean_gpu.py) */
 int lf_debug_conv1d_epi(const float* src, const float* w, const float* bias, float* dst, int transposed, int epi, const float* mask_src,
                         const float* add_src, const float* aux, const float* msc, const float* msh, float* stats, int N, int H, int W, int C,
                         int axis, int dilation, float* scratch, void* stream);

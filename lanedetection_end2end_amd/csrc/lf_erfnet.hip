@@ -574,6 +574,8 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
         }
         for (int t = 0; t < op.geom.ntaps; ++t) j.tapidx[t] = e.tapidx[t];
         c.reduce_jobs.push_back(j);
+        // (launching the reductions gathered so far early and WITHOUT a barrier bit, beside a later weight / data gradient, was
+        // measured: same bits, no gain -- DESIGN.md section 9)
         return 0;
     }
     LF_TRY(lf_wgrad_reduce_launch(a.partial, nsplit, op.geom.ntaps, op.geom.Cs, op.geom.Cd,
@@ -779,6 +781,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
 int upload_and_pack(const Ctx& c, const float* const* params_dev) {
     const lf_erfnet_plan* P = c.P;
     LfPackEntry* ent = reinterpret_cast<LfPackEntry*>(c.at(P->off_entries));
+    // (8 KB from a pageable vector; a page-locked copy of the table was measured: no difference on the step)
     if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
         return lf_fail("erfnet: upload of the pack table failed");
     LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
@@ -792,6 +795,7 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
 }  // namespace
 
 extern "C" {
+
 
 // Forward.  img (N,Cin,H,W) fp32 NCHW; params_host / params_dev: the n_params parameter tensors in
 // state_dict order (weights, biases, BN weight/bias; buffers excluded), as a HOST array and a DEVICE

@@ -96,7 +96,6 @@ extern "C" {
 
 void lf_debug_set_split_any_size(int v) { lf_tapgemm_set_split_any_size(v); }
 void lf_debug_set_bf16_lds(int v) { lf_tapgemm_set_bf16_lds(v); }
-void lf_debug_set_lean_p(int v) { lf_tapgemm_set_lean_p(v); }
 // precision mode of the kernel-level conv1d calls below (tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32 tensors,
 // 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src then hold bf16 elements; w, bias, gw, gb stay fp32)
 void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = mode; }

@@ -1047,3 +1047,4 @@ def test_bf16_tensor_mode_backward_straight_through(shape):
     for k, bound in sites.items():
         if k in errs:
             assert errs[k] < bound and cosines[k] > (0.995 if big else 0.999), (k, errs[k], cosines[k])
+
