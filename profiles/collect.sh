@@ -68,13 +68,14 @@ DB=$(find $OUT/trace_bp16 -name '*_results.db' | head -1)
 # 4d. (round 5) the read-once bf16 weight gradient against the job form on the same launches; the ticket-finalise micro-benchmark
 ( echo "# commit $COMMIT  sources digest $DIGEST (tools/wgrad_ro_ab.py: lf_conv1d_bwd_weight incl. the split-K reduction, HIP events)"; timeout 200 python tools/wgrad_ro_ab.py --iters 100 ) > profiles/${TAG}_wgrad_ro_vs_job_form.txt 2>&1
 [ -x tools/ticket_tail ] && ( echo "# commit $COMMIT  (tools/ticket_tail.hip: BatchNorm finalise as a dependent launch vs inside the producing launch by ticket)"; timeout 60 ./tools/ticket_tail ) > profiles/${TAG}_ticket_tail.txt 2>&1
+[ -x tools/write_policy ] && ( echo "# commit $COMMIT  (tools/write_policy.hip: a layer chain without arithmetic -- copy launches whose destination is the next one's source -- by number of buffers in the chain and store cache policy)"; timeout 60 ./tools/write_policy ) > profiles/${TAG}_write_policy.txt 2>&1
 # 5. the vendor library on the kernel-level problems (torch conv2d through MIOpen) beside the HIP kernels -> profiles/<tag>_kbench_vs_miopen.txt
 timeout 240 python tools/kbench.py --iters 100 --miopen > profiles/${TAG}_kbench_vs_miopen.txt 2>&1
 # only gpurun_out/ travels back (<= 64 MiB): keep the summaries and logs, drop the databases
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/${TAG}_pmc_bf16_lds.txt profiles/${TAG}_kbench_vs_miopen.txt \
    profiles/${TAG}_bp_bf16_kernel_stats.txt profiles/${TAG}_l2_stream.txt profiles/${TAG}_bf16_lds_vs_streaming.txt profiles/traffic.json profiles/traffic_step.json \
-   profiles/${TAG}_wgrad_ro_vs_job_form.txt profiles/${TAG}_ticket_tail.txt gpurun_out/profiles_$TAG/ 2>/dev/null
+   profiles/${TAG}_wgrad_ro_vs_job_form.txt profiles/${TAG}_ticket_tail.txt profiles/${TAG}_write_policy.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 cp $OUT/*.log $OUT/*.err $OUT/*.json gpurun_out/profiles_$TAG/ 2>/dev/null
 rm -rf $OUT
 head -12 profiles/${TAG}_kernel_stats.txt; cat profiles/traffic.json; tail -3 gpurun_out/profiles_$TAG/*.err gpurun_out/profiles_$TAG/pmc_*.log 2>/dev/null | tail -30

@@ -5,6 +5,7 @@
 cd "$(dirname "$0")/.."
 [ -x tools/l2_stream ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value tools/l2_stream.hip -o tools/l2_stream
 [ -x tools/ticket_tail ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result tools/ticket_tail.hip -o tools/ticket_tail
+[ -x tools/write_policy ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result tools/write_policy.hip -o tools/write_policy
 HEAD=$(git rev-parse HEAD)
 DIRTY=$(git status --porcelain --untracked-files=no | wc -l)
 DIGEST=$(cat lanedetection_end2end_amd/csrc/*.hip lanedetection_end2end_amd/csrc/*.h bench.py | sha256sum | cut -c1-16)
