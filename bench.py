@@ -225,6 +225,16 @@ def cpu_baseline_and_parity(precision):
                            "the fp64 run end to end; the fit on identical logits is held to 1e-5",
               "ok": bool(tb[0] <= max(1.5 * tb[2], 1e-5) and tl[0] <= max(1.5 * tl[2], 1e-5) and
                          e2e_oracle.relerr(beta, c["beta"]) <= 1e-5 and (precision != "fp32" or teb[0] <= 1e-5))}
+    if precision in ("bf16", "bf16_mfma"):
+        # bf16 operands (2^-9 per rounding, 2^16 x fp32's): the train-mode network at random initialisation amplifies a
+        # perturbation ~3000 x (fp32's own 6e-8 arrives as cpu32_vs_cpu64 = 1.7e-4 on the logits), so the train-mode figures above
+        # are reported, not gated; what is gated is what bf16 can promise: eval mode end to end and the fp64 fit on identical logits
+        parity["criterion"] = ("precision mode %s: eval mode: lane coefficients within 2e-2 of the fp64 run end to end (bf16 rounding "
+                               "through 23 blocks; measured 5e-3); the fit on identical logits within 1e-5; the train-mode figures are "
+                               "reported only (the train-mode network amplifies a rounding ~3000 x: fp32's own run sits "
+                               "cpu32_vs_cpu64 from fp64)" % precision)
+        parity["eval_mode"]["criterion"] = "lane coefficients hip_vs_cpu64 <= 2e-2 (bf16 operands)"
+        parity["ok"] = bool(e2e_oracle.relerr(beta, c["beta"]) <= 1e-5 and teb[0] <= 2e-2)
     return base, parity
 
 
