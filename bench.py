@@ -102,13 +102,16 @@ def _algorithmic_bytes(csv_path, esz, psteps):
     except OSError:
         return None
     out = {"tapgemm": 0.0, "tapwgrad": 0.0}
-    for fam, layer, Cs, Cd, ntaps, npix, epi, us, tf in rows:
-        fam, Cs, Cd, npix, epi = int(fam), int(Cs), int(Cd), int(npix), int(epi) & 0xff
-        if fam == 0:
-            extra = bin(epi & (2 | 4)).count("1") + (1 if epi & (16 | 32) else 0)      # MASK, ADD; one aux tensor for MASKBN / XHAT
-            out["tapgemm"] += npix * (Cs + Cd * (1 + extra)) * esz
-        else:
-            out["tapwgrad"] += npix * (Cs + Cd) * esz
+    try:
+        for row in rows:
+            fam, Cs, Cd, npix, epi = int(row[0]), int(row[2]), int(row[3]), int(row[5]), int(row[6]) & 0xff
+            if fam == 0:
+                extra = bin(epi & (2 | 4)).count("1") + (1 if epi & (16 | 32) else 0)      # MASK, ADD; one aux tensor for MASKBN / XHAT
+                out["tapgemm"] += npix * (Cs + Cd * (1 + extra)) * esz
+            else:
+                out["tapwgrad"] += npix * (Cs + Cd) * esz
+    except (ValueError, IndexError):          # a record layout this reader does not know: no figure rather than no JSON line
+        return None
     return {k: int(v / psteps) for k, v in out.items()}
 
 
@@ -123,19 +126,24 @@ def _load_json(path):
 def cpu_baseline_and_parity(precision):
     """(cpu_baseline, parity).
 
-    cpu_baseline: the CPU oracle ("port": oracle/e2e_oracle.bev_step = functional torch-CPU ERFNet in fp32 + fp64 numpy WLS /
-    area loss with analytic backward) timed on this box's host cores on a bounded sample: batch 4 (config C1, several steps)
-    and batch 32 (the headline's batch): one warm-up step, then >= 5 timed steps each, median.  profiles/cpu_port_calibration.json (oracle/calibrate_port.py, authoring
-    container, where /root/reference exists) gives the port's speed relative to the real reference modules.
+    cpu_baseline: the reference's step timed on this box's host cores.  /root/reference cannot travel to the GPU box, so the
+    timed code is oracle/vendor_baseline.bev_step on device "cpu": the reference's exact ATen call sequence (F.conv2d /
+    F.conv_transpose2d / F.max_pool2d / F.batch_norm / F.dropout2d / F.relu, torch.bmm + torch.inverse per lane, the closed-form
+    area loss, loss.backward()) -- on the CPU these dispatch the same oneDNN / LAPACK kernels the reference's nn.Modules do
+    (BEV/main.py:213-223,264-265; train mode, Dropout2d ON as in the reference).  Bounded sample: batch 4 (config C1) and batch 32
+    (the headline's batch), one warm-up step + 5 timed steps each, medians.  profiles/cpu_port_calibration.json
+    (oracle/calibrate_port.py, run in the authoring container where /root/reference exists) holds its speed relative to the
+    real reference modules on the same inputs (0.97) -- quoted, not applied.  Secondary key `port`: oracle/e2e_oracle.bev_step
+    (fp32 functional backbone + fp64 numpy fit with analytic backward), batch 4 only -- the step the parity legs below compute.
 
     parity (second half of the BASELINE.json metric, lane-coefficient error vs the CPU reference): the SAME batch-4 input
-    through the HIP path (same parameters, train mode, Dropout2d off) against the oracle's fp32-backbone leg ("cpu32", what
-    the timed step computed) and its fp64-backbone leg ("cpu64"): backbone + fit + loss, not the fit alone.  Checker only:
-    runs after the timed region, on rank 0 at N = 1."""
+    through the HIP path (same parameters, train mode, Dropout2d off) against the oracle's fp32-backbone leg ("cpu32") and
+    its fp64-backbone leg ("cpu64"): backbone + fit + loss, not the fit alone.  Checker only: runs after the timed region,
+    on rank 0 at N = 1."""
     from lanedetection_end2end_amd.bev.Loss_crit import Area_Loss
     from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Net
     import synthetic_inputs as inputs
-    from oracle import e2e_oracle, erfnet_oracle
+    from oracle import e2e_oracle, erfnet_oracle, fit_oracle, vendor_baseline
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
     R = 256
@@ -144,36 +152,47 @@ def cpu_baseline_and_parity(precision):
     def sample(N, seed):
         return torch.from_numpy(inputs.images(N, R, 2 * R, seed=seed)), inputs.bev_gt_params(N, seed=seed + 1)
 
-    def timed(N, seed, budget, max_steps, min_steps):
+    def timed(fn, budget, max_steps, min_steps):
         """One untimed warm-up step (allocator, thread pool, oneDNN primitive cache), then timed steps: at least `min_steps`
         (>= 5 timed iterations after the warm-up), more while the budget lasts, at most `max_steps`."""
-        x, gt = sample(N, seed)
-        out = e2e_oracle.bev_step(x, P, gt, torch.float32, R)
+        out = fn()
         times = []
         t_end = time.perf_counter() + budget
         while len(times) < max_steps and (len(times) < min_steps or time.perf_counter() < t_end):
             t0 = time.perf_counter()
-            out = e2e_oracle.bev_step(x, P, gt, torch.float32, R)
+            out = fn()
             times.append(time.perf_counter() - t0)
-        return x, gt, out, times
-    x4, gt4, o32, t4 = timed(4, 61, 8.0, 8, 5)
-    _, _, _, t32 = timed(32, 161, 0.0, 5, 5)        # the headline's batch: 1 warm-up + 5 timed steps (~20 s each on 64 threads)
-    cal = _load_json(CALIBRATION_FILE)
-    base = {"value": round(4 / float(np.median(t4)), 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "batch 4, 256x512, 2 lanes: fp32 backbone + fp64 fit and loss, fwd + bwd, 1 warm-up + %d timed steps "
-                      "(median); batch 32: 1 warm-up + %d timed steps (median)" % (len(t4), len(t32)),
-            "batch32": {"value": round(32 / float(np.median(t32)), 3), "unit": "images/sec", "steps": len(t32), "warmup": 1},
-            # what the real reference modules would show on these cores if the port / reference ratio measured in the
-            # authoring container carried over (the reference cannot travel to the GPU box): value / ratio
-            "reference_equivalent": None if cal is None else
-            {"value": round(4 / float(np.median(t4)) / cal["ratio_port_over_reference"], 3),
-             "batch32": round(32 / float(np.median(t32)) / cal["ratio_port_over_reference"], 3), "unit": "images/sec",
-             "note": "port figure / port_over_reference.ratio -- a calibrated ESTIMATE, not a measurement of the reference: the "
-                     "ratio was taken on another CPU at %d threads, this run used %d (the reference cannot travel to the GPU "
-                     "box: /root/reference does not exist there)" % (cal["threads"], threads)},
-            "port_over_reference": None if cal is None else
-            {"ratio": round(cal["ratio_port_over_reference"], 3), "measured_on": "%s, %d threads, batch %d"
-             % (cal["cpu"], cal["threads"], cal["batch"]), "source": "profiles/cpu_port_calibration.json"}}
+        return out, times
+
+    # ---- the reference's ATen call sequence on the CPU (train mode, Dropout2d on)
+    Pa = vendor_baseline.trainable_params(4, "cpu")
+    grid_cpu = vendor_baseline.bev_grid(R, "cpu")
+    zr = fit_oracle.zero_rows_of(R, 0.3)
+    x4, gt4 = sample(4, 61)
+    gt4t = torch.from_numpy(gt4)
+    _, ta4 = timed(lambda: vendor_baseline.bev_step(x4, Pa, gt4t, grid_cpu, zr), 6.0, 8, 5)
+    x32, gt32 = sample(32, 161)
+    gt32t = torch.from_numpy(gt32)
+    _, ta32 = timed(lambda: vendor_baseline.bev_step(x32, Pa, gt32t, grid_cpu, zr), 0.0, 5, 5)
+    del x32, gt32t
+    # ---- the oracle port (what the parity legs compute), batch 4
+    o32, t4 = timed(lambda: e2e_oracle.bev_step(x4, P, gt4, torch.float32, R), 4.0, 8, 5)
+    cal = _load_json(CALIBRATION_FILE) or {}
+    base = {"value": round(4 / float(np.median(ta4)), 3), "unit": "images/sec", "cores": threads,
+            "kind": "port (reference ATen call sequence)",
+            "sample": "oracle/vendor_baseline.bev_step on the CPU = the reference's own torch.nn.functional / bmm / inverse calls, "
+                      "train mode with Dropout2d, fwd + loss + bwd; batch 4, 256x512, 2 lanes: 1 warm-up + %d timed steps (median); "
+                      "batch 32: 1 warm-up + %d timed steps (median)" % (len(ta4), len(ta32)),
+            "batch32": {"value": round(32 / float(np.median(ta32)), 3), "unit": "images/sec", "steps": len(ta32), "warmup": 1},
+            # how this call sequence compares with the real reference modules, measured where both exist (authoring container)
+            "aten_over_reference": None if "ratio_aten_over_reference" not in cal else
+            {"ratio": round(cal["ratio_aten_over_reference"], 3), "measured_on": "%s, %d threads, batch %d"
+             % (cal["cpu"], cal["threads"], cal["batch"]), "source": "profiles/cpu_port_calibration.json",
+             "note": "quoted, not applied: the value above is what was timed on this box"},
+            "port": {"value": round(4 / float(np.median(t4)), 3), "unit": "images/sec", "steps": len(t4), "warmup": 1,
+                     "what": "oracle/e2e_oracle.bev_step, batch 4: fp32 functional backbone + fp64 numpy fit and loss with analytic "
+                             "backward (the parity legs' step)",
+                     "port_over_reference": None if "ratio_port_over_reference" not in cal else round(cal["ratio_port_over_reference"], 3)}}
     o64 = e2e_oracle.bev_step(x4, P, gt4, torch.float64, R)
     model = Net(make_args(4))
     model.net.load_state_dict(P)
@@ -188,7 +207,6 @@ def cpu_baseline_and_parity(precision):
     loss = crit(b0, gtc[:, 0]) + crit(b1, gtc[:, 1])
     beta = torch.stack([b0, b1], 1)[..., 0].detach().double().cpu().numpy()
     # the fit alone: fp64 WLS of the oracle on the very logits the HIP backbone produced
-    from oracle import fit_oracle
     Mh, _ = fit_oracle.bev_homography()
     grid = fit_oracle.projective_grid(R, 2 * R, Mh.astype(np.float32), True, np.float32)
     c = fit_oracle.wls_forward(output.detach().float().cpu().numpy(), grid, model.zero_rows, 2, 0.0, 1.0, "square")
@@ -209,32 +227,35 @@ def cpu_baseline_and_parity(precision):
     e64 = e2e_oracle.bev_step(x4, Pe, gt4, torch.float64, R, training=False)
     teb = e2e_oracle.triple(ebeta, e32["beta"], e64["beta"])
     teg = e2e_oracle.triple(eout.detach().cpu().numpy(), e32["logits"], e64["logits"])
+    bf16 = precision == "bf16"
+    fit_err = e2e_oracle.relerr(beta, c["beta"])
+    fit_ok = bool(fit_err <= 1e-5)
+    eval_ok = bool(teb[0] <= (2e-2 if bf16 else 1e-5))
+    # bf16 operands (2^-9 per rounding, 2^16 x fp32's): the train-mode network at random initialisation amplifies a perturbation
+    # ~3000 x (fp32's own 6e-8 arrives as cpu32_vs_cpu64 = 1.7e-4 on the logits), so no end-to-end train-mode bound exists for
+    # bf16: train_ok is null there and `train_mode_gated` says so (`ok` must not read "pass" for figures nobody
+    # gated -- bf16 train mode is pinned per kernel and per block by tests/, not by this line)
+    train_ok = None if bf16 else bool(tb[0] <= max(1.5 * tb[2], 1e-5) and tl[0] <= max(1.5 * tl[2], 1e-5))
     parity = {"input": "the cpu_baseline batch (4 x 3 x 256 x 512, seed 61), same parameters, train mode, Dropout2d off",
               "lane_coeff_max_rel_err": dict(zip(keys, (float("%.3e" % v) for v in tb))),
               "loss_rel_err": dict(zip(keys, (float("%.3e" % v) for v in tl))),
               "logits_max_rel_err": dict(zip(keys, (float("%.3e" % v) for v in tg))),
-              "fit_only_lane_coeff_max_rel_err": float("%.3e" % e2e_oracle.relerr(beta, c["beta"])),
+              "fit_only_lane_coeff_max_rel_err": float("%.3e" % fit_err),
               "hip_over_cpu32_distance_to_fp64": {"lane_coeff": round(tb[0] / max(tb[2], 1e-30), 3),
                                                   "logits_max": round(tg[0] / max(tg[2], 1e-30), 3)},
               "eval_mode": {"input": "the same batch and parameters, model.eval(): running statistics after the one train-mode step above",
                             "lane_coeff_max_rel_err": dict(zip(keys, (float("%.3e" % v) for v in teb))),
                             "logits_max_rel_err": dict(zip(keys, (float("%.3e" % v) for v in teg))),
-                            "criterion": "lane coefficients hip_vs_cpu64 <= 1e-5 (north_star's tolerance, end to end)"},
+                            "criterion": "lane coefficients hip_vs_cpu64 <= %s" % ("2e-2 (bf16 operands through 23 blocks; measured 5e-3)" if bf16 else
+                                                                                   "1e-5 (north_star's tolerance, end to end)")},
               "criterion": "train mode: hip_vs_cpu64 <= 1.5 * cpu32_vs_cpu64 (the distance of the reference arithmetic's own fp32 run "
-                           "from fp64; 2 x before round 4's two-accumulator convolutions); eval mode: lane coefficients within 1e-5 of "
-                           "the fp64 run end to end; the fit on identical logits is held to 1e-5",
-              "ok": bool(tb[0] <= max(1.5 * tb[2], 1e-5) and tl[0] <= max(1.5 * tl[2], 1e-5) and
-                         e2e_oracle.relerr(beta, c["beta"]) <= 1e-5 and (precision != "fp32" or teb[0] <= 1e-5))}
-    if precision in ("bf16", "bf16_mfma"):
-        # bf16 operands (2^-9 per rounding, 2^16 x fp32's): the train-mode network at random initialisation amplifies a
-        # perturbation ~3000 x (fp32's own 6e-8 arrives as cpu32_vs_cpu64 = 1.7e-4 on the logits), so the train-mode figures above
-        # are reported, not gated; what is gated is what bf16 can promise: eval mode end to end and the fp64 fit on identical logits
-        parity["criterion"] = ("precision mode %s: eval mode: lane coefficients within 2e-2 of the fp64 run end to end (bf16 rounding "
-                               "through 23 blocks; measured 5e-3); the fit on identical logits within 1e-5; the train-mode figures are "
-                               "reported only (the train-mode network amplifies a rounding ~3000 x: fp32's own run sits "
-                               "cpu32_vs_cpu64 from fp64)" % precision)
-        parity["eval_mode"]["criterion"] = "lane coefficients hip_vs_cpu64 <= 2e-2 (bf16 operands)"
-        parity["ok"] = bool(e2e_oracle.relerr(beta, c["beta"]) <= 1e-5 and teb[0] <= 2e-2)
+                           "from fp64) on lane coefficients and loss -- fp32 modes only; eval mode: lane coefficients within 1e-5 of "
+                           "the fp64 run end to end (bf16: 2e-2); the fit on identical logits within 1e-5",
+              "fit_ok": fit_ok, "eval_ok": eval_ok, "train_ok": train_ok, "train_mode_gated": not bf16,
+              # ok = every gate that exists for this precision mode passed AND the train-mode figures were gated; for bf16 the
+              # train-mode figures above are reported only, so `ok` is null (not true): read fit_ok / eval_ok
+              "ok": (fit_ok and eval_ok and train_ok) if not bf16 else None,
+              "failed": not (fit_ok and eval_ok and train_ok is not False)}
     return base, parity
 
 
@@ -388,7 +409,10 @@ def run_epoch(a, rank, world, dist):
 
 def dry_run(a, rank, world):
     """--dry-run: everything main() does around the model -- ranks from the environment, process group, warm-up, TIMED_BLOCKS
-    barrier-bracketed blocks of --steps steps, MAX over ranks, ONE JSON line from rank 0 -- with a CPU stand-in for the step."""
+    barrier-bracketed blocks of --steps steps, MAX over ranks, ONE JSON line from rank 0 -- with a CPU stand-in for the step.
+    With --workload epoch the stand-in walks BASELINE config 4's sharded epoch plan instead (dp.epoch_batches: 3626 frames,
+    32 per rank -> 14 steps x 256 at 8 ranks, 42 dropped): every rank takes ITS index batch per step, the flat gradient
+    all-reduce runs once per step, and the ranks' batches of every step are gathered and checked to be disjoint."""
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("gloo")
@@ -400,6 +424,54 @@ def dry_run(a, rank, world):
             dist.all_reduce(g)
             g /= world
         return g
+
+    n = dist.get_world_size() if world > 1 else 1
+    if a.workload == "epoch":
+        from lanedetection_end2end_amd import dp
+        B = a.batch or 32
+        batches = list(dp.epoch_batches(EPOCH_FRAMES, B, rank, world, seed=3, epoch=0))
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        seen, disjoint = [], True
+        for idx in batches:                                    # one step per index batch: gather the ranks' batches, reduce
+            mine = torch.from_numpy(np.asarray(idx, dtype=np.int64))
+            allb = [torch.empty_like(mine) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(allb, mine)
+            else:
+                allb = [mine]
+            glob = torch.cat(allb)
+            disjoint &= bool(glob.unique().numel() == glob.numel() == B * world)
+            seen.append(glob)
+            g = step()
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        steps_t = torch.tensor([len(batches)])
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            smin, smax = steps_t.clone(), steps_t.clone()
+            dist.all_reduce(smin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+        else:
+            smin = smax = steps_t
+        allseen = torch.cat(seen) if seen else torch.zeros(0, dtype=torch.int64)
+        ok = bool(abs(float(g[0]) - (world + 1) / 2.0) < 1e-6)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (no GPU work): config 4 epoch plan", "value": None, "unit": "images/sec", "n_gpus": n,
+                              "steps": len(batches), "warmup": 0, "ms_per_step": round(1e3 * float(t) / max(len(batches), 1), 3),
+                              "allreduce_mean_ok": ok, "data": "none",
+                              "epoch_plan": {"frames": EPOCH_FRAMES, "per_rank_batch": B, "global_batch": B * world,
+                                             "steps_min_max_over_ranks": [int(smin), int(smax)],
+                                             "frames_seen": int(allseen.numel()), "frames_dropped": EPOCH_FRAMES - int(allseen.numel()),
+                                             "all_indices_distinct": bool(allseen.unique().numel() == allseen.numel()),
+                                             "index_max": int(allseen.max()) if allseen.numel() else None,
+                                             "every_step_disjoint_across_ranks": disjoint}}))
+        return
 
     for _ in range(a.warmup):
         step()
@@ -417,7 +489,6 @@ def dry_run(a, rank, world):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         blocks.append(float(t))
     ok = bool(abs(float(g[0]) - (world + 1) / 2.0) < 1e-6)     # mean of 1..world
-    n = dist.get_world_size() if world > 1 else 1
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -425,6 +496,286 @@ def dry_run(a, rank, world):
         print(json.dumps({"metric": "dry run (no GPU work)", "value": None, "unit": "images/sec", "n_gpus": n, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": round(1e3 * float(np.median(blocks)) / a.steps, 3),
                           "allreduce_mean_ok": ok, "data": "none"}))
+
+
+DTYPE_NAMES = {"fp32": "f32", "fp32x9": "f32 (split x9)",
+               "bf16": "bf16 (MFMA operands + activation/gradient tensors; fp32 accumulate; weight gradient on the bf16 "
+                       "matrix cores too, v_mfma_f32_16x16x16_bf16; fp32 parameters/statistics/fit)"}
+KERNEL_TIME_FILE = os.path.join(ROOT, "profiles", "kernel_time.json")
+TG_FAMILY, WG_FAMILY = "conv forward + data gradient (tap-GEMM kernels)", "weight gradient (+ its reductions)"
+
+
+def measure(workload, precision, B, steps, warmup, min_seconds, rank, world, dist, no_dropout=False):
+    """The timed region of one workload in this process: build the model, `warmup` untimed steps, then >= TIMED_BLOCKS
+    barrier- and synchronize-bracketed blocks of exactly `steps` steps spanning >= `min_seconds` (MAX over ranks per block, the
+    MEDIAN block is reported), then -- rank 0 -- three extra steps with HIP events around every MFMA launch for the roofline.
+    Returns (line, handles): `line` = the JSON fields of this workload (None on ranks > 0), `handles` = what the extras of the
+    headline need (model, step function, sizes).  Imports nothing from oracle/."""
+    import synthetic_inputs as inputs
+    from lanedetection_end2end_amd import _lib
+    wl = WORKLOADS[workload]
+    R = wl["R"]
+    model, crit = build_model(B, seed=0, workload=workload)     # identical weights on every rank (same seed)
+    if no_dropout:
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0
+    model.net.precision = precision
+    model.check_singular = False             # no per-step D2H read; status is checked after the timed region
+    x = torch.from_numpy(inputs.images(B, R, 2 * R, seed=100 + rank)).cuda()
+    gt = torch.from_numpy(inputs.bev_gt_params(B, seed=200 + rank)).cuda()
+    if workload == "bp":
+        from lanedetection_end2end_amd.bp.Loss_crit import backprojection_loss
+        crit = backprojection_loss(model._bench_args)
+        lanes_np, valid_np = inputs.bp_targets(B, wl["K"], 256, seed=300 + rank)
+        lanes, valid = torch.from_numpy(lanes_np).cuda(), torch.from_numpy(valid_np).cuda()
+        gt_line = torch.zeros(B, wl["K"])
+    elif workload == "seg":
+        from lanedetection_end2end_amd.bp.Loss_crit import define_loss_crit
+        _, crit = define_loss_crit(model._bench_args)
+        target = torch.from_numpy(inputs.seg_targets(B, R, 2 * R, wl["K"] + 1, seed=300 + rank)).cuda()
+        gt_line = torch.zeros(B, wl["K"])
+    params = [p for p in model.parameters()]
+    statuses = []
+    reducer = None
+    if world > 1:
+        from lanedetection_end2end_amd import dp
+        dp.broadcast_parameters(model, src=0)
+        reducer = dp.FlatGradAllReduce(params, flat_provider=model.net.flat_grad)
+
+    def step(reduce=True):
+        if workload == "bev":
+            b0, b1, _, _, _, _, _, _, _ = model(x, True)
+            loss = crit(b0, gt[:, 0]) + crit(b1, gt[:, 1])
+        elif workload == "bp":
+            out = model(x, gt_line, True)
+            loss = sum(crit(out[k], lanes[:, k], valid[:, k])[0] for k in range(wl["K"])) / wl["K"]
+        else:
+            loss = crit(model(x, gt_line, False, early_return=True), target)
+        for p in params:
+            p.grad = None
+        loss.backward()
+        if model.last_status is not None:
+            statuses.append(model.last_status)
+        if reducer is not None and reduce:
+            reducer()          # one flat 8.25 MB RCCL all-reduce (sum / world)
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()                                   # one more untimed step, clocked: sizes the number of blocks
+    torch.cuda.synchronize()
+    est = max(time.perf_counter() - t0, 1e-4)
+    nblocks = max(TIMED_BLOCKS, min(200, int(np.ceil(min_seconds / (est * steps)))))
+    if world > 1:                            # every rank must run the same number of blocks (collectives inside)
+        nb = torch.tensor([nblocks], device="cuda")
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
+        nblocks = int(nb)
+    statuses.clear()
+    # timed region: nblocks blocks of exactly `steps` steps, each bracketed by barrier + synchronize on both sides and reduced
+    # with MAX over the ranks; the MEDIAN block is the reported one (the region spans >= 6.5 s, so that clocks are settled and
+    # an outside sampler with a 5 s period sees the GPU busy)
+    blocks = []
+    for _ in range(nblocks):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dtb], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtb = float(t)
+        blocks.append(dtb)
+    dt = float(np.median(blocks))
+    grad_check = None
+    if reducer is not None:
+        reducer.check()                      # the signature of the last all-reduce (inspected lazily inside the loop)
+        # debug field: every rank must hold bit-identical reduced gradients (two integer checksums of the bucket's bits)
+        bits = reducer.last_flat.view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 251 + 1)).sum()])
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        # the collective alone, event-timed on this rank (10 calls back to back, after the timed region): lets a SCALE line separate
+        # collective time from compute
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        ev0.record()
+        for _ in range(10):
+            reducer()
+        ev1.record()
+        torch.cuda.synchronize()
+        reducer.check()
+        grad_check = {"ranks": dist.get_world_size(), "backend": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
+                      "allreduce_us": round(1e3 * ev0.elapsed_time(ev1) / 10, 1),
+                      "devices": sorted(set(int(v) for v in _gather_ints(dist, torch.cuda.current_device(), world))),
+                      "bucket_elements": int(reducer.last_flat.numel()),
+                      "bit_identical_across_ranks": bool(all(torch.equal(allc[0], c) for c in allc))}
+    bad = int(torch.stack(statuses).abs().sum()) if statuses else 0
+    if bad or not torch.isfinite(loss):
+        raise SystemExit("bench: singular normal matrix / non-finite loss inside the timed region (%s %s)" % (workload, precision))
+    handles = dict(model=model, step=step, B=B, R=R, wl=wl)
+    if rank != 0:
+        return None, handles
+
+    ips = world * B * steps / dt
+    # ---- roofline of the dominant kernel family: extra steps with HIP events around every MFMA launch
+    lib = _lib.load()
+    plan = model.net._plan(B, R, 2 * R)
+    lib.lf_erfnet_profile(plan.handle, 1)
+    psteps = 3
+    for _ in range(psteps):
+        step(reduce=False)     # rank 0 only: no collective here, the other ranks are already at the final barrier
+    torch.cuda.synchronize()
+    buf = (ctypes.c_double * 6)()
+    import tempfile
+    keep_csv = os.environ.get("LF_PROFILE_CSV", "")
+    csv_path = keep_csv or os.path.join(tempfile.gettempdir(), "lf_profile_%d.csv" % os.getpid())
+    lib.lf_erfnet_profile_read(plan.handle, ctypes.cast(buf, ctypes.c_void_p), csv_path.encode())
+    lib.lf_erfnet_profile(plan.handle, 0)
+    alg_bytes = _algorithmic_bytes(csv_path, 2 if precision == "bf16" else 4, psteps)
+    if not keep_csv:
+        try:
+            os.remove(csv_path)
+        except OSError:
+            pass
+    fam = [dict(ms=buf[i * 3], flops=buf[i * 3 + 1], launches=buf[i * 3 + 2]) for i in range(2)]
+    key = "%s_%s_b%d" % (workload, precision, B)
+    traffic = _load_json(TRAFFIC_FILE)
+    tstep = (_load_json(TRAFFIC_STEP_FILE) or {}).get(key)
+    ktime = (_load_json(KERNEL_TIME_FILE) or {}).get(key)
+    names = ["tapgemm_kernel (conv forward + data gradient)", "tapwgrad_kernel (weight gradient)"]
+    dom = 0 if fam[0]["ms"] >= fam[1]["ms"] else 1
+    d = fam[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    # matrix cores each family runs on: both run on the bf16 cores in mode "bf16", else on the fp32 cores (fp32x9 forms its fp32
+    # products on the bf16 cores but is priced against the fp32 peak: it computes fp32 results)
+    fam_peak = [PEAK_BF16_MFMA if precision == "bf16" else PEAK_FP32_MFMA] * 2
+    peak = fam_peak[dom]
+    tfam = (tstep or {}).get("families") or {}
+    dom_t = tfam.get((TG_FAMILY, WG_FAMILY)[dom])
+    launches_per_step = max(d["launches"] / psteps, 1)
+    dom_alg = None if not alg_bytes else alg_bytes[("tapgemm", "tapwgrad")[dom]]
+    roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak / 1e12,
+                "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4),
+                "timing": "HIP event pairs on the launch stream around every launch of the family (includes the ~4 us between an "
+                          "event and the kernel's first wave); frac_by_kernel_durations is the same quotient on rocprofv3's kernel "
+                          "durations",
+                # the same fraction from the kernel durations of the committed rocprofv3 --kernel-trace of this command
+                # (profiles/kernel_time.json, written by profiles/collect.sh; null when the file has no entry for this workload)
+                "frac_by_kernel_durations": None if not ktime or not ktime.get("families", {}).get((TG_FAMILY, WG_FAMILY)[dom]) else
+                round(d["flops"] / psteps / (ktime["families"][(TG_FAMILY, WG_FAMILY)[dom]]["ms_per_step"] * 1e-3) / peak, 4),
+                "kernel_durations_source": None if not ktime else {"file": "profiles/kernel_time.json", "commit": ktime.get("commit"),
+                                                                   "measured_on_these_sources": ktime.get("sources_digest") == _sources_digest(),
+                                                                   "ms_per_step": {k: v.get("ms_per_step") for k, v in ktime.get("families", {}).items()}},
+                # HBM-side bytes per launch, the family's launch-weighted MEAN over the whole step (counters: traffic_step below);
+                # traffic_algorithmic = the mean ALGORITHMIC bytes per launch of the same launches (source + destination + every
+                # epilogue tensor, once each) -- the pair to divide
+                "traffic": None if not dom_t else int(dom_t["bytes_per_step"] / launches_per_step),
+                "traffic_algorithmic": None if not dom_alg else int(dom_alg / launches_per_step),
+                "traffic_over_algorithmic": None if not (dom_t and dom_alg) else round(dom_t["bytes_per_step"] / dom_alg, 3),
+                # one representative launch (128-channel 3-tap conv, batch 32) measured on its own: profiles/traffic.json
+                "traffic_one_launch": None if traffic is None or not (workload == "bev" and precision == "fp32" and B == 32) else
+                {"file": "profiles/traffic.json", "commit": traffic.get("commit"),
+                 "measured_on_these_sources": traffic.get("sources_digest") == _sources_digest(),
+                 "bytes_per_launch": (traffic.get(("tapgemm", "tapwgrad")[dom]) or {}).get("bytes_per_launch"),
+                 "algorithmic_bytes_per_launch": traffic.get("algorithmic_bytes_per_launch")},
+                # whole-step HBM-side bytes from counters (two rocprofv3 --pmc passes over this very command with --no-extras;
+                # profiles/summarize_traffic_step.py): per kernel family, beside the algorithmic bytes of the same launches
+                "traffic_step": None if tstep is None else {
+                    "file": "profiles/traffic_step.json", "commit": tstep.get("commit"),
+                    "measured_on_these_sources": tstep.get("sources_digest") == _sources_digest(),
+                    "traffic_measured_bytes_per_step": tstep.get("total_bytes_per_step"),
+                    "families": {k: {"measured_bytes_per_step": v.get("bytes_per_step"), "launches_per_step": v.get("launches_per_step")}
+                                 for k, v in tfam.items()},
+                    "algorithmic_bytes_per_step": alg_bytes,
+                    "measured_over_algorithmic": None if not alg_bytes else {
+                        "conv forward + data gradient": None if TG_FAMILY not in tfam else round(tfam[TG_FAMILY]["bytes_per_step"] / max(alg_bytes["tapgemm"], 1), 3),
+                        "weight gradient": None if WG_FAMILY not in tfam else round(tfam[WG_FAMILY]["bytes_per_step"] / max(alg_bytes["tapwgrad"], 1), 3)}},
+                "avg_launch_us": round(1e3 * d["ms"] / max(d["launches"], 1), 2),
+                "launches_per_step": d["launches"] / psteps,
+                "families": {names[i]: {"ms_per_step": round(fam[i]["ms"] / psteps, 3),
+                                        "tflops": round(fam[i]["flops"] / max(fam[i]["ms"], 1e-9) / 1e9, 2),
+                                        "peak_tflops": fam_peak[i] / 1e12}
+                             for i in range(2)},
+                "whole_step_frac_of_conv_roofline": round(ips * wl["flop"] / world / peak, 4),
+                "whole_step_roofline_peak_tflops": peak / 1e12,
+                # measured on this chip (tools/mfma_sustain.hip, profiles/r2_mfma_sustain.txt): a bare fp32 MFMA stream holds
+                # 156 TFLOP/s from 10 ms to 1.7 s, i.e. the datasheet peak above is the roof the kernels can be held to
+                "sustained_mfma_measured": 156.0}
+    metric = "images/sec fwd+bwd, 256x512 2-lane bs32" if workload == "bev" else "images/sec fwd+bwd, %s" % workload
+    out = {"metric": metric, "value": round(ips, 2), "unit": "images/sec",
+           "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": DTYPE_NAMES[precision], "data": "synthetic",
+           "config": {"workload": "%s, batch %d per GPU, %s, train mode (BN batch stats, Dropout2d %s), fwd+bwd, optimizer excluded"
+                                  % (wl["desc"], B, precision, "off" if no_dropout else "on"),
+                      "global_batch": world * B, "parallelism": "dp%d" % world,
+                      "grad_allreduce": ("flat fp32 bucket, %s over %d ranks" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else "none"},
+           "timed_blocks_ms_per_step": [round(1e3 * t / steps, 3) for t in blocks[:12]],
+           "timed_blocks": len(blocks), "timed_region_s": round(float(sum(blocks)), 2),
+           "roofline": roofline}
+    if grad_check is not None:
+        out["grad_allreduce_check"] = grad_check
+    if precision == "bf16":
+        # SURVEY 8d: the bf16 backbone is reported against BOTH roofs.  Algorithmic HBM bytes per step = every saved
+        # activation written once and read back twice (next layer's operand / backward's mask + weight-gradient operand)
+        # plus the gradient ping-pong at the same volume: 6 x the bytes of the tensors a backward needs
+        act_bytes = lib.lf_erfnet_activation_floats(plan.handle) * 2
+        hb = 6.0 * act_bytes / (dt / steps)
+        out["roofline_hbm"] = {"bound": "hbm", "achieved": round(hb / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                               "frac": round(hb / PEAK_HBM, 4),
+                               "algorithmic_bytes_per_step": int(6.0 * act_bytes),
+                               "note": "6 x the bytes of the activations a backward needs (the layers' own tensors: no scratch, "
+                                       "no partial rows): each written once, read by the next layer and twice by backward, plus "
+                                       "the gradient ping-pong at the same volume (DESIGN.md 5)",
+                               # HBM-side bytes of the step from counters (profiles/traffic_step.json) and the rate they imply
+                               "traffic_measured_bytes_per_step": None if tstep is None else tstep.get("total_bytes_per_step"),
+                               "measured_rate_GBps": None if tstep is None else round(tstep["total_bytes_per_step"] / (dt / steps) / 1e9, 1)}
+    return out, handles
+
+
+def other_configs(a):
+    """The other BASELINE.json configurations in their one-GPU form, in the SAME driver-run process as the headline (after its
+    timed region, before the CPU legs), >= 3 s of timed steps each: config 3 (BP, 4 lanes, 320x640, batch 64, bf16 --
+    BP/main.py:286-305), config 5's per-GPU shard (segmentation branch, 512x1024, batch 16 -- BP/main.py:256-263) and config 4's
+    epoch on one GPU (3626 synthetic frames through the input pipeline, fwd, loss, bwd, fused Adam).  Not the headline: reported
+    under `other_configs`; a failure of one of them is reported in its entry and does not take the headline line down."""
+    res = {}
+    for name, workload, precision in (("config3_bp_4lanes_320x640_b64_bf16", "bp", "bf16"), ("config5_seg_512x1024_b16_shard", "seg", "fp32")):
+        try:
+            line, h = measure(workload, precision, WORKLOADS[workload]["batch"], a.steps, 3, 3.0, 0, 1, None)
+            res[name] = {k: line[k] for k in ("value", "unit", "ms_per_step", "dtype", "timed_blocks", "timed_region_s") if k in line}
+            res[name]["workload"] = line["config"]["workload"]
+            r = line["roofline"]
+            res[name]["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_by_kernel_durations",
+                                                           "traffic", "traffic_algorithmic", "traffic_over_algorithmic", "families",
+                                                           "whole_step_frac_of_conv_roofline")}
+            if "roofline_hbm" in line:
+                res[name]["roofline_hbm"] = line["roofline_hbm"]
+            del h, line
+        except (Exception, SystemExit) as e:      # noqa: BLE001 -- the headline line must still come out
+            res[name] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    try:
+        ep = Namespace(batch=None, precision="fp32")
+        runs = [run_epoch(ep, 0, 1, None) for _ in range(2)]          # two epochs (~1.9 s each): the second is reported
+        e = runs[-1]
+        res["config4_epoch_3626_frames_1gpu"] = {"value": e["value"], "unit": e["unit"], "ms_per_step": e["ms_per_step"], "dtype": e["dtype"],
+                                                 "epoch_s": e["epoch_s"], "steps": e["steps"], "frames_dropped": e["frames_dropped"],
+                                                 "first_epoch_value": runs[0]["value"], "workload": e["config"]["workload"],
+                                                 "loss_first_last": e["loss_first_last"]}
+    except (Exception, SystemExit) as e:          # noqa: BLE001
+        res["config4_epoch_3626_frames_1gpu"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -439,6 +790,7 @@ def main():
                          "-> fwd -> loss -> bwd -> gradient all-reduce -> fused Adam); ignores --steps / --warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vendor-baseline", action="store_true", help="skip the PyTorch-ROCm / MIOpen leg (miopen_baseline)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE configs (other_configs) of the default run")
     ap.add_argument("--vendor-tune", action="store_true",
                     help="miopen_baseline with cudnn.benchmark=True (MIOpen find mode: ~9 minutes of kernel tuning on a fresh box)")
     ap.add_argument("--min-seconds", type=float, default=TIMED_REGION_S,
@@ -446,15 +798,16 @@ def main():
                          "sampler with a 5 s period then sees the GPU busy); the median block is reported")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rank plumbing check on a box without GPUs (tests/test_bench_contract_cpu.py): rendezvous over "
-                         "gloo, the barrier-bracketed timing loop around a CPU stand-in step (the flat 8.25 MB gradient all-reduce), "
+                         "gloo, the barrier-bracketed timing loop around a CPU stand-in step (the flat 8.25 MB gradient all-reduce; "
+                         "with --workload epoch: config 4's sharded epoch plan, every rank walking its index batches), "
                          "one JSON line from rank 0; measures nothing")
     ap.add_argument("--no-dropout", action="store_true", help="disable Dropout2d (parity-style run)")
-    ap.add_argument("--no-extras", action="store_true", help="the timed region and the roofline steps only: no fp32x9 leg, no "
-                    "baselines (counter passes: profiles/collect.sh, every launch of the run belongs to the measured step)")
-    ap.add_argument("--precision", choices=["fp32", "bf16_mfma", "bf16", "fp32x9", "fp32x6"], default="fp32",
-                    help="fp32 (default = the BASELINE headline); bf16_mfma = conv operands rounded to bf16, fp32 accumulation "
-                         "and fp32 tensors; bf16 = bf16 matrix cores and bf16 activation/gradient tensors (config 3; not "
-                         "parity modes, the reference is fp32 only)")
+    ap.add_argument("--no-extras", action="store_true", help="the timed region and the roofline steps only: no fp32x9 leg, no other "
+                    "configs, no baselines (counter passes: profiles/collect.sh, every launch of the run belongs to the measured step)")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp32x9"], default="fp32",
+                    help="fp32 (default = the BASELINE headline); bf16 = bf16 matrix cores and bf16 activation/gradient tensors "
+                         "(config 3; not a parity mode, the reference is fp32 only); fp32x9 = fp32 tensors and accumulation, "
+                         "products from exact 3-way bf16 splits on the bf16 matrix cores")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -492,221 +845,10 @@ def main():
             print(json.dumps(out))
         return
 
-    import synthetic_inputs as inputs
-    from lanedetection_end2end_amd import _lib
-    wl = WORKLOADS[a.workload]
-    B = a.batch or wl["batch"]
-    R = wl["R"]
-    model, crit = build_model(B, seed=0, workload=a.workload)     # identical weights on every rank (same seed)
-    if a.no_dropout:
-        for m in model.modules():
-            if isinstance(m, torch.nn.Dropout2d):
-                m.p = 0
-    model.net.precision = a.precision
-    model.check_singular = False             # no per-step D2H read; status is checked after the timed region
-    x = torch.from_numpy(inputs.images(B, R, 2 * R, seed=100 + rank)).cuda()
-    gt = torch.from_numpy(inputs.bev_gt_params(B, seed=200 + rank)).cuda()
-    if a.workload == "bp":
-        from lanedetection_end2end_amd.bp.Loss_crit import backprojection_loss
-        crit = backprojection_loss(model._bench_args)
-        lanes_np, valid_np = inputs.bp_targets(B, wl["K"], 256, seed=300 + rank)
-        lanes, valid = torch.from_numpy(lanes_np).cuda(), torch.from_numpy(valid_np).cuda()
-        gt_line = torch.zeros(B, wl["K"])
-    elif a.workload == "seg":
-        from lanedetection_end2end_amd.bp.Loss_crit import define_loss_crit
-        _, crit = define_loss_crit(model._bench_args)
-        target = torch.from_numpy(inputs.seg_targets(B, R, 2 * R, wl["K"] + 1, seed=300 + rank)).cuda()
-        gt_line = torch.zeros(B, wl["K"])
-    params = [p for p in model.parameters()]
-    statuses = []
-    reducer = None
-    if world > 1:
-        from lanedetection_end2end_amd import dp
-        dp.broadcast_parameters(model, src=0)
-        reducer = dp.FlatGradAllReduce(params, flat_provider=model.net.flat_grad)
-
-    def step(reduce=True):
-        if a.workload == "bev":
-            b0, b1, _, _, _, _, _, _, _ = model(x, True)
-            loss = crit(b0, gt[:, 0]) + crit(b1, gt[:, 1])
-        elif a.workload == "bp":
-            out = model(x, gt_line, True)
-            loss = sum(crit(out[k], lanes[:, k], valid[:, k])[0] for k in range(wl["K"])) / wl["K"]
-        else:
-            loss = crit(model(x, gt_line, False, early_return=True), target)
-        for p in params:
-            p.grad = None
-        loss.backward()
-        if model.last_status is not None:
-            statuses.append(model.last_status)
-        if reducer is not None and reduce:
-            reducer()          # one flat 8.25 MB RCCL all-reduce (sum / world)
-        return loss
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    step()                                   # one more untimed step, clocked: sizes the number of blocks
-    torch.cuda.synchronize()
-    est = max(time.perf_counter() - t0, 1e-4)
-    nblocks = max(TIMED_BLOCKS, min(200, int(np.ceil(a.min_seconds / (est * a.steps)))))
-    if world > 1:                            # every rank must run the same number of blocks (collectives inside)
-        nb = torch.tensor([nblocks], device="cuda")
-        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
-        nblocks = int(nb)
-    statuses.clear()
-    # timed region: nblocks blocks of exactly --steps steps, each bracketed by barrier + synchronize on both sides and reduced
-    # with MAX over the ranks; the MEDIAN block is the reported one (the region spans >= 6.5 s, so that clocks are settled and
-    # an outside sampler with a 5 s period sees the GPU busy)
-    blocks = []
-    for _ in range(nblocks):
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            loss = step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dtb = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dtb], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtb = float(t)
-        blocks.append(dtb)
-    dt = float(np.median(blocks))
-    grad_check = None
-    if reducer is not None:
-        reducer.check()                      # the signature of the last all-reduce (inspected lazily inside the loop)
-        # debug field: every rank must hold bit-identical reduced gradients (two integer checksums of the bucket's bits)
-        bits = reducer.last_flat.view(torch.int32).to(torch.int64)
-        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 251 + 1)).sum()])
-        allc = [torch.empty_like(chk) for _ in range(world)]
-        dist.all_gather(allc, chk)
-        # the collective alone, event-timed on this rank (10 calls back to back, after the timed region): lets a SCALE line separate
-        # collective time from compute
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dist.barrier()
-        ev0.record()
-        for _ in range(10):
-            reducer()
-        ev1.record()
-        torch.cuda.synchronize()
-        reducer.check()
-        grad_check = {"ranks": dist.get_world_size(), "backend": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
-                      "allreduce_us": round(1e3 * ev0.elapsed_time(ev1) / 10, 1),
-                      "devices": sorted(set(int(v) for v in _gather_ints(dist, torch.cuda.current_device(), world))),
-                      "bucket_elements": int(reducer.last_flat.numel()),
-                      "bit_identical_across_ranks": bool(all(torch.equal(allc[0], c) for c in allc))}
-    bad = int(torch.stack(statuses).abs().sum()) if statuses else 0
-    if bad or not torch.isfinite(loss):
-        raise SystemExit("bench: singular normal matrix / non-finite loss inside the timed region")
-
-    out = None
+    B = a.batch or WORKLOADS[a.workload]["batch"]
+    out, h = measure(a.workload, a.precision, B, a.steps, a.warmup, a.min_seconds, rank, world, dist, a.no_dropout)
     if rank == 0:
-        ips = world * B * a.steps / dt
-        # ---- roofline of the dominant kernel family: extra steps with HIP events around every MFMA launch
-        lib = _lib.load()
-        plan = model.net._plan(B, R, 2 * R)
-        lib.lf_erfnet_profile(plan.handle, 1)
-        psteps = 3
-        for _ in range(psteps):
-            step(reduce=False)     # rank 0 only: no collective here, the other ranks are already at the final barrier
-        torch.cuda.synchronize()
-        buf = (ctypes.c_double * 6)()
-        import tempfile
-        csv_path = os.environ.get("LF_PROFILE_CSV", "") or os.path.join(tempfile.gettempdir(), "lf_profile_%d.csv" % os.getpid())
-        lib.lf_erfnet_profile_read(plan.handle, ctypes.cast(buf, ctypes.c_void_p), csv_path.encode())
-        lib.lf_erfnet_profile(plan.handle, 0)
-        alg_bytes = _algorithmic_bytes(csv_path, 2 if a.precision == "bf16" else 4, psteps)
-        fam = [dict(ms=buf[i * 3], flops=buf[i * 3 + 1], launches=buf[i * 3 + 2]) for i in range(2)]
-        traffic = _load_json(TRAFFIC_FILE)
-        tstep = (_load_json(TRAFFIC_STEP_FILE) or {}).get("%s_%s_b%d" % (a.workload, a.precision, B))
-        names = ["tapgemm_kernel (conv forward + data gradient)", "tapwgrad_kernel (weight gradient)"]
-        dom = 0 if fam[0]["ms"] >= fam[1]["ms"] else 1
-        d = fam[dom]
-        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        # matrix cores each family runs on: family 0 (conv forward + data gradient) uses the bf16 cores in both bf16 modes; the
-        # weight gradient uses them in mode "bf16" only (v_mfma_f32_16x16x16_bf16 on the raw bf16 tensors), fp32 in "bf16_mfma"
-        fam_peak = [PEAK_BF16_MFMA if a.precision in ("bf16", "bf16_mfma") else PEAK_FP32_MFMA,
-                    PEAK_BF16_MFMA if a.precision == "bf16" else PEAK_FP32_MFMA]
-        peak = fam_peak[dom]
-        step_peak = PEAK_BF16_MFMA if a.precision in ("bf16", "bf16_mfma") else PEAK_FP32_MFMA
-        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak / 1e12,
-                    "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4),
-                    # HBM-side bytes per launch of the family's representative launch (128-channel 3-tap conv, batch 32:
-                    # 33.5 MB in + 33.5 MB out algorithmic) from the committed PMC summary (profiles/collect.sh)
-                    # HBM-side bytes per launch: the family's launch-weighted MEAN over the whole step when the step counters exist
-                    # (traffic_step below), else the representative kbench launch of profiles/traffic.json
-                    "traffic": (int(tstep["families"][("conv forward + data gradient (tap-GEMM kernels)", "weight gradient (+ its reductions)")[dom]]["bytes_per_step"] /
-                                    max(d["launches"] / psteps, 1)) if tstep and tstep.get("families") else
-                                (traffic or {}).get(("tapgemm", "tapwgrad")[dom], {}).get("bytes_per_launch")
-                                if (a.workload == "bev" and a.precision == "fp32" and B == 32) else None),
-                    "traffic_source": None if traffic is None else {"file": "profiles/traffic.json", "commit": traffic.get("commit"),
-                                                                     "measured_on_these_sources": traffic.get("sources_digest") == _sources_digest(),
-                                                                     "algorithmic_bytes_per_launch": traffic.get("algorithmic_bytes_per_launch")},
-                    # whole-step HBM-side bytes from counters (two rocprofv3 --pmc passes over this very command with --no-extras;
-                    # profiles/summarize_traffic_step.py): per kernel family, beside the algorithmic bytes of the same launches
-                    # (per launch: source + destination + every epilogue tensor, once each, from the engine's own launch records)
-                    "traffic_step": None if tstep is None else {
-                        "file": "profiles/traffic_step.json", "commit": tstep.get("commit"),
-                        "measured_on_these_sources": tstep.get("sources_digest") == _sources_digest(),
-                        "traffic_measured_bytes_per_step": tstep.get("total_bytes_per_step"),
-                        "families": {k: {"measured_bytes_per_step": v["bytes_per_step"], "launches_per_step": v["launches_per_step"]}
-                                     for k, v in tstep.get("families", {}).items()},
-                        "algorithmic_bytes_per_step": alg_bytes,
-                        "measured_over_algorithmic": {
-                            "conv forward + data gradient": round(tstep["families"]["conv forward + data gradient (tap-GEMM kernels)"]["bytes_per_step"] / max(alg_bytes["tapgemm"], 1), 3),
-                            "weight gradient": round(tstep["families"]["weight gradient (+ its reductions)"]["bytes_per_step"] / max(alg_bytes["tapwgrad"], 1), 3)}
-                        if alg_bytes and "conv forward + data gradient (tap-GEMM kernels)" in tstep.get("families", {}) else None},
-                    "avg_launch_us": round(1e3 * d["ms"] / max(d["launches"], 1), 2),
-                    "launches_per_step": d["launches"] / psteps,
-                    "families": {names[i]: {"ms_per_step": round(fam[i]["ms"] / psteps, 3),
-                                            "tflops": round(fam[i]["flops"] / max(fam[i]["ms"], 1e-9) / 1e9, 2),
-                                            "peak_tflops": fam_peak[i] / 1e12}
-                                 for i in range(2)},
-                    "whole_step_frac_of_conv_roofline": round(ips * wl["flop"] / world / step_peak, 4),
-                    "whole_step_roofline_peak_tflops": step_peak / 1e12,
-                    # measured on this chip (tools/mfma_sustain.hip, profiles/r2_mfma_sustain.txt): a bare fp32 MFMA stream holds
-                    # 156 TFLOP/s from 10 ms to 1.7 s, i.e. the datasheet peak above is the roof the kernels can be held to
-                    "sustained_mfma_measured": 156.0}
-        metric = "images/sec fwd+bwd, 256x512 2-lane bs32" if a.workload == "bev" else \
-            "images/sec fwd+bwd, %s" % a.workload
-        out = {"metric": metric, "value": round(ips, 2), "unit": "images/sec",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": {"fp32": "f32", "fp32x9": "f32 (split x9)", "fp32x6": "f32 (split x6)", "bf16_mfma": "bf16 MFMA operands (fp32 accumulate, fp32 tensors); weight gradient f32",
-                         "bf16": "bf16 (MFMA operands + activation/gradient tensors; fp32 accumulate; weight gradient on the bf16 "
-                                 "matrix cores too, v_mfma_f32_16x16x16_bf16; fp32 parameters/statistics/fit)"}[a.precision],
-               "data": "synthetic",
-               "config": {"workload": "%s, batch %d per GPU, "
-                                      "%s, train mode (BN batch stats, Dropout2d %s), fwd+bwd, optimizer excluded"
-                                      % (wl["desc"], B, a.precision, "off" if a.no_dropout else "on"),
-                          "global_batch": world * B, "parallelism": "dp%d" % world,
-                          "grad_allreduce": ("flat fp32 bucket, %s over %d ranks" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else "none"},
-               "timed_blocks_ms_per_step": [round(1e3 * t / a.steps, 3) for t in blocks[:12]],
-               "timed_blocks": len(blocks), "timed_region_s": round(float(sum(blocks)), 2),
-               "roofline": roofline}
-        if grad_check is not None:
-            out["grad_allreduce_check"] = grad_check
-        if a.precision in ("bf16", "bf16_mfma"):
-            # the bf16 backbone is reported against BOTH roofs.  Algorithmic HBM bytes per step = every saved
-            # activation written once and read back twice (next layer's operand / backward's mask + weight-gradient operand)
-            # plus the gradient ping-pong at the same volume: 6 x the bytes of the tensors a backward needs
-            lib2 = _lib.load()
-            act_bytes = lib2.lf_erfnet_activation_floats(model.net._plan(B, R, 2 * R).handle) * (2 if a.precision == "bf16" else 4)
-            hb = 6.0 * act_bytes / (dt / a.steps)
-            out["roofline_hbm"] = {"bound": "hbm", "achieved": round(hb / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                                   "frac": round(hb / PEAK_HBM, 4),
-                                   "algorithmic_bytes_per_step": int(6.0 * act_bytes),
-                                   "note": "6 x the bytes of the activations a backward needs (the layers' own tensors: no scratch, "
-                                           "no partial rows): each written once, read by the next layer and twice by backward, plus "
-                                           "the gradient ping-pong at the same volume (DESIGN.md 5)",
-                                   # HBM-side bytes of the step from counters (profiles/traffic_step.json) and the rate they imply
-                                   "traffic_measured_bytes_per_step": None if tstep is None else tstep.get("total_bytes_per_step"),
-                                   "measured_rate_GBps": None if tstep is None else round(tstep["total_bytes_per_step"] / (dt / a.steps) / 1e9, 1)}
+        model, step, R = h["model"], h["step"], h["R"]
         if world == 1 and a.precision == "fp32" and not a.no_extras:
             # not the headline: the same step with the 64- / 128-channel conv products formed on the bf16 matrix cores
             # from exact 3-way splits of both fp32 operands (all 9 partial products, fp32 accumulation)
@@ -725,18 +867,24 @@ def main():
                                     "note": "same workload, precision mode fp32x9 (fp32 tensors and accumulation, exact "
                                             "products via bf16 x3 splits on the bf16 matrix cores; weight gradient on the "
                                             "fp32 cores); parity tests hold it to the fp32 tolerances"}
-        if world == 1 and not a.no_vendor_baseline and not a.no_extras and a.workload == "bev":
+        ips = out["value"]
+        del model, step, h
+        torch.cuda.empty_cache()
+        headline = world == 1 and a.workload == "bev" and not a.no_extras
+        if headline and a.precision == "fp32" and a.batch is None and not a.no_other_configs:
+            out["other_configs"] = other_configs(a)
+        if headline and not a.no_vendor_baseline:
             out["miopen_baseline"] = miopen_baseline(B, R, tune=a.vendor_tune)
             if out["miopen_baseline"].get("value"):
                 out["miopen_baseline"]["hip_over_miopen"] = round(ips / out["miopen_baseline"]["value"], 2)
-        if world == 1 and not a.no_cpu_baseline and not a.no_extras and a.workload == "bev":
+        if headline and not a.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(a.precision)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
-        if out.get("parity") is not None and not out["parity"]["ok"]:
+        if out.get("parity") is not None and out["parity"]["failed"]:
             sys.stderr.write("bench: PARITY FAILED -- the HIP path is further from the fp64 CPU run than the criterion allows: %s\n"
                              % json.dumps(out["parity"]))
             sys.exit(3)

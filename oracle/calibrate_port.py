@@ -1,12 +1,18 @@
-"""Port-vs-reference calibration of bench.py's cpu_baseline ("kind": "port"): times the REAL reference modules
-(/root/reference, through oracle/ref_shims.py) and the port (oracle/e2e_oracle.bev_step, fp32 backbone) on the same
-inputs, same thread count, in the authoring container (the GPU box has no /root/reference).  Writes
-profiles/cpu_port_calibration.json; bench.py quotes the ratio next to the port's number.
+"""Calibration of bench.py's cpu_baseline against the REAL reference: times, on the same inputs and thread count, in the
+authoring container (the GPU box has no /root/reference),
+
+  reference   the unmodified BEV LSQ_layer.Net + Area_Loss from /root/reference (through oracle/ref_shims.py)
+  aten        oracle/vendor_baseline.bev_step on device "cpu": the reference's exact ATen call sequence (F.conv2d / F.batch_norm /
+              F.dropout2d / bmm + inverse; the same oneDNN / LAPACK kernels the reference's nn.Modules dispatch to) -- what
+              bench.py times as cpu_baseline on the GPU box
+  port        oracle/e2e_oracle.bev_step (fp32 backbone, fp64 numpy fit + loss with analytic backward): bench.py's secondary figure
+
+and writes profiles/cpu_port_calibration.json; bench.py quotes the ratios next to its numbers.
 
     python -m oracle.calibrate_port [--batch 4] [--steps 5]
 
 TEST INFRASTRUCTURE ONLY.  Reference step = BEV/main.py:213-223,264-265: model(x, True) -> Area_Loss per lane ->
-zero_grad -> backward, train mode (dropout left ON in the reference: its cost is part of the reference's step).
+zero_grad -> backward, train mode (Dropout2d left ON: its cost is part of the reference's step).
 """
 import argparse
 import json
@@ -16,7 +22,7 @@ import time
 import numpy as np
 import torch
 
-from . import e2e_oracle, erfnet_oracle, inputs, ref_shims
+from . import e2e_oracle, erfnet_oracle, fit_oracle, inputs, ref_shims, vendor_baseline
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -25,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=3, help="the three legs are timed in turn this many times (clock drift)")
     a = ap.parse_args()
     assert ref_shims.available(), "needs /root/reference"
     threads = min(os.cpu_count() or 1, 64)
@@ -49,24 +56,35 @@ def main():
         loss.backward()
         return float(loss)
 
+    Pa = vendor_baseline.trainable_params(4, "cpu")
+    grid = vendor_baseline.bev_grid(R, "cpu")
+    zr = fit_oracle.zero_rows_of(R, 0.3)
+
+    def aten_step():
+        return float(vendor_baseline.bev_step(x, Pa, gtt, grid, zr)[0])
+
     def port_step():
         return e2e_oracle.bev_step(x, P, gt, torch.float32, R)["loss"]
 
-    out = {}
-    for name, fn in (("reference", ref_step), ("port", port_step)):
-        fn()
-        ts = []
-        for _ in range(a.steps):
-            t0 = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - t0)
-        out[name] = {"images_per_sec": N / float(np.median(ts)), "median_s": float(np.median(ts)), "steps": a.steps}
+    legs = (("reference", ref_step), ("aten", aten_step), ("port", port_step))
+    ts = {name: [] for name, _ in legs}
+    for name, fn in legs:
+        fn()                                           # warm-up: allocator, thread pool, oneDNN primitive cache
+    for _ in range(a.rounds):
+        for name, fn in legs:
+            for _ in range(a.steps):
+                t0 = time.perf_counter()
+                fn()
+                ts[name].append(time.perf_counter() - t0)
+    out = {name: {"images_per_sec": N / float(np.median(t)), "median_s": float(np.median(t)), "steps": len(t)} for name, t in ts.items()}
     out["ratio_port_over_reference"] = out["port"]["images_per_sec"] / out["reference"]["images_per_sec"]
+    out["ratio_aten_over_reference"] = out["aten"]["images_per_sec"] / out["reference"]["images_per_sec"]
     out["batch"], out["threads"] = N, threads
     out["cpu"] = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
     out["note"] = ("reference = unmodified BEV LSQ_layer.Net + Area_Loss from /root/reference (cv2 stub, masked_select cast), "
-                   "train mode with its Dropout2d; port = oracle/e2e_oracle.bev_step fp32 (functional torch backbone, fp64 numpy "
-                   "fit + loss with analytic backward, no dropout)")
+                   "train mode with its Dropout2d; aten = oracle/vendor_baseline.bev_step on the CPU (the reference's "
+                   "torch.nn.functional / bmm / inverse calls, Dropout2d on); port = oracle/e2e_oracle.bev_step fp32 (functional "
+                   "torch backbone, fp64 numpy fit + loss with analytic backward, no dropout); legs timed in turn, medians")
     with open(os.path.join(ROOT, "profiles", "cpu_port_calibration.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))

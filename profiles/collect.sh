@@ -31,6 +31,8 @@ esac
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 16 --warmup 4 --min-seconds 1 --no-extras > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 DB=$(find $OUT/trace -name '*_results.db' | head -1)
 ( echo "# commit $COMMIT  sources digest $DIGEST (sha256 of csrc/*.hip csrc/*.h bench.py, first 16 hex)"; python profiles/summarize_rocpd.py "$DB" ) > profiles/${TAG}_kernel_stats.txt
+# 1b. (round 6) kernel durations per step and family of the same trace -> profiles/kernel_time.json (bench.py: roofline.frac_by_kernel_durations)
+python profiles/summarize_kernel_time.py "$DB" bev_fp32_b32 "$COMMIT" "$DIGEST"
 
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 120 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o p -- python tools/kbench.py --iters 3 --one 128 32 64 1 16 > $OUT/pmc_$C.log 2>&1
@@ -49,7 +51,7 @@ for W in "bev fp32 32" "bp bf16 64"; do
 done
 set -- $TAG
 
-timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-vendor-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
+timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o p -- python bench.py --steps 4 --warmup 2 --min-seconds 0 --no-extras > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
 DB=$(find $OUT/pmc_mfma -name '*_results.db' | head -1)
 ( echo "# commit $COMMIT  sources digest $DIGEST"; python profiles/summarize_pmc.py "$DB" 3 ) > profiles/${TAG}_pmc_bench.txt
 # 4b. the bf16-tensor tap-GEMM, LDS-staged vs streaming (tools/bf16_ab.py runs both on the same launches): LDS vs vector-memory
@@ -60,9 +62,10 @@ DB=$(find $OUT/pmc_bf16 -name '*_results.db' | head -1)
 # 4c. bf16 config 3 (BASELINE config 3's geometry and dtype): per-kernel trace of the step -> profiles/<tag>_bp_bf16_kernel_stats.txt;
 #     the L2 -> CU access-pattern micro-benchmark behind the whole-line kernels -> profiles/<tag>_l2_stream.txt; the three bf16 kernel
 #     forms on the same launches -> profiles/<tag>_bf16_lds_vs_streaming.txt
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace_bp16 -o bench -- python bench.py --workload bp --precision bf16 --steps 8 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-vendor-baseline > $OUT/trace_bp16.json 2> $OUT/trace_bp16.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/trace_bp16 -o bench -- python bench.py --workload bp --precision bf16 --steps 8 --warmup 3 --min-seconds 0 --no-extras > $OUT/trace_bp16.json 2> $OUT/trace_bp16.err
 DB=$(find $OUT/trace_bp16 -name '*_results.db' | head -1)
 [ -n "$DB" ] && ( echo "# commit $COMMIT  sources digest $DIGEST"; python profiles/summarize_rocpd.py "$DB" ) > profiles/${TAG}_bp_bf16_kernel_stats.txt
+[ -n "$DB" ] && python profiles/summarize_kernel_time.py "$DB" bp_bf16_b64 "$COMMIT" "$DIGEST"
 [ -x tools/l2_stream ] && ( echo "# commit $COMMIT  (tools/l2_stream.hip; 204800 pixels = 52 MB, then 819200 = 210 MB)"; timeout 60 ./tools/l2_stream 204800; timeout 60 ./tools/l2_stream 819200 ) > profiles/${TAG}_l2_stream.txt 2>&1
 ( echo "# commit $COMMIT  sources digest $DIGEST"; timeout 200 python tools/bf16_ab.py --iters 100 ) > profiles/${TAG}_bf16_lds_vs_streaming.txt 2>&1
 # 4d. (round 5) the read-once bf16 weight gradient against the job form on the same launches; the ticket-finalise micro-benchmark
@@ -74,7 +77,7 @@ timeout 240 python tools/kbench.py --iters 100 --miopen > profiles/${TAG}_kbench
 # only gpurun_out/ travels back (<= 64 MiB): keep the summaries and logs, drop the databases
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_hbm_conv128.txt profiles/${TAG}_pmc_bench.txt profiles/${TAG}_pmc_bf16_lds.txt profiles/${TAG}_kbench_vs_miopen.txt \
-   profiles/${TAG}_bp_bf16_kernel_stats.txt profiles/${TAG}_l2_stream.txt profiles/${TAG}_bf16_lds_vs_streaming.txt profiles/traffic.json profiles/traffic_step.json \
+   profiles/${TAG}_bp_bf16_kernel_stats.txt profiles/${TAG}_l2_stream.txt profiles/${TAG}_bf16_lds_vs_streaming.txt profiles/traffic.json profiles/traffic_step.json profiles/kernel_time.json \
    profiles/${TAG}_wgrad_ro_vs_job_form.txt profiles/${TAG}_ticket_tail.txt profiles/${TAG}_write_policy.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 cp $OUT/*.log $OUT/*.err $OUT/*.json gpurun_out/profiles_$TAG/ 2>/dev/null
 rm -rf $OUT

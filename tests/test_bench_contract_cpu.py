@@ -70,6 +70,10 @@ def test_measured_path_of_bench_imports_nothing_from_the_oracle():
     import ast
     tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
     allowed = {"cpu_baseline_and_parity", "miopen_baseline"}
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    # the legs that DO touch the oracle run after every timed region of the process: other_configs() is called before them
+    assert src.index('out["other_configs"] = other_configs(a)') < src.index('out["miopen_baseline"] = miopen_baseline(') < \
+        src.index('out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(')
     for node in tree.body:
         names = []
         for sub in ast.walk(node):
@@ -86,7 +90,7 @@ def test_single_rank_dry_run():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    path = next(p for p in (os.path.join(ROOT, "profiles", "r%d_bench.json" % r) for r in (3, 2, 1)) if os.path.exists(p))
+    path = next(p for p in (os.path.join(ROOT, "profiles", "r%d_bench.json" % r) for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(p))
     d = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -101,7 +105,19 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] in ("reference", "port")
+    assert c["kind"].split(" ")[0] in ("reference", "port")          # round 6: "port (reference ATen call sequence)"
+    if "other_configs" in d:                            # round 6: the other BASELINE configs ride in the driver-run line
+        oc = d["other_configs"]
+        assert set(oc) == {"config3_bp_4lanes_320x640_b64_bf16", "config5_seg_512x1024_b16_shard", "config4_epoch_3626_frames_1gpu"}
+        for name, e in oc.items():
+            assert e.get("value"), (name, e)
+            for k in ("unit", "ms_per_step", "dtype", "workload"):
+                assert k in e, (name, k)
+        for name in ("config3_bp_4lanes_320x640_b64_bf16", "config5_seg_512x1024_b16_shard"):
+            r2 = oc[name]["roofline"]
+            assert abs(r2["frac"] - r2["achieved"] / r2["peak"]) < 1e-3
+        assert "roofline_hbm" in oc["config3_bp_4lanes_320x640_b64_bf16"]
+        assert r.get("traffic_algorithmic") and r.get("traffic")      # the pair to divide: mean measured / mean algorithmic bytes per launch
     # consistency of the line itself: value = images per step / step time
     assert abs(d["value"] - 32 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     # second half of the BASELINE metric: lane-coefficient error against the CPU oracle
@@ -112,4 +128,6 @@ def test_committed_bench_line_has_the_contract_fields():
         t = par["lane_coeff_max_rel_err"]
         assert set(t) == {"hip_vs_cpu64", "hip_vs_cpu32", "cpu32_vs_cpu64"}
         assert par["ok"] is True and t["hip_vs_cpu64"] <= max(2 * t["cpu32_vs_cpu64"], 1e-5)
+        if "train_ok" in par:                        # round 6: the gates are reported one by one; ok = all of them
+            assert par["fit_ok"] and par["eval_ok"] and par["train_ok"] and par["train_mode_gated"] and not par["failed"]
         assert par["fit_only_lane_coeff_max_rel_err"] <= 1e-5

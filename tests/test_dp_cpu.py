@@ -122,6 +122,31 @@ def test_epoch_batches_config4_sharding():
     assert np.array_equal(np.concatenate(list(dp.epoch_batches(64, 32, shuffle=False))), np.arange(64))
 
 
+def test_epoch_plan_dry_run_world2_gloo():
+    """BASELINE config 4's sharded epoch plan exercised with MORE than one rank before the first real SCALE run: bench.py
+    --workload epoch --dry-run at world size 2 over gloo -- both ranks walk their dp.epoch_batches index batches in step (56 steps
+    of 2 x 32, 42 frames dropped), every step's global batch is disjoint across the ranks, the flat gradient all-reduce runs once
+    per step, one JSON line comes out of rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "epoch", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    ep = d["epoch_plan"]
+    assert d["n_gpus"] == 2 and d["allreduce_mean_ok"] is True
+    assert ep["steps_min_max_over_ranks"] == [56, 56] and d["steps"] == 56
+    assert ep["frames_seen"] == 56 * 64 == 3584 and ep["frames_dropped"] == 42
+    assert ep["all_indices_distinct"] and ep["every_step_disjoint_across_ranks"] and ep["index_max"] < 3626
+
+
 def _premul_avg(per_rank_values, world):
     """What RCCL's ReduceOp.AVG computes for fp32: every rank's value times fp32(1 / world), then an fp32 sum (rank order)."""
     import numpy as np
