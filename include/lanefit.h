@@ -142,18 +142,20 @@ int lf_ce2d_bwd(const float* logits, const int64_t* target, const float* weights
 typedef struct lf_erfnet_plan lf_erfnet_plan;
 lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int out_channels, int n_heads);
 void lf_erfnet_plan_destroy(lf_erfnet_plan* plan);
-/* Matrix-core precision of the convolutions and their data gradients (BASELINE config 3 "bf16"; there is no
- * reference for it -- the reference is fp32 only): 0 = fp32 MFMA (default; the parity path), 1 = operands
- * rounded to bf16 (RNE) in registers, v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 tensors in HBM,
- * 2 = mode 1 with every activation / gradient tensor of the workspace stored as bf16 (weight gradient on the fp32
- * matrix cores from widened operands; parameters, their gradients, BN statistics, logits stay fp32),
- * 3 / 4 = fp32 results on the bf16 matrix cores: tensors and accumulation as in mode 0, but every product of the 64- and
- * 128-channel convolutions and data gradients is formed from exact 3-way bf16 splits of both fp32 operands (3 = all 9
- * partial products, i.e. exact products; 4 = the 6 above 2^-24); parity as mode 0 (tests/test_backbone_gpu.py); launches
- * the split kernel cannot take (other channel counts, pixel counts not a multiple of 512) and the weight gradient run
- * on the fp32 matrix cores. */
+/* Precision mode of the backbone (there is no reference for modes 2 and 3 -- the reference is fp32 only):
+ * 0 = fp32 matrix cores (v_mfma_f32_16x16x4_f32), fp32 tensors: the default, the parity path, the BASELINE headline;
+ * 2 = bf16 tensors (BASELINE config 3): every activation / gradient tensor of the workspace stored as bf16, convolutions, data
+ *     gradients and weight gradients on the bf16 matrix cores with fp32 accumulation; parameters, their gradients, BatchNorm
+ *     statistics and the logits stay fp32;
+ * 3 = fp32 results on the bf16 matrix cores: tensors and accumulation as in mode 0, every product of the 64- and 128-channel
+ *     convolutions and data gradients formed from exact 3-way bf16 splits of both fp32 operands (all 9 partial products, i.e.
+ *     exact products); parity as mode 0 (tests/test_backbone_gpu.py); launches the split kernel cannot take (other channel
+ *     counts, pixel counts not a multiple of 512) and the weight gradient run on the fp32 matrix cores.
+ * (Modes 1 and 4 -- bf16 operands with fp32 tensors, and the 6-term split -- existed until ABI 4; no BASELINE configuration
+ * used them and they were removed in round 6: the call returns an error for them.) */
 int lf_erfnet_set_precision(const lf_erfnet_plan* plan, int mode);
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* plan);   /* follows the precision mode (bf16 tensors: larger partial-row regions): query it after lf_erfnet_set_precision */
+size_t lf_erfnet_workspace_bytes_for(const lf_erfnet_plan* plan, int mode);   /* the same for a named mode, whatever the plan's current setting (0: unknown mode) */
 long lf_erfnet_activation_floats(const lf_erfnet_plan* plan);   /* elements of the saved activations (all layers): bench.py's HBM roofline */
 int lf_erfnet_num_params(const lf_erfnet_plan* plan);
 int lf_erfnet_num_bn(const lf_erfnet_plan* plan);
@@ -196,7 +198,8 @@ int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, vo
  * x / y / gy / gx are NCHW fp32 like the reference's tensors; head >= 0 (only with last = the layer count) appends
  * output_conv (0) / output_conv2 (1) and makes y the logits.  Only the range's parameters are read / receive gradients
  * (grads_host entries outside it are left untouched); BatchNorm running statistics of the range are updated in train mode.
- * lf_erfnet_backward_range must follow lf_erfnet_forward_range on the same workspace.  fp32-tensor precision modes only.
+ * lf_erfnet_backward_range must follow lf_erfnet_forward_range on the same workspace.  Every precision mode (in mode 2 the
+ * range's input and the incoming gradient are rounded to bf16 on their way into the workspace, outputs widened on their way out).
  * The workspace of a range is COMPACT (ABI 4): lf_erfnet_range_workspace_bytes(plan, first, last) = the range's own activations
  * + the plan's globals (packed weights, statistics rows, one partial-row region, three gradient buffers), so that a loop over
  * the blocks of a network keeps the activations of ONE network alive until backward, not one whole-network workspace per block.

@@ -37,6 +37,7 @@ def _declare(lib):
         "lf_erfnet_plan_create": (P, [I, I, I, I, I, I]),
         "lf_erfnet_plan_destroy": (None, [P]),
         "lf_erfnet_workspace_bytes": (c_size_t, [P]),
+        "lf_erfnet_workspace_bytes_for": (c_size_t, [P, I]),
         "lf_erfnet_activation_floats": (L, [P]),
         "lf_erfnet_num_params": (I, [P]),
         "lf_erfnet_num_bn": (I, [P]),

@@ -38,7 +38,7 @@ struct LfTapArgs {
     const float* wp;        // packed weights [tap][Cs/4][Cd][4]
     int s16;                // 1: src / dst / mask_src / add_src / aux hold bf16 elements (needs wp16)
     const void* wp16;       // non-null selects the bf16 matrix-core kernel: packed bf16 weights [tap][ceil(Cs/32)*4][Cd][8]
-    int split;              // 9 or 6: fp32 on the bf16 matrix cores from 3-way split operands (tapgemm_split_kernel);
+    int split;              // 9: fp32 on the bf16 matrix cores from 3-way split operands, all nine partial products (tapgemm_split_kernel);
     const void* wp48;       //   its weights, split by the pack kernel: bf16 [tap][Cs/8][Cd][3][8]; launches the split
                             //   kernel cannot take (Cs % 32, Cd % 64) fall back to the fp32 matrix cores (wp)
     const float* bias;      // [Cd] or null
@@ -72,7 +72,7 @@ struct LfWgradArgs {
     const float* pro_sc;    // optional BN+ReLU recompute on x
     const float* pro_sh;
     int s16;                // 1: x and g hold bf16 elements (partials and bias rows stay fp32)
-    int split;              // 9 or 6: fp32 from 3-way split operands on the bf16 matrix cores (fp32 tensors, 64-channel blocks)
+    int split;              // (unused since round 6: the weight gradient of the split mode runs on the fp32 matrix cores)
     float* partial;         // [splits][ntaps][Cs][Cd]
     float* bias_partial;    // [bias_rows][Cd] or null
     unsigned long long* dbg = nullptr;   // tools/kbench.py --phases: 8 words per wave (start, first operands, loop done, end, HW id)
@@ -80,8 +80,7 @@ struct LfWgradArgs {
 // number of k-split rows the kernel will write for this geometry
 int lf_tapwgrad_splits(const LfTapGeom& g);          // upper bound over the kernels that take fp32 tensors
 int lf_tapwgrad_splits_bound(const LfTapGeom& g, int s16);   // ... by storage type: bf16 tensors add the read-once kernel's rows
-int lf_tapwgrad_bias_rows(const LfTapGeom& g);
-// rows the launch with these arguments writes (<= lf_tapwgrad_splits: the split-arithmetic kernel uses fewer, larger splits)
+// rows the launch with these arguments writes (bf16 tensors: the read-once kernel's row count)
 int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro);
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st);
 

@@ -17,13 +17,13 @@
 // Kernels in this file:
 //   tapgemm_kernel            fp32 matrix cores, operands streamed L2 -> VGPR: the 64- / 128-channel launches of the network
 //   tapgemm_lean_kernel       16-channel layers in fp32 (HBM-bound)
-//   tapgemm_split_kernel      precision modes fp32x9 / fp32x6: fp32 results from exact 3-way bf16 splits on the bf16 matrix cores
-//   tapgemm_bf16_kernel       precision modes bf16_mfma / bf16, operands streamed into registers (operand prologue, ragged widths)
+//   tapgemm_split_kernel      precision mode fp32x9: fp32 results from exact 3-way bf16 splits on the bf16 matrix cores
+//   tapgemm_bf16_kernel       precision mode bf16, operands streamed into registers (operand prologue, ragged widths)
 //   tapgemm_bf16_wl_kernel    bf16 tensors, the 3-tap convolutions at 64 / 128 channels: memory touched in whole 128-byte lines
 //                             (LDS-DMA operand ring, weights in registers, LDS-transposed stores)
 //   tapgemm_bf16_ring_kernel  bf16 tensors, every other tap table: persistent LDS-DMA ring
 //   tapgemm_bf16_lean_kernel  bf16 tensors, 16 -> 16 channels (two taps per K = 32 MFMA)
-//   tapwgrad_kernel / tapwgrad16_kernel / tapwgrad16_tr_kernel / tapwgrad_split_kernel   weight gradients, split-K over pixels
+//   tapwgrad_kernel / tapwgrad16_kernel / tapwgrad16_tr_kernel   weight gradients, split-K over pixels
 //   the split-K reductions (one per weight gradient, or batched per backward pass) and the weight-packing kernels.
 // The tap-GEMM kernels share one epilogue (LF_TAPGEMM_EPILOGUE: bias, ReLU, masks, residual, BN sums); the whole-line kernel has
 // its own (same arithmetic, output and operand tensors through LDS tiles).
@@ -117,6 +117,12 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+// lane 0 of every 16-lane DPP row broadcast to its row (row_share:0 / row_newbcast:0)
+__device__ __forceinline__ f32x4 bcast16(f32x4 v) {
+    f32x4 r;
+    r.x = dpp_mov<0x150>(v.x); r.y = dpp_mov<0x150>(v.y); r.z = dpp_mov<0x150>(v.z); r.w = dpp_mov<0x150>(v.w);
+    return r;
+}
 __device__ __forceinline__ float sum16(float v) {
     v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
@@ -129,6 +135,8 @@ __device__ __forceinline__ float sum16(float v) {
 #define LF_EPI_ONE_TILE false  /* tapgemm_kernel: true for the per-lane-row form of the three-tensor epilogue (one register short) */
 #define LF_EPI_TID threadIdx.x  /* tapgemm_kernel: its per-tile laundered copy */
 #define LF_EPI_ROW1 false      /* tapgemm_kernel: its ROW1 (a wave's 64 pixels in one image row) */
+#define LF_EPI_PIVOT true      /* BN forward sums about a pivot (below); the run-time-flag forms of the 128-register split kernel and of the LDS-ring \
+                                  kernels (cold paths: no network launch) have no registers for it and sum about 0 -- same row format */
 #define LF_TAPGEMM_EPILOGUE \
     /* Pixel-tile outer, channel-tile inner: the loads of one operand tensor issued back to back cover one pixel's     \
      * contiguous channel run, so every cache line is touched once while it is hot (the channel-tile-outer order        \
@@ -147,11 +155,18 @@ __device__ __forceinline__ float sum16(float v) {
                                  r_msk = make_rsrc(a.mask_src, 0xffffffffu), r_aux = make_rsrc(a.aux, 0xffffffffu), \
                                  r_bias = make_rsrc(a.bias, 0xffffffffu), r_msc = make_rsrc(a.msc, 0xffffffffu), \
                                  r_msh = make_rsrc(a.msh, 0xffffffffu), r_dm = make_rsrc(a.dm, 0xffffffffu); \
-    f32x4 s1[NT], s2[NT], bs[NOBIAS ? 1 : NT], hv[HOISTV ? NT : 1][2]; \
+    /* BatchNorm FORWARD statistics (STATS_SQ) are accumulated about a PIVOT: per channel the value of the wave's first pixel   \
+     * (lane 0 of the 16-lane row, broadcast by DPP): sum (v - piv), sum (v - piv)^2.  With |v - piv| ~ sigma neither sum loses the  \
+     * digits that sum v^2 loses when |mean| >> sigma -- E[v^2] - mean^2 from fp32 partials kept 2^-24 (mean / sigma)^2 of the    \
+     * variance: 2.3e-4 on a parameter gradient at 50 sigma, where nn.BatchNorm2d has no such term (round 6).  A wave turns its   \
+     * sums into (sum v, M2 = sum (v - mean_wave)^2) of its 64 pixels, the workgroup's four waves are merged with Chan's formula    \
+     * (differences of wave means, never squares of sums), and the partial row of a 256-pixel tile is [sum v][M2 about the tile's  \
+     * own mean]; the finalise kernel merges the tiles in fp64 (LfStatPart::tile_pix). */ \
+    f32x4 s1[NT], s2[NT], bs[NOBIAS ? 1 : NT], hv[HOISTV ? NT : 1][2], piv[LF_EPI_PIVOT ? NT : 1]; \
 _Pragma("unroll") \
     for (int n = 0; n < NT; ++n) { \
         const int co = cob + n * 16 + kq * 4; \
-        s1[n] = zero4(); s2[n] = zero4(); \
+        s1[n] = zero4(); s2[n] = zero4(); piv[LF_EPI_PIVOT ? n : 0] = zero4(); \
         if constexpr (!NOBIAS) bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4(); \
         if (HOISTV) { \
             if (HOISTM && (epi & LF_EPI_MASKBN)) { hv[n][0] = ldb4(r_msc, co * 4u, 0u); hv[n][1] = ldb4(r_msh, co * 4u, 0u); } \
@@ -184,7 +199,12 @@ _Pragma("unroll") \
             if (S16) v = round_bf16(v);   /* statistics are taken from the values as stored */ \
             if (pv[m]) epi_st<S16>(r_dst, dbase + n * 16, v); \
             if (!pv[m]) v = zero4(); \
-            if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; } \
+            if (epi & LF_EPI_STATS_SQ) { \
+                if (LF_EPI_PIVOT && m == 0) piv[LF_EPI_PIVOT ? n : 0] = bcast16(v); \
+                f32x4 dv = LF_EPI_PIVOT ? v - piv[LF_EPI_PIVOT ? n : 0] : v; \
+                if (!pv[m]) dv = zero4(); \
+                s1[n] += dv; s2[n] += dv * dv; \
+            } \
             if (epi & LF_EPI_STATS_XHAT) { \
                 const f32x4 gm = (a.dm && !LF_EPI_ROW1) ? v * ld[j] : v; \
                 s1[n] += gm; s2[n] += gm * lx[j];      /* RAW second sum: the finalise kernel applies x^ = t * rstd - mean * rstd in fp64 */ \
@@ -209,6 +229,14 @@ _Pragma("unroll") \
             f32x4 r1, r2; \
             r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w); \
             r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w); \
+            if (epi & LF_EPI_STATS_SQ) {      /* pivot sums -> (sum v, M2 about the wave's own mean) of the wave's nw valid pixels */ \
+                const unsigned lf_t0 = (bx * (unsigned)(WG_WAVES * LF_EPI_GROUPS) + (unsigned)wave) * 64u; \
+                const float nw = lf_t0 < npix ? (float)min(npix - lf_t0, 64u) : 0.f; \
+                const float rn = nw > 0.f ? 1.f / nw : 0.f; \
+                r2 = r2 - r1 * r1 * rn; \
+                r2.x = fmaxf(r2.x, 0.f); r2.y = fmaxf(r2.y, 0.f); r2.z = fmaxf(r2.z, 0.f); r2.w = fmaxf(r2.w, 0.f); \
+                if (LF_EPI_PIVOT) r1 = r1 + piv[LF_EPI_PIVOT ? n : 0] * nw; \
+            } \
             if (pl == 0) { \
                 float* d = sred[EG][EW][n][kq]; \
                 d[0] = r1.x; d[1] = r1.y; d[2] = r1.z; d[3] = r1.w; d[4] = r2.x; d[5] = r2.y; d[6] = r2.z; d[7] = r2.w; \
@@ -218,7 +246,22 @@ _Pragma("unroll") \
         if ((LF_EPI_TID & 255) < NT * 4 * 8) { \
             const int tg = LF_EPI_TID >> 8, tt = LF_EPI_TID & 255; \
             const int j = tt & 7, q = (tt >> 3) & 3, n = tt >> 5; \
-            const float v = sred[tg][0][n][q][j] + sred[tg][1][n][q][j] + sred[tg][2][n][q][j] + sred[tg][3][n][q][j]; \
+            float v = sred[tg][0][n][q][j] + sred[tg][1][n][q][j] + sred[tg][2][n][q][j] + sred[tg][3][n][q][j]; \
+            if ((epi & LF_EPI_STATS_SQ) && j >= 4) {      /* Chan: M2 = sum_w M2_w + sum_w n_w (mean_w - mean)^2 */ \
+                const unsigned lf_tb = (bx * (unsigned)LF_EPI_GROUPS + (unsigned)tg) * (unsigned)(WG_WAVES * 64); \
+                float nwv[4], sw[4], nt = 0.f, st = 0.f; \
+_Pragma("unroll") \
+                for (int w = 0; w < 4; ++w) { \
+                    const unsigned t0w = lf_tb + (unsigned)w * 64u; \
+                    nwv[w] = t0w < npix ? (float)min(npix - t0w, 64u) : 0.f; \
+                    sw[w] = sred[tg][w][n][q][j - 4]; \
+                    nt += nwv[w]; st += sw[w]; \
+                } \
+                const float mg = nt > 0.f ? st / nt : 0.f; \
+_Pragma("unroll") \
+                for (int w = 0; w < 4; ++w) \
+                    if (nwv[w] > 0.f) { const float dmw = sw[w] / nwv[w] - mg; v += nwv[w] * dmw * dmw; } \
+            } \
             const int co = cob + n * 16 + q * 4 + (j & 3); \
             a.stats[(((long)bx * LF_EPI_GROUPS + tg) * 2 + (j >> 2)) * g.Cd + co] = v; \
         } \
@@ -500,15 +543,16 @@ __global__ __launch_bounds__(256, (EPIC >= 0 || NT < 4) ? 2 : 1) void tapgemm_ke
 }
 
 // ---------------------------------------------------------------------------------------
-// bf16 matrix-core variant (precision mode "bf16": operands rounded to bf16 in registers, fp32 accumulate,
-// fp32 tensors in HBM).  v_mfma_f32_16x16x32_bf16: a lane supplies 8 consecutive k of its row / column
-// (k-block kq = l>>4 of the 32-channel step), C/D layout as the fp32 form -- so the tap table, the pixel
-// mapping and the whole epilogue are shared with tapgemm_kernel.  Per 32-channel step a lane loads 2 dwordx4
-// of its pixel (8 fp32 channels), applies the optional BN+ReLU prologue and the validity mask in fp32,
-// converts with v_cvt_pk_bf16_f32 (round to nearest even) and feeds 16 MFMAs (one per 16x16 tile).
-// Weights are pre-packed bf16 [tap][ceil(Cs/32)*4][Cd][8], zero-padded to whole 32-channel steps, so the
-// partial last step of a 16- or 48-channel contraction multiplies (valid, clamped) pixel data by zeros.
+// bf16 matrix-core kernel, operands streamed into registers (precision mode "bf16": bf16 tensors in HBM, fp32 accumulate; the
+// launches the LDS kernels below do not take: operand prologue, ragged widths, tap tables with few pixels).
+// v_mfma_f32_16x16x32_bf16: a lane supplies 8 consecutive k of its row / column (k-block kq = l>>4 of the 32-channel step), C/D
+// layout as the fp32 form -- so the tap table, the pixel mapping and the whole epilogue are shared with tapgemm_kernel.  Per
+// 32-channel step a lane loads ONE dwordx4 of its pixel (8 bf16 channels: the operand as it is), or, with the BN+ReLU prologue,
+// widens it, applies the prologue and the validity mask in fp32 and converts back with v_cvt_pk_bf16_f32 (round to nearest even);
+// 16 MFMAs (one per 16x16 tile) per step.  Weights are pre-packed bf16 [tap][ceil(Cs/32)*4][Cd][8], zero-padded to whole
+// 32-channel steps, so the partial last step of a 16- or 48-channel contraction multiplies (valid, clamped) pixel data by zeros.
 // At the bf16 rate (16 cycles per MFMA) the loop is bound by the operand path, not by the matrix cores.
+// (Through round 5 the kernel also took fp32 tensors -- precision mode "bf16_mfma": removed, no BASELINE configuration used it.)
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -523,11 +567,11 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(f32x4 lo, f32x4 hi) {
 // EPIC >= 0: epilogue flags compiled in (as in tapgemm_kernel).  FAST (no prologue, whole 32-channel steps): a padding position
 // holds the out-of-range offset and reads as zero bits, the channel step is a scalar offset -- no per-step VALU work at all on
 // bf16 tensors, where the 16 MFMAs of a step take 256 cycles and every VALU instruction beside them ~13.
-template <int NT, int PROC, bool S16, int EPIC = -1, bool FAST = false>
+template <int NT, int PROC, int EPIC = -1, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     static_assert(!FAST || PROC == 0, "FAST: the out-of-range zero must be the operand itself");
     const int epi = EPIC >= 0 ? EPIC : epi_rt;
-    constexpr bool HOISTV = true;
+    constexpr bool HOISTV = true, S16 = true;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl);
@@ -554,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = zero4();
 
-    // S16: the source holds bf16 -> one dwordx4 per tile is the whole 8-channel operand (xl used as raw bits)
-    struct Step { u32x4 w[NT]; f32x4 xl[MT], xh[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
+    // one dwordx4 per tile is the whole 8-channel operand (xl holds raw bf16 bits)
+    struct Step { u32x4 w[NT]; f32x4 xl[MT]; f32x4 sc0, sc1, sh0, sh1; unsigned ok; };
     __shared__ uint4 tab_off[WG_WAVES][LF_MAX_TAPS][64];
     __shared__ unsigned tab_ok[WG_WAVES][LF_MAX_TAPS][64];
     for (int t = 0; t < g.ntaps; ++t) {
@@ -567,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
             const bool in = pv[m] && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
             const int syc = min(max(sy, 0), g.Hs - 1), sxc = min(max(sx, 0), g.Ws - 1);
             o[m] = (unsigned)(((pn[m] * g.Hs + syc) * g.Ws + sxc) * g.s_pix + g.s_choff);
-            if constexpr (FAST) o[m] = in ? (o[m] + kq * 8) * (S16 ? 2u : 4u) : LF_OOB;      // bytes, this lane's 8 channels
+            if constexpr (FAST) o[m] = in ? (o[m] + kq * 8) * 2u : LF_OOB;      // bytes, this lane's 8 channels
             okb |= (in ? 1u : 0u) << m;
         }
         tab_off[wave][t][lane] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -576,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
     const int ncb = (g.Cs + 31) >> 5;                       // 32-channel steps per tap
     const int nsteps = g.ntaps * ncb;
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp16, 0xffffffffu),
-                                 rx = make_rsrc(a.src, FAST ? (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * (S16 ? 2 : 4), (long)LF_OOB) : 0xffffffffu),
+                                 rx = make_rsrc(a.src, FAST ? (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB) : 0xffffffffu),
                                  rsc = make_rsrc(a.pro_sc, 0xffffffffu), rsh = make_rsrc(a.pro_sh, 0xffffffffu);
     const unsigned wlane = (unsigned)(kq * g.Cd + cob + pl) * 16u;      // bytes (8 bf16 per lane and tile)
     const int wstep = g.Cd * 32;                            // bf16 elements per 32-channel step
@@ -593,27 +637,14 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
         const int c8 = min(cb_ld * 32 + kq * 8, g.Cs - 8);  // a partial last step re-reads valid channels (weights are 0)
         if constexpr (FAST) {
             const unsigned dead = live ? 0u : LF_OOB;        // a dead step (odd step count) reads zeros
-            const unsigned cs = (unsigned)cb_ld * (S16 ? 64u : 128u);
-            if constexpr (S16) {
-                S.xl[0] = ldb4(rx, o.x | dead, cs); S.xl[1] = ldb4(rx, o.y | dead, cs);
-                S.xl[2] = ldb4(rx, o.z | dead, cs); S.xl[3] = ldb4(rx, o.w | dead, cs);
-            } else {
-                S.xl[0] = ldb4(rx, o.x | dead, cs); S.xh[0] = ldb4(rx, (o.x | dead) + 16u, cs);
-                S.xl[1] = ldb4(rx, o.y | dead, cs); S.xh[1] = ldb4(rx, (o.y | dead) + 16u, cs);
-                S.xl[2] = ldb4(rx, o.z | dead, cs); S.xh[2] = ldb4(rx, (o.z | dead) + 16u, cs);
-                S.xl[3] = ldb4(rx, o.w | dead, cs); S.xh[3] = ldb4(rx, (o.w | dead) + 16u, cs);
-            }
-        } else
-        if constexpr (S16) {                                 // buffer-addressed (see ldb4): bf16 elements, 16 bytes = 8 channels
+            const unsigned cs = (unsigned)cb_ld * 64u;
+            S.xl[0] = ldb4(rx, o.x | dead, cs); S.xl[1] = ldb4(rx, o.y | dead, cs);
+            S.xl[2] = ldb4(rx, o.z | dead, cs); S.xl[3] = ldb4(rx, o.w | dead, cs);
+        } else {                                             // buffer-addressed (see ldb4): bf16 elements, 16 bytes = 8 channels
             S.xl[0] = ldb4(rx, (o.x + c8) * 2u, 0u);
             S.xl[1] = ldb4(rx, (o.y + c8) * 2u, 0u);
             S.xl[2] = ldb4(rx, (o.z + c8) * 2u, 0u);
             S.xl[3] = ldb4(rx, (o.w + c8) * 2u, 0u);
-        } else {
-            S.xl[0] = ldb4(rx, (o.x + c8) * 4u, 0u); S.xh[0] = ldb4(rx, (o.x + c8) * 4u + 16u, 0u);
-            S.xl[1] = ldb4(rx, (o.y + c8) * 4u, 0u); S.xh[1] = ldb4(rx, (o.y + c8) * 4u + 16u, 0u);
-            S.xl[2] = ldb4(rx, (o.z + c8) * 4u, 0u); S.xh[2] = ldb4(rx, (o.z + c8) * 4u + 16u, 0u);
-            S.xl[3] = ldb4(rx, (o.w + c8) * 4u, 0u); S.xh[3] = ldb4(rx, (o.w + c8) * 4u + 16u, 0u);
         }
         if constexpr (PROC == LF_PRO_BNRELU) {
             S.sc0 = ldb4(rsc, c8 * 4u, 0u); S.sc1 = ldb4(rsc, c8 * 4u + 16u, 0u);
@@ -631,21 +662,19 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const bool in = FAST || ((S.ok >> m) & 1u);
-            if constexpr (S16 && PROC != LF_PRO_BNRELU) {       // raw bf16 bits: mask and use as they are
+            if constexpr (PROC != LF_PRO_BNRELU) {       // raw bf16 bits: mask and use as they are
                 u32x4 r = __builtin_bit_cast(u32x4, S.xl[m]);
                 r.x = in ? r.x : 0u; r.y = in ? r.y : 0u; r.z = in ? r.z : 0u; r.w = in ? r.w : 0u;
                 xb[m] = __builtin_bit_cast(bf16x8, r);
                 continue;
             }
             f32x4 lo, hi;
-            if constexpr (S16) {
+            {
                 const u32x4 r = __builtin_bit_cast(u32x4, S.xl[m]);
                 lo.x = __uint_as_float(r.x << 16); lo.y = __uint_as_float(r.x & 0xffff0000u);
                 lo.z = __uint_as_float(r.y << 16); lo.w = __uint_as_float(r.y & 0xffff0000u);
                 hi.x = __uint_as_float(r.z << 16); hi.y = __uint_as_float(r.z & 0xffff0000u);
                 hi.z = __uint_as_float(r.w << 16); hi.w = __uint_as_float(r.w & 0xffff0000u);
-            } else {
-                lo = S.xl[m]; hi = S.xh[m];
             }
             if constexpr (PROC == LF_PRO_BNRELU) { lo = max0(lo * S.sc0 + S.sh0); hi = max0(hi * S.sc1 + S.sh1); }
             lo.x = in ? lo.x : 0.f; lo.y = in ? lo.y : 0.f; lo.z = in ? lo.z : 0.f; lo.w = in ? lo.w : 0.f;
@@ -670,7 +699,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_kernel(const LfTapGeom g,
         issue(A);
         mma(B);
     }
+#undef LF_EPI_PIVOT
+#define LF_EPI_PIVOT (EPIC >= 0 || NT < 4)      /* (the 64-channel-slab run-time-flag forms have no registers for the pivot: 282-810 spilled) */
     LF_TAPGEMM_EPILOGUE
+#undef LF_EPI_PIVOT
+#define LF_EPI_PIVOT true
 }
 
 // ---------------------------------------------------------------------------------------
@@ -882,7 +915,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_ring_kernel(const LfTapGe
             for (int m = 0; m < MT; ++m) { pn[m] = G.n[m]; pi[m] = G.i[m]; pj[m] = G.j[m] + pl; pv[m] = G.ok[m]; }
         }
         const int cob = (int)(it & (unsigned)slsh) * 64;
+#undef LF_EPI_PIVOT
+#define LF_EPI_PIVOT (EPIC >= 0)
         LF_TAPGEMM_EPILOGUE
+#undef LF_EPI_PIVOT
+#define LF_EPI_PIVOT true
         __builtin_amdgcn_s_setprio(0);
         if constexpr (DBG) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1082,9 +1119,10 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
     const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0;
     int st_c = 0;
     for (unsigned bx = it_first; bx < it_end; bx += it_stride) {
-        f32x4 s1[NT], s2[NT];
+        constexpr bool PIVOT = EPIC >= 0;    // the pivot of the BN forward sums (see LF_TAPGEMM_EPILOGUE); the run-time-flag form sums about 0
+        f32x4 s1[NT], s2[NT], piv[PIVOT ? NT : 1];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) { s1[n] = zero4(); s2[n] = zero4(); }
+        for (int n = 0; n < NT; ++n) { s1[n] = zero4(); s2[n] = zero4(); piv[PIVOT ? n : 0] = zero4(); }
         for (int sub = 0; sub < 4; ++sub) {
             f32x4 acc[NT][MT];
 #pragma unroll
@@ -1206,7 +1244,12 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
                     if (stats) {
                         v.x = (float)b[0]; v.y = (float)b[1]; v.z = (float)b[2]; v.w = (float)b[3];     // statistics of the values as stored
                         if (!G.ok[m]) v = zero4();
-                        if (epi & LF_EPI_STATS_SQ) { s1[n] += v; s2[n] += v * v; }
+                        if (epi & LF_EPI_STATS_SQ) {
+                            if (PIVOT && sub == 0 && m == 0) piv[PIVOT ? n : 0] = bcast16(v);      // the item's first pixel (this wave owns all 256 of its channels)
+                            f32x4 dv = PIVOT ? v - piv[PIVOT ? n : 0] : v;
+                            if (!G.ok[m]) dv = zero4();
+                            s1[n] += dv; s2[n] += dv * dv;
+                        }
                         if (epi & LF_EPI_STATS_XHAT) {
                             const f32x4 gm = a.dm ? v * ld[n] : v;
                             s1[n] += gm; s2[n] += gm * lx[n];
@@ -1242,12 +1285,365 @@ __global__ __launch_bounds__(256, 2) void tapgemm_bf16_wl_kernel(const LfTapGeom
                 f32x4 r1, r2;
                 r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w);
                 r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w);
+                if (epi & LF_EPI_STATS_SQ) {      // pivot sums -> (sum v, M2 about the item's own mean) of the item's valid pixels
+                    const unsigned t0 = bx * (unsigned)PIX_PER_WG;
+                    const float ni = t0 < npix ? (float)min(npix - t0, (unsigned)PIX_PER_WG) : 0.f;
+                    const float rn = ni > 0.f ? 1.f / ni : 0.f;
+                    r2 = r2 - r1 * r1 * rn;
+                    r2.x = fmaxf(r2.x, 0.f); r2.y = fmaxf(r2.y, 0.f); r2.z = fmaxf(r2.z, 0.f); r2.w = fmaxf(r2.w, 0.f);
+                    if (PIVOT) r1 = r1 + piv[PIVOT ? n : 0] * ni;
+                }
                 if (pl == 0) {
                     float* d = a.stats + ((long)bx * 2) * g.Cd + cobw + n * 16 + kq * 4;
                     *reinterpret_cast<f32x4*>(d) = r1;
                     *reinterpret_cast<f32x4*>(d + g.Cd) = r2;
                 }
             }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing (dead) steps: nothing may land in LDS after this
+    __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------
+// tapgemm_bf16_wv_kernel ("wave-private", round 6): the 3-tap bf16 convolutions of non_bottleneck_1d at 64 channels.
+//
+// At 64 channels the whole-line kernel above shares a 64-pixel sub-tile between its four waves (each owns 16 output channels):
+// 24 MFMAs per wave between five workgroup barriers, and the launch sits at 4.0 TB/s of tensor bytes where the same kernel at 128
+// channels has twice the work per barrier.  But at 64 channels ALL the weights of the convolution are 3 taps x 64 x 64 x 2 B =
+// 24 KB = 96 registers per lane -- what a wave of the 128-channel form holds for its quarter of the output channels.  So here a
+// wave owns its pixels AND every output channel: wave tile = 32 pixels x 64 channels (8 accumulator tiles), the weights live in
+// its registers for the workgroup's life, its operands arrive by LDS-DMA in a PRIVATE ring (stage = one tap of its 32 pixels = 4 KB,
+// 4 instructions of 8 pixels x 128 B: whole lines), its output leaves through a private 4 KB tile as whole-line stores -- and no
+// instruction of the K loop or the epilogue waits for another wave: the only barriers are the two that merge the four waves'
+// BatchNorm partial sums into the 256-pixel statistics row, in the launches that take statistics.
+//   ring order (per wave):   s_waitcnt vmcnt(N) lgkmcnt(0)      my DMA of this step has landed; my fragment reads of the step before
+//                                                               have retired (their stage is restaged next)
+//                            issue the step R - 1 ahead; read fragments; 16 MFMAs
+// N counts the vector-memory instructions YOUNGER than the awaited DMA: 4 (R - 2) ring instructions, the item's staging
+// instructions behind its first step, and -- vmcnt retires loads AND stores in issue order on gfx9-family hardware -- the four
+// whole-line stores of the previous item's epilogue in front of an item's first step (all four are always issued: a group beyond
+// the tensor stores to the out-of-range offset, which the buffer unit drops).
+// Work: a workgroup walks 256-pixel tiles (the statistics rows of the other kernels) inside its XCD's range; wave w takes pixels
+// w*64 .. w*64+63 of the tile as two items of 32.  K order = tapgemm_bf16_kernel's (tap, then channel): results bit-identical.
+// Measured on one box (tools/bf16_ab.py, config 3's 64 x 80 x 160 x 64 launches, whole-line kernel -> this one): forward 52.1 -> 41.6 us,
+// data gradient + mask 65.0 -> 60.3 / 66.7 -> 58.1.  The BN+ReLU operand prologue (the block's third convolution) was built here
+// too -- the wave transforming the stage it brought in, in place, behind its own vmcnt wait -- and is SLOWER than the streaming
+// kernel's register form (102.9 vs 88.3 us: the transform sits between the wave's DMA wait and its fragment reads, three times per
+// pixel, with one partner wave to hide it): removed, those launches stay on tapgemm_bf16_kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int WV_PX = 32, WV_STAGE = WV_PX * 128;
+template <int EPIC> struct WvCfg {
+    static constexpr bool ST_ADD = EPIC >= 0 && (EPIC & LF_EPI_ADD) != 0, ST_MSK = EPIC >= 0 && (EPIC & LF_EPI_MASK) != 0,
+                          ST_AUX = EPIC >= 0 && (EPIC & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) != 0;
+    static constexpr int NBUF = (ST_MSK ? 1 : 0) + (ST_AUX ? 1 : 0);                  // tiles beside the output tile
+    static constexpr int R = NBUF == 1 ? 3 : 4;                                       // ring stages (one extra tile: 3 keeps two workgroups per CU)
+    static constexpr int NAUXI = ((ST_ADD ? 1 : 0) + NBUF) * 4;                       // staging instructions per item
+    static constexpr int WAVE_LDS = (R + 1 + NBUF) * WV_STAGE;
+    static constexpr size_t LDS = (size_t)WG_WAVES * WAVE_LDS;
+};
+
+// (two workgroups per CU by LDS except with two staged operand tiles or run-time flags: those get the whole register file)
+template <int EPIC>
+__global__ __launch_bounds__(256, (EPIC >= 0 && WvCfg<EPIC>::NBUF < 2) ? 2 : 1) void tapgemm_bf16_wv_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
+    typedef WvCfg<EPIC> C;
+    constexpr int NT = 4, MW = 2, R = C::R, CD = 64;
+    constexpr bool S16 = true;
+    const int epi = EPIC >= 0 ? EPIC : epi_rt;
+    constexpr bool NOBIAS = EPIC >= 0 && (EPIC & (LF_EPI_MASK | LF_EPI_ADD | LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) != 0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pl = lane & 15, kq = lane >> 4;
+    const unsigned npix = (unsigned)(g.N * g.Hl * g.Wl), ngroups = npix >> 4, GR = (unsigned)g.Wl >> 4;
+    const unsigned ntiles = (npix + PIX_PER_WG - 1) / PIX_PER_WG;
+    unsigned it_first = blockIdx.x, it_stride = gridDim.x, it_end = ntiles;
+    if ((gridDim.x & 7u) == 0 && (ntiles & 7u) == 0) {
+        const unsigned per = ntiles >> 3;
+        it_first = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); it_stride = gridDim.x >> 3; it_end = (blockIdx.x & 7u) * per + per;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lf_tap_lds + (unsigned)(wave * C::WAVE_LDS);
+    unsigned char* const ring = lf_tap_lds + wave * C::WAVE_LDS;
+    unsigned char* const otile = ring + R * WV_STAGE;
+    unsigned char* const mtile = otile + WV_STAGE;                                     // mask source (when staged)
+    unsigned char* const xtile = otile + WV_STAGE * (C::ST_MSK ? 2 : 1);              // BN-backward operand (when staged)
+
+    // ---- all the weights -> registers: [tap][32-channel k-block][16-channel output tile], the MFMA A operand
+    bf16x8 wr[3][2][NT];
+    {
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wp16, 0xffffffffu);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    wr[t][kb][n] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        rw, (int)((((t * 2 + kb) * 4 + kq) * CD + n * 16 + pl) * 16), 0, 0));
+    }
+    int tapv = 0;            // tap t's offsets in lane t (v_readlane: see tapgemm_bf16_wl_kernel)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (lane == t) tapv = (g.tdh[t] & 0xffff) | (g.tdw[t] << 16);
+    const i32x4s rx = make_rsrc_words(a.src, (unsigned)min((long)g.N * g.Hs * g.Ws * g.s_pix * 2, (long)LF_OOB));
+    const int spix2 = g.s_pix * 2;
+    // DMA mapping: instruction q of a step carries pixels q*8 .. q*8+7 of the item (group q >> 1): lane -> pixel q*8 + (lane >> 3),
+    // LDS slot lane & 7 = chunk XOR ((pixel >> 1) & 7) -- which depends on q & 1 only
+    const int dpx = lane >> 3;
+    unsigned lane_x[2];
+    int lane_dx[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int chunk = (lane & 7) ^ ((jj * 4 + (lane >> 4)) & 7);
+        lane_x[jj] = (unsigned)(((jj * 8 + dpx) * g.s_pix + g.s_choff) * 2 + chunk * 16);
+        lane_dx[jj] = jj * 8 + dpx;
+    }
+    // the two 16-pixel groups of item (tile, h) of this wave: (image, row, first column), wave-uniform
+    struct Item { int n[2], i[2], j[2]; bool ok[2]; };
+    auto item_at = [&](unsigned tile, int h, Item& o) __attribute__((always_inline)) {
+        const unsigned G0 = tile * 16u + (unsigned)(wave * 4 + h * 2);
+        const unsigned Gc = G0 < ngroups ? G0 : 0u;
+        const unsigned Rw = Gc / GR;
+        int jg = __builtin_amdgcn_readfirstlane((int)(Gc - Rw * GR));
+        int n = __builtin_amdgcn_readfirstlane((int)(Rw / (unsigned)g.Hl));
+        int i = __builtin_amdgcn_readfirstlane((int)Rw) - n * g.Hl;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            o.ok[q] = G0 + q < ngroups;
+            o.n[q] = n; o.i[q] = i; o.j[q] = jg * 16;
+            if (++jg == (int)GR) { jg = 0; if (++i == g.Hl) { i = 0; ++n; } }
+        }
+    };
+    // ---- load cursor (wave-uniform): tile, half, tap, ring stage; its item's groups as (pixel index without the tap, row, column)
+    unsigned tile_ld = it_first;
+    int h_ld = 0, t_ld = 0, st_ld = 0;
+    int lrow[2] = {0, 0}, liy[2] = {0, 0}, lsx[2] = {0, 0};
+    bool lok[2] = {false, false};
+    auto cursor_item = [&]() __attribute__((always_inline)) {
+        lok[0] = false; lok[1] = false;
+        if (tile_ld < it_end) {
+            Item I;
+            item_at(tile_ld, h_ld, I);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { lok[q] = I.ok[q]; liy[q] = I.i[q]; lsx[q] = I.j[q]; lrow[q] = (I.n[q] * g.Hs + I.i[q]) * g.Ws + I.j[q]; }
+        }
+    };
+    cursor_item();
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int tv = __builtin_amdgcn_readlane(tapv, t_ld);
+        const int dh = (int)(short)(tv & 0xffff), dw = tv >> 16;
+        const unsigned dst = lds0 + (unsigned)(st_ld * WV_STAGE);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gq = q >> 1, jj = q & 1;
+            const int sy = liy[gq] + dh;
+            const bool yok = lok[gq] && sy >= 0 && sy < g.Hs;
+            const unsigned base = (unsigned)((lrow[gq] + dh * g.Ws + dw) * spix2);
+            const bool in = yok && (unsigned)(lsx[gq] + dw + lane_dx[jj]) < (unsigned)g.Ws;
+            lds_dma16(rx, dst + (unsigned)q * 1024u, in ? base + lane_x[jj] : LF_OOB, 0u);
+        }
+        st_ld = st_ld == R - 1 ? 0 : st_ld + 1;
+        if (++t_ld == 3) {
+            t_ld = 0;
+            if (++h_ld == 2) { h_ld = 0; tile_ld += it_stride; }
+            cursor_item();
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) issue();
+
+    // ---- staging of the epilogue's operand tensors (whole lines, the output tile's layout): instruction ii = pixels ii*8 .. +7 of
+    // the item: lane -> pixel p = ii*8 + (lane >> 3), 16-byte slot lane & 7 = chunk XOR (p & 7)
+    const unsigned dbytes = (unsigned)min((long)g.N * g.Hd * g.Wd * g.d_pix * 2, (long)LF_OOB);
+    const i32x4s ra_add = make_rsrc_words(a.add_src, dbytes), ra_msk = make_rsrc_words(a.mask_src, dbytes), ra_aux = make_rsrc_words(a.aux, dbytes);
+    auto tile_lane_off = [&](int ii) __attribute__((always_inline)) {          // byte offset of this lane's chunk inside its group's 16 pixels
+        const int p = ii * 8 + (lane >> 3);
+        return (unsigned)((((p & 15) * g.d_pix + g.d_choff) * 2) + (((lane & 7) ^ p) & 7) * 16);
+    };
+    auto stage_tensors = [&](const Item& I) __attribute__((always_inline)) {
+        if constexpr (C::NAUXI > 0) {
+            const unsigned dst0 = lds0 + (unsigned)(R * WV_STAGE);
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int gq = ii >> 1;
+                const unsigned base = (unsigned)(((I.n[gq] * g.Hd + I.i[gq]) * g.Wd + I.j[gq]) * g.d_pix * 2);
+                const unsigned vo = I.ok[gq] ? base + tile_lane_off(ii) : LF_OOB;      // (a group beyond the tensor: zeros)
+                if constexpr (C::ST_ADD) lds_dma16(ra_add, dst0 + (unsigned)(ii * 1024), vo, 0u);
+                if constexpr (C::ST_MSK) lds_dma16(ra_msk, dst0 + (unsigned)(WV_STAGE + ii * 1024), vo, 0u);
+                if constexpr (C::ST_AUX) lds_dma16(ra_aux, dst0 + (unsigned)(WV_STAGE * (C::ST_MSK ? 2 : 1) + ii * 1024), vo, 0u);
+            }
+        }
+    };
+
+    // epilogue constants (destination bounded by the tensor: the store of a group beyond it goes to the out-of-range offset and is dropped)
+    const __amdgpu_buffer_rsrc_t r_dst = make_rsrc(a.dst, dbytes), r_add = make_rsrc(a.add_src, 0xffffffffu),
+                                 r_msk = make_rsrc(a.mask_src, 0xffffffffu), r_aux = make_rsrc(a.aux, 0xffffffffu),
+                                 r_bias = make_rsrc(a.bias, 0xffffffffu), r_msc = make_rsrc(a.msc, 0xffffffffu),
+                                 r_msh = make_rsrc(a.msh, 0xffffffffu), r_dm = make_rsrc(a.dm, 0xffffffffu);
+    // fragment read addresses inside a stage: pixel m*16 + pl (128 B rows), chunk kb*4 + kq XOR (pl >> 1) & 7
+    const unsigned xf0 = (unsigned)(pl * 128 + (((0 + kq) ^ (pl >> 1)) & 7) * 16), xf1 = (unsigned)(pl * 128 + (((4 + kq) ^ (pl >> 1)) & 7) * 16);
+    const bool stats = (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) != 0;
+    int st_c = 0;
+    bool first_item = true;          // no stores in flight in front of the very first step
+    for (unsigned bx = it_first; bx < it_end; bx += it_stride) {
+        constexpr bool PIVOT = EPIC >= 0;    // the pivot of the BN forward sums (see LF_TAPGEMM_EPILOGUE); the run-time-flag form sums about 0
+        f32x4 s1[NT], s2[NT], piv[PIVOT ? NT : 1];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { s1[n] = zero4(); s2[n] = zero4(); piv[PIVOT ? n : 0] = zero4(); }
+        for (int h = 0; h < 2; ++h) {
+            f32x4 acc[NT][MW];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MW; ++m) acc[n][m] = zero4();
+            Item I;
+            item_at(bx, h, I);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                // my DMA of this step has landed; my fragment reads of the step before have retired (header: what N counts)
+                if (t == 0) {
+                    if (first_item) wait_vm_lgkm0<4 * (R - 2)>();
+                    else wait_vm_lgkm0<4 * (R - 2) + 4>();
+                } else wait_vm_lgkm0<4 * (R - 2) + C::NAUXI>();
+                issue();                             // R - 1 steps ahead -> the stage the previous step occupied
+                if (t == 0) stage_tensors(I);
+                const unsigned char* st = ring + st_c * WV_STAGE;
+                st_c = st_c == R - 1 ? 0 : st_c + 1;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8 xb[MW];
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(st + (kb ? xf1 : xf0) + m * 2048);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int m = 0; m < MW; ++m)
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t][kb][n], xb[m], acc[n][m], 0, 0, 0);
+                }
+            }
+            first_item = false;
+            // ---- epilogue of the item: accumulator tile (n, m) = channels n*16 + kq*4 .. +3 of pixel m*16 + pl
+            if constexpr (C::NAUXI > 0) wait_vm_lgkm0<8>();      // the staged tensors have landed (the two ring steps issued since are younger)
+            constexpr bool HOISTM = !(EPIC >= 0 && (EPIC & LF_EPI_MASKBN) != 0 && (EPIC & LF_EPI_STATS_XHAT) != 0);
+            f32x4 bs[NOBIAS ? 1 : NT], hsc[HOISTM ? NT : 1], hsh[HOISTM ? NT : 1];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const unsigned co = (unsigned)(n * 16 + kq * 4);
+                if constexpr (!NOBIAS) bs[n] = a.bias ? ldb4(r_bias, co * 4u, 0u) : zero4();
+                if constexpr (HOISTM) { if (epi & LF_EPI_MASKBN) { hsc[n] = ldb4(r_msc, co * 4u, 0u); hsh[n] = ldb4(r_msh, co * 4u, 0u); } }
+            }
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const unsigned dbase = (unsigned)(((I.n[m] * g.Hd + I.i[m]) * g.Wd + I.j[m] + pl) * g.d_pix + g.d_choff + kq * 4);
+                auto tile_ld = [&](const unsigned char* tile, int n) __attribute__((always_inline)) {      // this lane's 4 channels of (m, n)
+                    const int p = m * 16 + pl, chunk = (n * 16 + kq * 4) >> 3;
+                    const uint2 q = *reinterpret_cast<const uint2*>(tile + p * 128 + ((chunk ^ p) & 7) * 16 + (kq & 1) * 8);
+                    f32x4 v;
+                    v.x = __uint_as_float(q.x << 16); v.y = __uint_as_float(q.x & 0xffff0000u);
+                    v.z = __uint_as_float(q.y << 16); v.w = __uint_as_float(q.y & 0xffff0000u);
+                    return v;
+                };
+                // (two channel tiles at a time: with all four tiles' operands live beside the 96 weight registers the three-operand
+                // epilogues spilled 10-31 registers)
+#pragma unroll
+                for (int n0 = 0; n0 < NT; n0 += 2) {
+                f32x4 la[NT], lm[NT], lx[NT];
+#pragma unroll
+                for (int n = n0; n < n0 + 2; ++n) {
+                    if (epi & LF_EPI_ADD) la[n] = C::ST_ADD ? tile_ld(otile, n) : epi_ld<S16>(r_add, dbase + n * 16);
+                    if (epi & LF_EPI_MASK) lm[n] = C::ST_MSK ? tile_ld(mtile, n) : epi_ld<S16>(r_msk, dbase + n * 16);
+                    if (epi & (LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) lx[n] = C::ST_AUX ? tile_ld(xtile, n) : epi_ld<S16>(r_aux, dbase + n * 16);
+                }
+#pragma unroll
+                for (int n = n0; n < n0 + 2; ++n) {
+                    f32x4 v = acc[n][m];
+                    if constexpr (!NOBIAS) v += bs[n];
+                    if (epi & LF_EPI_ADD) v += la[n];
+                    if (epi & LF_EPI_MASK) v = keep_pos(v, lm[n]);
+                    if (epi & LF_EPI_MASKBN) {
+                        const unsigned co = (unsigned)(n * 16 + kq * 4);
+                        v = keep_pos(v, lx[n] * (HOISTM ? hsc[HOISTM ? n : 0] : ldb4(r_msc, co * 4u, 0u)) + (HOISTM ? hsh[HOISTM ? n : 0] : ldb4(r_msh, co * 4u, 0u)));
+                    }
+                    if (epi & LF_EPI_RELU) v = max0(v);
+                    lf_bf16x4 b;
+                    b[0] = (lf_bf16)v.x; b[1] = (lf_bf16)v.y; b[2] = (lf_bf16)v.z; b[3] = (lf_bf16)v.w;
+                    // output tile: pixel p = m*16 + pl, 16-byte chunk (channel / 8) XOR p, half kq & 1
+                    const int p = m * 16 + pl, chunk = (n * 16 + kq * 4) >> 3;
+                    *reinterpret_cast<lf_bf16x4*>(otile + p * 128 + ((chunk ^ p) & 7) * 16 + (kq & 1) * 8) = b;
+                    if (stats) {
+                        v.x = (float)b[0]; v.y = (float)b[1]; v.z = (float)b[2]; v.w = (float)b[3];     // statistics of the values as stored
+                        if (!I.ok[m]) v = zero4();
+                        if (epi & LF_EPI_STATS_SQ) {
+                            if (PIVOT && h == 0 && m == 0) piv[PIVOT ? n : 0] = bcast16(v);      // this wave's first pixel of the tile
+                            f32x4 dv = PIVOT ? v - piv[PIVOT ? n : 0] : v;
+                            if (!I.ok[m]) dv = zero4();
+                            s1[n] += dv; s2[n] += dv * dv;
+                        }
+                        if (epi & LF_EPI_STATS_XHAT) {
+                            // (the Dropout2d factor of (image, channel): an L1-resident vector, read where it is used instead of held)
+                            const f32x4 gm = a.dm ? v * ldb4(r_dm, (unsigned)(I.n[m] * g.Cd + n * 16 + kq * 4) * 4u, 0u) : v;
+                            s1[n] += gm; s2[n] += gm * lx[n];
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one chunk's operands at a time
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my quads are in the output tile
+            // whole-line stores: instruction ii = pixels ii*8 .. +7 of the item (all four always issued: header)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int gq = ii >> 1;
+                const u32x4v v = *reinterpret_cast<const u32x4v*>(otile + ii * 1024 + lane * 16);
+                const unsigned base = (unsigned)(((I.n[gq] * g.Hd + I.i[gq]) * g.Wd + I.j[gq]) * g.d_pix * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(v, r_dst, (int)(I.ok[gq] ? base + tile_lane_off(ii) : LF_OOB), 0, 0);
+            }
+            // (the next item's first wait carries lgkmcnt(0): these reads of the output tile retire before its next writes)
+        }
+        if (stats) {
+            // the four waves' sums of this 256-pixel tile -> one partial row (the merge of LF_TAPGEMM_EPILOGUE); staging area = the
+            // first 512 bytes of every wave's output tile (free: its stores read it above, the next item writes it 3 steps from now)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float (*sred)[4][8] = reinterpret_cast<float (*)[4][8]>(otile);           // [n][kq][8]
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x4 r1, r2;
+                r1.x = sum16(s1[n].x); r1.y = sum16(s1[n].y); r1.z = sum16(s1[n].z); r1.w = sum16(s1[n].w);
+                r2.x = sum16(s2[n].x); r2.y = sum16(s2[n].y); r2.z = sum16(s2[n].z); r2.w = sum16(s2[n].w);
+                if (epi & LF_EPI_STATS_SQ) {      // pivot sums -> (sum v, M2 about the wave's own mean) of the wave's nw valid pixels
+                    const unsigned t0 = (bx * (unsigned)WG_WAVES + (unsigned)wave) * 64u;
+                    const float nw = t0 < npix ? (float)min(npix - t0, 64u) : 0.f;
+                    const float rn = nw > 0.f ? 1.f / nw : 0.f;
+                    r2 = r2 - r1 * r1 * rn;
+                    r2.x = fmaxf(r2.x, 0.f); r2.y = fmaxf(r2.y, 0.f); r2.z = fmaxf(r2.z, 0.f); r2.w = fmaxf(r2.w, 0.f);
+                    if (PIVOT) r1 = r1 + piv[PIVOT ? n : 0] * nw;
+                }
+                if (pl == 0) {
+                    float* d = sred[n][kq];
+                    d[0] = r1.x; d[1] = r1.y; d[2] = r1.z; d[3] = r1.w; d[4] = r2.x; d[5] = r2.y; d[6] = r2.z; d[7] = r2.w;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < NT * 4 * 8) {
+                const int tt = threadIdx.x;
+                const int j = tt & 7, q = (tt >> 3) & 3, n = tt >> 5;
+                auto at = [&](int w, int jj) { return reinterpret_cast<const float (*)[4][8]>(lf_tap_lds + w * C::WAVE_LDS + R * WV_STAGE)[n][q][jj]; };
+                float v = at(0, j) + at(1, j) + at(2, j) + at(3, j);
+                if ((epi & LF_EPI_STATS_SQ) && j >= 4) {      // Chan: M2 = sum_w M2_w + sum_w n_w (mean_w - mean)^2
+                    float nwv[4], sw[4], nt = 0.f, stt = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned t0w = (bx * (unsigned)WG_WAVES + (unsigned)w) * 64u;
+                        nwv[w] = t0w < npix ? (float)min(npix - t0w, 64u) : 0.f;
+                        sw[w] = at(w, j - 4);
+                        nt += nwv[w]; stt += sw[w];
+                    }
+                    const float mg = nt > 0.f ? stt / nt : 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (nwv[w] > 0.f) { const float dmw = sw[w] / nwv[w] - mg; v += nwv[w] * dmw * dmw; }
+                }
+                a.stats[((long)bx * 2 + (j >> 2)) * g.Cd + n * 16 + q * 4 + (j & 3)] = v;
+            }
+            __syncthreads();      // the staging areas are output tiles again
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing (dead) steps: nothing may land in LDS after this
@@ -1338,17 +1734,17 @@ __global__ __launch_bounds__(256, 4) void tapgemm_bf16_lean_kernel(const LfTapGe
 }
 
 // ---------------------------------------------------------------------------------------
-// fp32 ON THE bf16 MATRIX CORES ("split" mode, LfTapArgs::split = 9 or 6).  gfx950 multiplies bf16 16x faster
+// fp32 ON THE bf16 MATRIX CORES ("split" mode, LfTapArgs::split = 9).  gfx950 multiplies bf16 16x faster
 // than fp32 (v_mfma_f32_16x16x32_bf16: 16 cycles for K = 32; v_mfma_f32_16x16x4_f32: 8 x 32 cycles for the same K),
 // so an fp32 product is formed from bf16 pieces instead: every fp32 operand is split EXACTLY into three bf16 values
 //     a = a_h + a_m + a_l,   a_h = bf16(a), a_m = bf16(a - a_h), a_l = bf16(a - a_h - a_m)      (8 + 8 + 8 mantissa bits)
 // (both subtractions are exact in fp32, a_l is exact because at most 8 significant bits are left), and
 //     a * b = sum_{i,j} a_i * b_j
-// where each of the nine bf16 x bf16 products is exact in the fp32 accumulator.  TERMS = 9 keeps them all: the result
-// is an fp32 accumulation of exact products, the same contract as the fp32 FMA chain of tapgemm_kernel.  TERMS = 6
-// drops a_m*b_l, a_l*b_m, a_l*b_l (< 2^-24 |a b| together, unbiased because the pieces are rounded to nearest): below
-// the rounding of one fp32 accumulation step.  Tensors, accumulators, epilogue and statistics are fp32 as in mode 0.
-// Cost per 64 x 64 x 32 wave step: 144 (96) MFMAs x 16 cycles = 2304 (1536) cycles against 4096 on the fp32 cores.
+// where each of the nine bf16 x bf16 products is exact in the fp32 accumulator; all nine are kept: the result is an fp32
+// accumulation of exact products, the same contract as the fp32 FMA chain of tapgemm_kernel.  (A 6-term form that dropped
+// a_m*b_l, a_l*b_m, a_l*b_l -- < 2^-24 |a b| together -- existed through round 5; no BASELINE configuration used it.)
+// Tensors, accumulators, epilogue and statistics are fp32 as in mode 0.
+// Cost per 64 x 64 x 32 wave step: 144 MFMAs x 16 cycles = 2304 cycles against 4096 on the fp32 cores.
 // The pixel operand is split in registers (v_cvt_pk_bf16_f32 + exact residuals, ~5 VALU ops per element, issued in the
 // shadow of the MFMAs); weights are split once per forward by the pack kernel ([tap][K/8][Cd][3][8] bf16) and, being
 // 3x the bytes of the fp32 form, staged ONCE per workgroup and step through LDS (double-buffered, one barrier per step)
@@ -1368,14 +1764,14 @@ __device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& h
 }
 
 // Workgroup = 512 threads = two 4-wave groups A (waves 0-3) and B (waves 4-7); waves w and w+4 share SIMD w.  A wave's
-// step has a VALU part (split the 32 pixel values it loaded, issue the next loads) and a matrix part (144 / 96 MFMAs).
+// step has a VALU part (split the 32 pixel values it loaded, issue the next loads) and a matrix part (144 MFMAs).
 // Two waves running the same code in lockstep would both want the VALU, then both the matrix pipe; so B runs HALF A STEP
 // behind A, phase-locked by the workgroup barrier: while A multiplies, B splits, and vice versa -- the matrix pipe of every
 // SIMD always has exactly one wave streaming back-to-back MFMAs.  Group A also stages the weights: W[s+1] is written to
 // the idle LDS buffer during A's split phase (B is reading W[s-1]'s successor W[s] from the other one).
 #undef LF_EPI_GROUPS
 #define LF_EPI_GROUPS 2
-template <int NT, int PROC, int TERMS, int EPIC = -1, bool DBG = false>
+template <int NT, int PROC, int EPIC = -1, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g, const LfTapArgs a, const int pro, const int epi_rt) {
     const int epi = EPIC >= 0 ? EPIC : epi_rt;      // compiled-in epilogue flags, as in tapgemm_kernel
     constexpr bool S16 = false, HOISTV = EPIC >= 0;
@@ -1473,7 +1869,6 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
     };
     static_assert(MT == 4, "tab_off packs 4 pixel tiles");
     static_assert(NT == 4, "group A (256 threads) stages a 64-channel weight slab");
-    static_assert(TERMS == 9 || TERMS == 6, "9 = every partial product, 6 = those above 2^-24");
     Raw R;
     bf16x8 xb[MT][3];
     if constexpr (DBG) tstamp[1] = __builtin_amdgcn_s_memrealtime();
@@ -1517,14 +1912,12 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
             const bf16x8 wm = __builtin_bit_cast(bf16x8, wl[cur][1][kq][n * 16 + pl]);
             const bf16x8 wo = __builtin_bit_cast(bf16x8, wl[cur][2][kq][n * 16 + pl]);
             // smallest terms first; consecutive MFMAs of one term go to four different accumulators
-            if constexpr (TERMS == 9) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][2], acc[n][m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][2], acc[n][m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][1], acc[n][m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][1], acc[n][m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][2], acc[n][m], 0, 0, 0);
-            }
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xb[m][2], acc[n][m], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xb[m][0], acc[n][m], 0, 0, 0);
 #pragma unroll
@@ -1547,7 +1940,11 @@ __global__ __launch_bounds__(512, 2) void tapgemm_split_kernel(const LfTapGeom g
         asm volatile("" ::"v"(acc[0][0][0]));
         tstamp[2] = __builtin_amdgcn_s_memrealtime();
     }
+#undef LF_EPI_PIVOT
+#define LF_EPI_PIVOT (EPIC >= 0)
     LF_TAPGEMM_EPILOGUE
+#undef LF_EPI_PIVOT
+#define LF_EPI_PIVOT true
     if constexpr (DBG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memrealtime();
@@ -1716,7 +2113,8 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
 }
 
 int g_split_any_size = 0;      // kernel-level tests only: let the split kernel take launches below its shipped size rule
-int g_bf16_lds = 4;            // tools / A-B runs only: 4 = whole-line + 16-channel kernels where they apply, else the ring (shipped); 2 = the ring
+int g_bf16_lds = 4;            // tools / A-B runs only: 4 = wave-private (64 ch) / whole-line (128 ch) + 16-channel kernels where they apply, else the ring (shipped);
+                               // 3 = the whole-line kernel at 64 channels too (round 5's routing); 2 = the ring
                                // for every launch it takes; 0 = the streaming bf16 kernel only
 
 int pick_nt(int Cd) {
@@ -1820,6 +2218,18 @@ bool launch_bf16_wl(unsigned nitems, hipStream_t st, const LfTapGeom& g, const L
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, st, g, a, pro, epi);
     return true;
 }
+// tapgemm_bf16_wv_kernel (64 channels): same contract
+template <int EPIV>
+bool launch_bf16_wv(unsigned ntiles, hipStream_t st, const LfTapGeom& g, const LfTapArgs& a, int pro, int epi) {
+    auto kern = tapgemm_bf16_wv_kernel<EPIV>;
+    const size_t lds = WvCfg<EPIV>::LDS;
+    if (!allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 4096)) return false;
+    unsigned gx = ntiles;
+    const unsigned res = (unsigned)resident_workgroups(kern, lds);
+    if (gx > res && res >= 8) gx = res & ~7u;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, st, g, a, pro, epi);
+    return true;
+}
 }  // namespace
 
 int lf_tapgemm_launch_unordered(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st) {
@@ -1855,17 +2265,15 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     const int epis = ((epi & (LF_EPI_MASK | LF_EPI_ADD | LF_EPI_MASKBN | LF_EPI_STATS_XHAT)) && a.bias) ? -2 : epi;
     LF_REQUIRE(!a.s16 || a.wp16, "tapgemm: bf16 tensors need the bf16 matrix-core kernel (wp16)");
     if (a.split && a.wp48 && !a.wp16 && lf_tapgemm_split_ok(g)) {
-        LF_REQUIRE(a.split == 9 || a.split == 6, "tapgemm: split must be 9 or 6 (got %d)", a.split);
+        LF_REQUIRE(a.split == 9, "tapgemm: split must be 9 (got %d; the 6-term form was removed in round 6)", a.split);
         LfTapArgs b = a;
         b.wp16 = a.wp48;
         const dim3 grid2((unsigned)(npix / (2 * PIX_PER_WG)), g.Cd / 64);     // 512-pixel workgroups (two 4-wave groups)
         if (a.dbg) {       // phase stamps (tools/kbench.py --phases): the plain conv only
             LF_REQUIRE(pro == LF_PRO_NONE && epi == 0, "tapgemm: phase stamps are compiled into the plain convolution only");
-            if (a.split == 9) hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 9, 0, true>), grid2, dim3(512), 0, st, g, b, pro, epi);
-            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 6, -1, true>), grid2, dim3(512), 0, st, g, b, pro, epi);
-        } else
-        if (a.split == 9) {
-#define LF_TS9(PROV, EPIV) hipLaunchKernelGGL((tapgemm_split_kernel<4, PROV, 9, EPIV>), grid2, dim3(512), 0, st, g, b, pro, epi)
+            hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 0, true>), grid2, dim3(512), 0, st, g, b, pro, epi);
+        } else {
+#define LF_TS9(PROV, EPIV) hipLaunchKernelGGL((tapgemm_split_kernel<4, PROV, EPIV>), grid2, dim3(512), 0, st, g, b, pro, epi)
             if (pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) LF_TS9(1, LF_EPI_RELU);
             else if (pro == LF_PRO_BNRELU) LF_TS9(1, -1);
             else switch (epis) {
@@ -1880,9 +2288,6 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
                 default: LF_TS9(0, -1); break;
             }
 #undef LF_TS9
-        } else {
-            if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_split_kernel<4, 1, 6>), grid2, dim3(512), 0, st, g, b, pro, epi);
-            else hipLaunchKernelGGL((tapgemm_split_kernel<4, 0, 6>), grid2, dim3(512), 0, st, g, b, pro, epi);
         }
         LF_CHECK_LAUNCH("tapgemm_split");
         return 0;
@@ -1891,15 +2296,14 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
     if (a.wp16) {
 #define LF_TG16(NTV)                                                                                                     \
     do {                                                                                                                 \
-        if (a.s16 && pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 1, true>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else if (a.s16) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0, true>), grid, dim3(256), 0, st, g, a, pro, epi);  \
-        else if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 1, false>), grid, dim3(256), 0, st, g, a, pro, epi); \
-        else hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0, false>), grid, dim3(256), 0, st, g, a, pro, epi);            \
+        if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 1>), grid, dim3(256), 0, st, g, a, pro, epi); \
+        else hipLaunchKernelGGL((tapgemm_bf16_kernel<NTV, 0>), grid, dim3(256), 0, st, g, a, pro, epi);                  \
     } while (0)
+        LF_REQUIRE(a.s16, "tapgemm: the bf16 matrix-core kernels take bf16 tensors (s16); bf16 operands on fp32 tensors were removed in round 6");
         LF_REQUIRE(g.Cs >= 8 && g.s_pix >= g.s_choff + 8, "tapgemm bf16: needs at least 8 source channels");
-#define LF_TG16F(EPIV) hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 0, true, EPIV, true>), grid, dim3(256), 0, st, g, a, pro, epi)
+#define LF_TG16F(EPIV) hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 0, EPIV, true>), grid, dim3(256), 0, st, g, a, pro, epi)
         // the 16 -> 16 channel 3-tap convolutions on bf16 tensors: tapgemm_bf16_lean_kernel
-        if (a.s16 && g_bf16_lds == 4 && !a.dbg && g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0 && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 &&
+        if (a.s16 && g_bf16_lds >= 3 && !a.dbg && g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0 && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 &&
             (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB) {
 #define LF_TGL(EPIV) do { if (pro == LF_PRO_BNRELU) hipLaunchKernelGGL((tapgemm_bf16_lean_kernel<1, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi); \
                           else hipLaunchKernelGGL((tapgemm_bf16_lean_kernel<0, EPIV>), grid, dim3(256), 0, st, g, a, pro, epi); } while (0)
@@ -1928,10 +2332,35 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
         // channels the in-LDS transform is as long as the whole step (88 -> 91 us): those stay on the streaming kernel
         const bool fast16p = nt == 4 && a.s16 && pro == LF_PRO_BNRELU && epi == LF_EPI_RELU && g.Cs == 128 &&
                              (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB;
-        const bool wl = (fast16 || fast16p) && g_bf16_lds == 4 && !a.dbg && g.ntaps == 3 && g.Cs == g.Cd && (g.Cd == 64 || g.Cd == 128) && g.Wl % 16 == 0 &&
-                        g.ssh == 1 && g.ssw == 1 && g.dsh == 1 && g.dsw == 1 && g.dah == 0 && g.daw == 0 && g.Hs == g.Hl && g.Ws == g.Wl &&
-                        g.Hd == g.Hl && g.Wd == g.Wl && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
-                        (long)g.N * g.Hd * g.Wd * g.d_pix * 2 < (long)LF_OOB;
+        const bool line3 = g_bf16_lds >= 3 && !a.dbg && g.ntaps == 3 && g.Cs == g.Cd && (g.Cd == 64 || g.Cd == 128) && g.Wl % 16 == 0 &&
+                           g.ssh == 1 && g.ssw == 1 && g.dsh == 1 && g.dsw == 1 && g.dah == 0 && g.daw == 0 && g.Hs == g.Hl && g.Ws == g.Wl &&
+                           g.Hd == g.Hl && g.Wd == g.Wl && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
+                           (long)g.N * g.Hd * g.Wd * g.d_pix * 2 < (long)LF_OOB;
+        // 64 channels (g_bf16_lds = 4, shipped): tapgemm_bf16_wv_kernel -- a wave owns its pixels and all 64 output channels; 3 = the
+        // whole-line kernel for both channel counts (round 5's routing, kept for A/B runs: tools/bf16_ab.py)
+        const bool wv = line3 && g_bf16_lds == 4 && g.Cd == 64 && fast16;
+        const bool wl = line3 && !wv && (fast16 || fast16p);
+        if (wv) {
+            const unsigned ntiles = (unsigned)lf_cdiv(npix, PIX_PER_WG);
+            bool launched = false;
+#define LF_TGV(EPIV) do { launched = launch_bf16_wv<EPIV>(ntiles, st, g, a, pro, epi); } while (0)
+            switch (epis) {
+                case 0: LF_TGV(0); break;
+                case LF_EPI_RELU: LF_TGV(LF_EPI_RELU); break;
+                case LF_EPI_MASK: LF_TGV(LF_EPI_MASK); break;
+                case LF_EPI_ADD: LF_TGV(LF_EPI_ADD); break;
+                case LF_EPI_STATS_SQ: LF_TGV(LF_EPI_STATS_SQ); break;
+                case LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGV(LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT: LF_TGV(LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT); break;
+                case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TGV(LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
+                default: LF_TGV(-1); break;
+            }
+#undef LF_TGV
+            if (launched) {
+                LF_CHECK_LAUNCH("tapgemm_bf16_wv");
+                return 0;
+            }
+        }
         if (wl && fast16p) {        // (128 channels only)
             if (launch_bf16_wl<4, LF_EPI_RELU, 1>((unsigned)lf_cdiv(npix, PIX_PER_WG), st, g, a, pro, epi)) {
                 LF_CHECK_LAUNCH("tapgemm_bf16_wl (prologue)");
@@ -1991,7 +2420,7 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
                 default: LF_TG16F(-1); break;
             }
         } else if (nt == 4 && a.s16 && pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) {
-            hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 1, true, LF_EPI_RELU, false>), grid, dim3(256), 0, st, g, a, pro, epi);
+            hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 1, LF_EPI_RELU, false>), grid, dim3(256), 0, st, g, a, pro, epi);
         } else
         switch (nt) {
             case 4: LF_TG16(4); break;
@@ -2421,195 +2850,6 @@ __global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, con
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
             d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Weight gradient in the split arithmetic (precision modes fp32x9 / fp32x6, see tapgemm_split_kernel): fp32 tensors and
-// accumulators, every product X*G formed on the bf16 matrix cores from exact 3-way splits of BOTH operands (they are both
-// activations, so both are split in registers).  v_mfma_f32_16x16x32_bf16: a lane's k-block = its 8 pixels
-// (p + kq + 4u, u = 0..7, one image row) -- an iteration covers 32 pixels -- and, as in the fp32 kernel, the float4 a lane
-// loads per pixel (channels 4*pl .. 4*pl+3) feeds four tiles (tile r = channels {4*row + r}).  64 x 64 channel blocks only.
-// Workgroup = 512 threads = two 4-wave groups on the same four SIMDs, group B half an iteration behind A (workgroup
-// barrier as phase lock): one wave of a SIMD streams its 144 (96) MFMAs while its partner splits the next 64 values and
-// issues the following loads.  All eight waves split K (pixels) and are reduced through LDS at the end.
-// ---------------------------------------------------------------------------------------
-template <int TERMS>
-__global__ __launch_bounds__(512, 2) void tapwgrad_split_kernel(const LfTapGeom g, const LfWgradArgs a, const long pps,
-                                                                const int write_bias) {
-    constexpr int WAVES = 8, U = 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pl = lane & 15, kq = lane >> 4;
-    const int grp = wave >> 2;
-    const int ncob = g.Cd / 64;
-    unsigned ord = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) ord = (ord & 7u) * (gridDim.x >> 3) + (ord >> 3);
-    const unsigned nz = (unsigned)((g.Cs / 64) * ncob);
-    const int t = (int)(ord % (unsigned)g.ntaps);
-    const int bz = (int)((ord / (unsigned)g.ntaps) % nz);
-    const unsigned bxs = ord / ((unsigned)g.ntaps * nz);
-    const int cib = bz / ncob, cob = bz % ncob;
-    const long npix = (long)g.N * g.Hl * g.Wl;
-    const long p_begin = ((long)bxs * WAVES + wave) * pps;
-    long p_end = p_begin + pps;
-    if (p_end > npix) p_end = npix;
-    const int niter = (int)(pps / (4 * U));          // the same for every wave of the workgroup (barriers in the loop)
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[r][q] = zero4();
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-
-    long p = p_begin + kq;
-    int pj, pi, pn;
-    {
-        const unsigned q = p < npix ? (unsigned)p : 0u;
-        const unsigned r = q / (unsigned)g.Wl;
-        pj = (int)(q - r * (unsigned)g.Wl);
-        pn = (int)(r / (unsigned)g.Hl);
-        pi = (int)(r - (unsigned)pn * (unsigned)g.Hl);
-    }
-    const int dh = g.tdh[t], dw = g.tdw[t];
-    const int xch = g.s_choff + cib * 64 + 4 * pl;
-    const int gch = g.d_choff + cob * 64 + 4 * pl;
-    const bool need_bias = write_bias && a.bias_partial && t == 0 && cib == 0;      // workgroup-uniform
-
-    struct Raw { f32x4 x4[U], g4[U]; unsigned vmask, xmask; };
-    auto wload = [&](Raw& S) {
-        unsigned vm = 0, xm = 0;
-        const bool rowv = (p - kq) < p_end;
-        const int nn = rowv ? pn : 0, ii = rowv ? pi : 0, jj = rowv ? pj : 0;
-        const unsigned gofs = (unsigned)(((nn * g.Hd + ii * g.dsh + g.dah) * g.Wd + jj * g.dsw + g.daw) * g.d_pix + gch);
-        const unsigned gstep = (unsigned)(4 * g.dsw * g.d_pix);
-        const int sy = ii * g.ssh + dh;
-        const bool yin = sy >= 0 && sy < g.Hs;
-        const int syc = min(max(sy, 0), g.Hs - 1);
-        const unsigned xrow = (unsigned)((nn * g.Hs + syc) * g.Ws * g.s_pix + xch);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool v = rowv && (p + 4 * u) < p_end;
-            vm |= (v ? 1u : 0u) << u;
-            S.g4[u] = ldg4(a.g + (v ? gofs + u * gstep : gofs));
-            const int sx = (jj + 4 * u) * g.ssw + dw;
-            const bool xin = v && yin && sx >= 0 && sx < g.Ws;
-            xm |= (xin ? 1u : 0u) << u;
-            S.x4[u] = ldg4(a.x + xrow + (unsigned)(min(max(sx, 0), g.Ws - 1) * g.s_pix));
-        }
-        S.vmask = vm; S.xmask = xm;
-    };
-    auto advance = [&]() {
-        p += 4 * U;
-        pj += 4 * U;
-        if (pj >= g.Wl) { pj -= g.Wl; if (++pi >= g.Hl) { pi = 0; ++pn; } }
-    };
-
-    Raw R;
-    bf16x8 xp[4][3], gp[4][3];
-    wload(R);
-    if (grp == 1) __syncthreads();                  // B starts one phase late
-    for (int it = 0; it < niter; ++it) {
-        // ---- VALU phase: mask (only where the wave touches padding or its end), split, start the next loads
-        if (__builtin_amdgcn_ballot_w64(R.vmask != 255u || R.xmask != 255u) != 0ull) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool v = (R.vmask >> u) & 1u, xin = (R.xmask >> u) & 1u;
-                f32x4 gg = R.g4[u], xx = R.x4[u];
-                gg.x = v ? gg.x : 0.f; gg.y = v ? gg.y : 0.f; gg.z = v ? gg.z : 0.f; gg.w = v ? gg.w : 0.f;
-                xx.x = xin ? xx.x : 0.f; xx.y = xin ? xx.y : 0.f; xx.z = xin ? xx.z : 0.f; xx.w = xin ? xx.w : 0.f;
-                R.g4[u] = gg; R.x4[u] = xx;
-            }
-        }
-        if (need_bias) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) { bsum[0] += R.g4[u].x; bsum[1] += R.g4[u].y; bsum[2] += R.g4[u].z; bsum[3] += R.g4[u].w; }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {               // tile e = element e of every pixel's quad; k = the lane's 8 pixels
-            const f32x4 xlo = {R.x4[0][e], R.x4[1][e], R.x4[2][e], R.x4[3][e]}, xhi = {R.x4[4][e], R.x4[5][e], R.x4[6][e], R.x4[7][e]};
-            const f32x4 glo = {R.g4[0][e], R.g4[1][e], R.g4[2][e], R.g4[3][e]}, ghi = {R.g4[4][e], R.g4[5][e], R.g4[6][e], R.g4[7][e]};
-            split3(xlo, xhi, xp[e][0], xp[e][1], xp[e][2]);
-            split3(glo, ghi, gp[e][0], gp[e][1], gp[e][2]);
-        }
-        advance();
-        wload(R);                                   // past the end: clamped, fully masked
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) asm volatile("" ::"v"(xp[e][pc]), "v"(gp[e][pc]));
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- matrix phase
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if constexpr (TERMS == 9) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][2], gp[q][2], acc[r][q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][2], gp[q][1], acc[r][q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][1], gp[q][2], acc[r][q], 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][2], gp[q][0], acc[r][q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][0], gp[q][2], acc[r][q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][1], gp[q][1], acc[r][q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][1], gp[q][0], acc[r][q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][0], gp[q][1], acc[r][q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[r][0], gp[q][0], acc[r][q], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (grp == 0) __syncthreads();                  // pairs B's extra first barrier
-
-    // ---- reduce the 8 waves through LDS, wave 0 writes one partial row
-    __shared__ float red[WAVES - 1][64][64];
-    __shared__ float bred[WAVES][4][64];
-    if (wave > 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) red[wave - 1][(r * 4 + q) * 4 + e][lane] = acc[r][q][e];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bred[wave][q][lane] = bsum[q];
-    __syncthreads();
-    if (wave == 0) {
-        float* out = a.partial + ((long)bxs * g.ntaps + t) * g.Cs * g.Cd;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[r][q][e];
-#pragma unroll
-                    for (int w = 0; w < WAVES - 1; ++w) v += red[w][(r * 4 + q) * 4 + e][lane];
-                    const int i = 4 * kq + e;
-                    out[(long)(cib * 64 + 4 * i + r) * g.Cd + cob * 64 + 4 * pl + q] = v;
-                }
-        if (need_bias) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) v += bred[w][q][lane];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (kq == 0) a.bias_partial[(long)bxs * g.Cd + cob * 64 + 4 * pl + q] = v;
-            }
         }
     }
 }
@@ -3046,42 +3286,18 @@ WgradCfg wgrad_cfg(const LfTapGeom& g) {
     return c;
 }
 
-// split-arithmetic kernel: 64-channel blocks, 32-pixel iterations, fp32 tensors, no BN prologue on the x side
-// Used for 6 terms only: both operands are split in registers (~450 VALU per 144 / 96 MFMAs) and a VALU instruction beside
-// the partner's MFMA stream issues only every ~12 cycles -- measured 79 us (x9) / 71-77 us (x6) against 75-81 us on the fp32
-// cores for the 128- / 64-channel launches of the network.
-bool wgrad_split_ok(const LfTapGeom& g, const LfWgradArgs* a, int pro) {
-    if (a && (a->split != 6 || a->s16)) return false;
-    return pro == LF_PRO_NONE && g.Cs % 64 == 0 && g.Cd % 64 == 0 && g.Wl % 32 == 0;
-}
-WgradCfg wgrad_split_cfg(const LfTapGeom& g) {
-    WgradCfg c = wgrad_cfg(g);
-    const int jobs = g.ntaps * (g.Cs / 64) * (g.Cd / 64);
-    const long npix = (long)g.N * g.Hl * g.Wl;
-    int gx = 256 / jobs;                                    // one 8-wave workgroup per CU
-    if (gx < 1) gx = 1;
-    long pps = (npix + (long)gx * 8 - 1) / ((long)gx * 8);
-    pps = (pps + 31) / 32 * 32;
-    c.gx = (int)((npix + pps * 8 - 1) / (pps * 8));
-    c.pps = pps;
-    return c;
-}
 
 }  // namespace
 
-int lf_tapwgrad_splits(const LfTapGeom& g) {
-    const int a = wgrad_cfg(g).gx;
-    const int b = wgrad_split_ok(g, nullptr, LF_PRO_NONE) ? wgrad_split_cfg(g).gx : 0;
-    return a > b ? a : b;                                   // sizes the partial rows for either kernel on fp32 tensors
-}
+int lf_tapwgrad_splits(const LfTapGeom& g) { return wgrad_cfg(g).gx; }
 int lf_tapwgrad_splits_bound(const LfTapGeom& g, int s16) {
     const int a = lf_tapwgrad_splits(g), c = s16 ? lf_tapwgrad_ro_rows_bound(g) : 0;
     return a > c ? a : c;
 }
-int lf_tapwgrad_bias_rows(const LfTapGeom& g) { return lf_tapwgrad_splits(g); }
 int lf_tapwgrad_splits_for(const LfTapGeom& g, const LfWgradArgs& a, int pro) {
     if (lf_tapwgrad_ro_ok(g, a.s16) && !a.dbg) return lf_tapwgrad_ro_rows(g);
-    return wgrad_split_ok(g, &a, pro) ? wgrad_split_cfg(g).gx : wgrad_cfg(g).gx;
+    (void)pro;
+    return wgrad_cfg(g).gx;
 }
 
 int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStream_t st) {
@@ -3091,20 +3307,11 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
                "tapwgrad: tensor too large for 32-bit byte offsets");
     if (lf_tapwgrad_ro_ok(g, a.s16) && !a.dbg) return lf_tapwgrad_ro_launch(g, a, pro, st);     // bf16 tensors, 3 taps, 64 / 128 channels
     const int wb = a.bias_partial != nullptr;
-    if (wgrad_split_ok(g, &a, pro)) {
-        LF_REQUIRE(a.split == 9 || a.split == 6, "tapwgrad: split must be 9 or 6 (got %d)", a.split);
-        const WgradCfg cs = wgrad_split_cfg(g);
-        dim3 grid(cs.gx * g.ntaps * (g.Cs / 64) * (g.Cd / 64));
-        if (a.split == 9) hipLaunchKernelGGL(tapwgrad_split_kernel<9>, grid, dim3(512), 0, st, g, a, cs.pps, wb);
-        else hipLaunchKernelGGL(tapwgrad_split_kernel<6>, grid, dim3(512), 0, st, g, a, cs.pps, wb);
-        LF_CHECK_LAUNCH("tapwgrad_split");
-        return 0;
-    }
     const WgradCfg c = wgrad_cfg(g);
     const int xb = c.xt * 16, gb = c.gt * 16;
     if (g.Cs == 16 && g.Cd == 16 && g.ntaps == 3 && g.Wl % 16 == 0) {
         // both LDS-ring forms need 16-byte-aligned pixels of both tensors inside 32-bit byte offsets, and the LDS attribute
-        const bool ring_ok = g_bf16_lds == 4 && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
+        const bool ring_ok = g_bf16_lds >= 3 && g.s_pix % 8 == 0 && g.s_choff % 8 == 0 && g.d_pix % 8 == 0 && g.d_choff % 8 == 0 &&
                              (long)g.N * g.Hs * g.Ws * g.s_pix * (a.s16 ? 2 : 4) < (long)LF_OOB && (long)g.N * g.Hd * g.Wd * g.d_pix * (a.s16 ? 2 : 4) < (long)LF_OOB;
         const size_t ring_lds = (size_t)WG_WAVES * W16_STAGES * W16_STAGE;
         static_assert(W16F_STAGES * W16F_STAGE == W16_STAGES * W16_STAGE, "the two 16-channel rings share their LDS budget");

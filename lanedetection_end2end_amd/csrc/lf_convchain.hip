@@ -164,7 +164,7 @@ lf_convchain_plan* lf_convchain_plan_create(int N, int H, int W, int nlayers, co
         P->stat_floats = lf_maxl(P->stat_floats, (long)lf_tapgemm_stat_rows(g) * 2 * Co);
         P->stat_floats = lf_maxl(P->stat_floats, (long)lf_tapgemm_stat_rows(d) * 2 * Ci);
         P->wpart_floats = lf_maxl(P->wpart_floats, (long)lf_tapwgrad_splits(g) * kk * Ci * Co);
-        P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_tapwgrad_bias_rows(g) * Co);
+        P->bpart_floats = lf_maxl(P->bpart_floats, (long)lf_tapwgrad_splits_bound(g, 0) * Co);      // (fp32 tensors: the chain has no bf16 mode)
     }
     P->stat_floats = lf_maxl(P->stat_floats, (long)lf_bn_bwd_reduce_rows(npix) * 2 * cmax);
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
@@ -208,7 +208,8 @@ int lf_convchain_forward(const lf_convchain_plan* P, const float* x, const float
         int pro = LF_PRO_NONE;
         if (i > 0) { a.pro_sc = ws + P->sc[i - 1]; a.pro_sh = ws + P->sh[i - 1]; pro = LF_PRO_BNRELU; }
         LF_TRY(lf_tapgemm_launch(P->fwd[i], a, pro, training ? LF_EPI_STATS_SQ : 0, st));
-        LfStatPart part = {stat, lf_tapgemm_stat_rows_for(P->fwd[i], a), P->C[i + 1], 0};
+        const int srows = lf_tapgemm_stat_rows_for(P->fwd[i], a);
+        LfStatPart part = lf_stat_part_tiles(stat, srows, P->C[i + 1], 0, srows, npix);      // centred rows (LfStatPart)
         LF_TRY(lf_bn_finalize_fwd(&part, 1, P->C[i + 1], (double)npix, params_host[4 * i + 2], params_host[4 * i + 3],
                                   running_host[2 * i], running_host[2 * i + 1], momentum, eps, training, ws + P->sc[i],
                                   ws + P->sh[i], ws + P->asc[i], ws + P->ash[i], st));

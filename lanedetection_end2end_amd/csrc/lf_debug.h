@@ -7,11 +7,12 @@ extern "C" {
 #endif
 /* 1: the split kernels also take launches below their shipped size rule (kernel-level tests at small shapes) */
 void lf_debug_set_split_any_size(int v);
-/* which bf16-tensor tap-GEMM kernels run: 4 (shipped) whole-line + 16-channel kernels where they apply, else the ring; 2 the ring for
-   every launch it takes; 0 the streaming kernel only (A/B timing, bit-identity of the forms: tools/bf16_ab.py, tests/test_bf16_kernels_gpu.py) */
+/* which bf16-tensor tap-GEMM kernels run: 4 (shipped) wave-private kernel at 64 channels, whole-line kernel at 128, 16-channel kernels
+   where they apply, else the ring; 3 the whole-line kernel at 64 channels too (round 5's routing); 2 the ring for every launch it takes;
+   0 the streaming kernel only (A/B timing, bit-identity of the forms: tools/bf16_ab.py, tests/test_bf16_kernels_gpu.py) */
 void lf_debug_set_bf16_lds(int v);
-/* precision mode of the lf_conv1d_* calls: 0 fp32, 1 bf16 matrix cores on fp32 tensors, 2 bf16 matrix cores on bf16
- * tensors (x, y, gx, gy, mask_src hold bf16; w, bias, gw, gb stay fp32), 9 / 6 fp32 from 3-way split operands */
+/* precision mode of the lf_conv1d_* calls: 0 fp32, 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src hold bf16; w, bias,
+ * gw, gb stay fp32), 9 fp32 from 9-term split operands (modes 1 and 6 were removed in round 6 and select 0) */
 void lf_debug_set_ops_precision(int mode);
 /* lf_conv1d_fwd + per-wave s_memrealtime stamps (100 MHz) (start, tap table built, main loop done, stores
  * retired; 8 words per wave) */

@@ -7,9 +7,20 @@
 
 struct LfStatPart {   // one source of per-channel partial sums: rows x 2 x C floats
     const float* rows; int nrows; int C; int ch_off;
+    // tile_pix = 0: RAW rows [sum v][sum v^2] (or [sum g][sum g t] for the backward sums).
+    // tile_pix > 0: CENTRED rows of the tap-GEMM epilogues (round 6): [sum v][M2 = sum (v - mean_row)^2] where row r covers pixels
+    // (r % seg_rows) * tile_pix .. + tile_pix - 1 of a launch of seg_pix pixels (the four sub-pixel phases of a transposed
+    // convolution lay their rows end to end: seg_rows rows per phase); the finalise kernel merges the rows in fp64,
+    // sum v^2 = M2_r + (sum v)_r^2 / n_r, so the fp32 partials never hold a sum of squares about the origin.
+    int tile_pix = 0; int seg_rows = 0; long seg_pix = 0;
 };
+inline LfStatPart lf_stat_part_tiles(const float* rows, int nrows, int C, int ch_off, int seg_rows, long seg_pix, int tile_pix = 256) {
+    LfStatPart p = {rows, nrows, C, ch_off};
+    p.tile_pix = tile_pix; p.seg_rows = seg_rows; p.seg_pix = seg_pix;
+    return p;
+}
 
-// Forward BN: partial (sum, sum^2) -> mean/rstd, scale = gamma*rstd, shift = beta - mean*scale;
+// Forward BN: partial rows (raw or centred, see LfStatPart) -> mean/rstd, scale = gamma*rstd, shift = beta - mean*scale;
 // train: batch stats + running-stat update (momentum, unbiased var); eval: running stats.
 int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, int training,

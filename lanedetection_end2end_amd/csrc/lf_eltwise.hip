@@ -55,6 +55,11 @@ struct StatParts { LfStatPart p[2]; int n; };
 // batch 32, 14.1 vs 12.0 at config 3: the kernel's time is its launch, one or two memory round trips and the fp64 shuffle /
 // combine / divide tail that every wave runs, not the row loop)
 constexpr int FIN_THREADS = 256;
+// U = rows per thread and loop trip, all 2 U loads requested before the first add: 4 (1024 rows per trip).  Round 6 measured U = 16 --
+// config 3's 3200 rows per BatchNorm in ONE trip, 128 registers of loads in flight -- and it is SLOWER: 21.8 vs 11.9 us (forward),
+// 19.0 vs 10.7 (backward): the kernel is not bound by its dependent trips but by what each workgroup drags through its L1: it
+// uses 16 bytes of every 256-byte row half, so the 16-32 workgroups of a launch fetch every line 8 times.
+template <int U>
 __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, double (&s1)[4], double (&s2)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
@@ -65,10 +70,10 @@ __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, doub
         // four rows = eight 16-byte loads requested before the first add: the kernel is ONE memory round trip per loop trip (rows
         // written by the previous launch: L2 / Infinity Cache, ~1 us), and at config 3's 3200 rows the two-load form made 13 of them
         // -- 12 us per BatchNorm, 0.9 ms per step.  Rows beyond the count re-read row 0 and are skipped by a scalar-free select.
-        for (int r0 = threadIdx.x; r0 < q.nrows; r0 += 4 * FIN_THREADS) {
-            f32x4 a[4], b[4];
+        for (int r0 = threadIdx.x; r0 < q.nrows; r0 += U * FIN_THREADS) {
+            f32x4 a[U], b[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int r = r0 + u * FIN_THREADS < q.nrows ? r0 + u * FIN_THREADS : 0;
                 a[u] = ld4(q.rows + ((long)r * 2 + 0) * q.C + cc);
                 b[u] = ld4(q.rows + ((long)r * 2 + 1) * q.C + cc);
@@ -76,10 +81,20 @@ __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, doub
             asm volatile("" ::: "memory");      // all eight requests are out before the first add (with a `break` in the sum loop hipcc
                                                 // fused the two loops back into load, load, wait, add: one round trip per row)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool v = r0 + u * FIN_THREADS < q.nrows;  // a row beyond the count adds +0.0
-                s1[0] += v ? (double)a[u].x : 0.0; s1[1] += v ? (double)a[u].y : 0.0; s1[2] += v ? (double)a[u].z : 0.0; s1[3] += v ? (double)a[u].w : 0.0;
-                s2[0] += v ? (double)b[u].x : 0.0; s2[1] += v ? (double)b[u].y : 0.0; s2[2] += v ? (double)b[u].z : 0.0; s2[3] += v ? (double)b[u].w : 0.0;
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * FIN_THREADS;
+                const bool v = r < q.nrows;  // a row beyond the count adds +0.0
+                // centred rows: sum v^2 about the origin = M2_r + (sum v)_r^2 / n_r, formed in fp64 (n_r from the launch geometry)
+                double inv = 0.0;
+                if (q.tile_pix > 0) {
+                    const long left = q.seg_pix - (long)(r % q.seg_rows) * q.tile_pix;
+                    const long n = left < q.tile_pix ? left : q.tile_pix;
+                    inv = n > 0 ? 1.0 / (double)n : 0.0;
+                }
+                const double ax = (double)a[u].x, ay = (double)a[u].y, az = (double)a[u].z, aw = (double)a[u].w;
+                s1[0] += v ? ax : 0.0; s1[1] += v ? ay : 0.0; s1[2] += v ? az : 0.0; s1[3] += v ? aw : 0.0;
+                s2[0] += v ? (double)b[u].x + ax * ax * inv : 0.0; s2[1] += v ? (double)b[u].y + ay * ay * inv : 0.0;
+                s2[2] += v ? (double)b[u].z + az * az * inv : 0.0; s2[3] += v ? (double)b[u].w + aw * aw * inv : 0.0;
             }
         }
     }
@@ -105,6 +120,7 @@ __device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, doub
     }
 }
 
+template <int U>
 __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ rmean, float* __restrict__ rvar,
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_fwd_kernel(StatParts 
                                                             float* __restrict__ asc, float* __restrict__ ash) {
     const int c0 = blockIdx.x * 4;
     double s1[4], s2[4];
-    if (training) stat_rows_sum4(sp, c0, s1, s2);
+    if (training) stat_rows_sum4<U>(sp, c0, s1, s2);
     const int c = c0 + (int)threadIdx.x;
     if (threadIdx.x < 4 && c < C) {
         double mean, var;
@@ -226,6 +242,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // terms of the data gradient vanish (c1 = c2 = 0); the parameter gradients are the same sums.
 // (mean_scale = 1 / count in training mode, 0 in eval mode -- decided on the host: a run-time `training ? :` in here made hipcc
 // unroll the final sum into 128 registers + 564 bytes of scratch, 19 us per launch instead of 6)
+template <int U>
 __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(StatParts sp, int C, double mean_scale, const float* __restrict__ asc,
                                                             const float* __restrict__ ash, float* __restrict__ c1,
                                                             float* __restrict__ c2, float* __restrict__ ggamma,
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(StatParts 
     // sum g * x^ = rstd * sum g t - mean rstd * sum g, formed here in fp64 from the fp64 column sums
     const int c0 = blockIdx.x * 4;
     double s1[4], s2[4];
-    stat_rows_sum4(sp, c0, s1, s2);
+    stat_rows_sum4<U>(sp, c0, s1, s2);
     const int c = c0 + (int)threadIdx.x;
     if (threadIdx.x < 4 && c < C) {
         double t1 = s1[0], t2 = s2[0];
@@ -464,7 +481,10 @@ int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count,
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
     for (int i = 0; i < nparts; ++i) LF_REQUIRE(parts[i].C % 4 == 0 && parts[i].ch_off % 4 == 0, "bn_finalize: channel ranges must be multiples of 4");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(lf_cdiv(C, 4)), dim3(FIN_THREADS), 0, st, sp, C, count, gamma, beta,
+    for (int i = 0; i < nparts; ++i)
+        LF_REQUIRE(parts[i].tile_pix == 0 || (parts[i].seg_rows > 0 && parts[i].seg_pix > 0 && parts[i].nrows % parts[i].seg_rows == 0),
+                   "bn_finalize: centred rows need the launch geometry (seg_rows, seg_pix)");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel<4>, dim3(lf_cdiv(C, 4)), dim3(FIN_THREADS), 0, st, sp, C, count, gamma, beta,
                        running_mean, running_var, momentum, eps, training, scale, shift, asc, ash);
     LF_CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
@@ -508,7 +528,7 @@ int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count,
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
     for (int i = 0; i < nparts; ++i) LF_REQUIRE(parts[i].C % 4 == 0 && parts[i].ch_off % 4 == 0, "bn_bwd_finalize: channel ranges must be multiples of 4");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lf_cdiv(C, 4)), dim3(FIN_THREADS), 0, st, sp, C, training ? 1.0 / count : 0.0, asc, ash,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(lf_cdiv(C, 4)), dim3(FIN_THREADS), 0, st, sp, C, training ? 1.0 / count : 0.0, asc, ash,
                        c1, c2, ggamma, gbeta);
     LF_CHECK_LAUNCH("bn_bwd_finalize");
     return 0;

@@ -17,6 +17,7 @@
 #include "lf_conv.h"
 #include "lf_eltwise.h"
 #include "lf_plan.h"
+#include "lf_types.h"
 
 namespace {
 
@@ -57,7 +58,7 @@ struct lf_erfnet_plan {
     int n_params, n_bn, n_drop;
     int p_head_w[2], p_head_b[2], n_heads;
     long off_entries, off_packed, packed_floats;
-    long off_packed16, packed16_elems;          // bf16 operand copies of the packed weights (precision modes 1, 2)
+    long off_packed16, packed16_elems;          // bf16 operand copies of the packed weights (precision mode 2)
     long off_packed48;                          // 3-piece bf16 split of the packed weights (modes 3, 4): 3 * packed16_elems
     mutable int precision = 0;                  // lf_erfnet_set_precision
     long off_stat0, off_stat1, stat_floats;     // two scratch regions for BN partial rows
@@ -324,15 +325,18 @@ void lf_erfnet_plan_destroy(lf_erfnet_plan* P) {
 }
 // (follows the precision mode: call it after lf_erfnet_set_precision)
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* P) { return (size_t)wpart_all_end(P, P->precision == 2) * sizeof(float); }
-// Matrix-core precision of the convolutions and their data gradients: 0 = fp32 MFMA (default, the parity
-// path), 1 = operands rounded to bf16 in registers (v_mfma_f32_16x16x32_bf16), fp32 accumulation, fp32 tensors,
-// 2 = mode 1 + every activation / gradient tensor of the backbone stored as bf16 (half the HBM traffic; the
-// weight gradient widens its bf16 operands and stays on the fp32 matrix cores; parameters, parameter gradients,
-// BatchNorm statistics and the logits stay fp32).
-// Set before a forward; the matching backward must run with the same setting.
+// ... or for a NAMED precision mode, independent of the plan's current setting (a plan is shared between calls: sizing by hidden
+// mutable state depends on call order -- ADVICE round 5); 0 for an unknown mode
+size_t lf_erfnet_workspace_bytes_for(const lf_erfnet_plan* P, int mode) {
+    if (!P || !(mode == 0 || mode == 2 || mode == 3)) return 0;
+    return (size_t)wpart_all_end(P, mode == 2) * sizeof(float);
+}
+// Precision mode (include/lanefit.h): 0 = fp32 matrix cores, fp32 tensors (default, the parity path); 2 = bf16 tensors and bf16
+// matrix cores (parameters, parameter gradients, BatchNorm statistics and the logits stay fp32); 3 = fp32 tensors, products from
+// exact 9-term bf16 splits on the bf16 matrix cores.  Set before a forward; the matching backward must run with the same setting.
 int lf_erfnet_set_precision(const lf_erfnet_plan* P, int mode) {
-    LF_REQUIRE(P && mode >= 0 && mode <= 4, "lf_erfnet_set_precision: mode must be 0 (fp32 cores), 1 (bf16 operands), 2 (bf16 tensors), "
-               "3 / 4 (fp32 from split operands on the bf16 cores, 9 / 6 partial products)");
+    LF_REQUIRE(P && (mode == 0 || mode == 2 || mode == 3), "lf_erfnet_set_precision: mode must be 0 (fp32 cores), 2 (bf16 tensors) or "
+               "3 (fp32 from 9-term split operands on the bf16 cores); modes 1 and 4 were removed in round 6");
     P->precision = mode;
     return 0;
 }
@@ -427,10 +431,10 @@ int run_gemm(const Ctx& c, const GemmOp& op, const float* src, float* dst, const
              LfTapArgs extra, bool beside_wgrad = false) {
     extra.src = src; extra.dst = dst; extra.bias = bias; extra.wp = c.packed(op.pack);
     extra.s16 = c.s16;
-    if (c.P->precision == 1 || c.P->precision == 2)
+    if (c.P->precision == 2)
         extra.wp16 = reinterpret_cast<const unsigned short*>(c.at(c.P->off_packed16)) + c.P->packs[op.pack].dst16_off;
-    if (c.P->precision >= 3) {      // fp32 from split operands on the bf16 matrix cores (9 or 6 partial products)
-        extra.split = c.P->precision == 3 ? 9 : 6;
+    if (c.P->precision == 3) {      // fp32 from split operands on the bf16 matrix cores (all 9 partial products)
+        extra.split = 9;
         extra.wp48 = reinterpret_cast<const unsigned short*>(c.at(c.P->off_packed48)) + 3 * c.P->packs[op.pack].dst16_off;
     }
     c.last_rows = lf_tapgemm_stat_rows_for(op.geom, extra);
@@ -475,7 +479,7 @@ int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
                 a.stats = stat0;
                 LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
-                parts[np++] = {stat0, c.last_rows, L.Cout - L.Cin, 0};
+                parts[np++] = lf_stat_part_tiles(stat0, c.last_rows, L.Cout - L.Cin, 0, c.last_rows, npo);     // centred rows (LfStatPart)
                 LF_TRY(lf_pool_concat_fwd(c.at(L.x), N, L.Hin, L.Win, L.Cin, c.at(L.b[0]), L.Cout, L.Cout - L.Cin,
                                           c.training ? stat1 : nullptr, c.s16, c.st));
                 parts[np++] = {stat1, lf_pool_rows(npo), L.Cin, L.Cout - L.Cin};
@@ -489,7 +493,7 @@ int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
             a.stats = stat0;
             LF_TRY(run_gemm(c, L.cv[1].fwd, c.at(L.b[0]), c.at(L.b[1]), c.params[L.cv[1].p_b], LF_PRO_NONE,
                             c.training ? LF_EPI_STATS_SQ : 0, a));
-            LfStatPart p0 = {stat0, c.last_rows, L.Cout, 0};
+            LfStatPart p0 = lf_stat_part_tiles(stat0, c.last_rows, L.Cout, 0, c.last_rows, npo);
             LF_TRY(bn_finalize(c, L.bn[0], &p0, 1, (double)npo));
             a = lf_no_args();
             a.pro_sc = c.at(L.bn[0].sc); a.pro_sh = c.at(L.bn[0].sh);
@@ -498,7 +502,7 @@ int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
             a.stats = stat0;
             LF_TRY(run_gemm(c, L.cv[3].fwd, c.at(L.b[2]), c.at(L.b[3]), c.params[L.cv[3].p_b], LF_PRO_NONE,
                             c.training ? LF_EPI_STATS_SQ : 0, a));
-            p0.nrows = c.last_rows;
+            p0.nrows = p0.seg_rows = c.last_rows;
             LF_TRY(bn_finalize(c, L.bn[1], &p0, 1, (double)npo));
             const float* dm = (c.training && L.drop_idx >= 0 && c.dropmask) ? c.dropmask + P->drop_off[L.drop_idx] : nullptr;
             LF_TRY(lf_bn_act(c.at(L.b[3]), c.at(L.bn[1].sc), c.at(L.bn[1].sh), dm, c.at(L.x), c.at(L.b[4]), npo, L.Cout,
@@ -514,7 +518,7 @@ int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
                 rows += c.last_rows;
             }
-            parts[0] = {stat0, rows, L.Cout, 0};
+            parts[0] = lf_stat_part_tiles(stat0, rows, L.Cout, 0, rows / 4, npo / 4);      // every phase: N * Hin * Win pixels, rows / 4 rows
             LF_TRY(bn_finalize(c, L.bn[0], parts, 1, (double)npo));
             LF_TRY(lf_bn_act(c.at(L.b[0]), c.at(L.bn[0].sc), c.at(L.bn[0].sh), nullptr, nullptr, c.at(L.b[1]), npo, L.Cout,
                              (long)L.Hout * L.Wout, c.s16, c.st));
@@ -536,7 +540,7 @@ int run_wgrad(const Ctx& c, const GemmOp& op, const ConvRef& cv, const float* x,
     hipStream_t ws = c.st;
     LfWgradArgs a;
     a.x = x; a.g = g; a.pro_sc = pro_sc; a.pro_sh = pro_sh; a.s16 = c.s16;
-    a.split = P->precision == 3 ? 9 : (P->precision == 4 ? 6 : 0);
+    a.split = 0;        // (the weight gradient of mode 3 runs on the fp32 matrix cores)
     // Batched mode (default): this weight gradient keeps its partial rows in its own region and its reduction joins the
     // one launch at the end of the pass.  Immediate mode (compact workspaces): summed on the spot from the shared region; the
     // transposed-conv phases' bias rows then accumulate in order.
@@ -785,9 +789,9 @@ int upload_and_pack(const Ctx& c, const float* const* params_dev) {
     if (hipMemcpyAsync(ent, P->packs.data(), P->packs.size() * sizeof(LfPackEntry), hipMemcpyHostToDevice, c.st) != hipSuccess)
         return lf_fail("erfnet: upload of the pack table failed");
     LF_TRY(lf_pack_weights_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed), c.st));
-    if (P->precision == 1 || P->precision == 2)
+    if (P->precision == 2)
         LF_TRY(lf_pack_weights_bf16_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed16), c.st));
-    if (P->precision >= 3)
+    if (P->precision == 3)
         LF_TRY(lf_pack_weights_split_launch(ent, (int)P->packs.size(), params_dev, c.at(P->off_packed48), c.st));
     return 0;
 }
@@ -897,7 +901,9 @@ int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, vo
 }  // extern "C"
 
 namespace {
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ s, float* __restrict__ d, int H, int W,
+// T = the storage type of the NHWC workspace tensor (float, or lf_bf16 in precision mode 2); the NCHW side is always fp32
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ s, float* __restrict__ d, int H, int W,
                                                           int C, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int w = (int)(i % W);
@@ -906,18 +912,22 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
         r /= H;
         const int ch = (int)(r % C);
         const long n = r / C;
-        d[i] = s[((n * H + h) * W + w) * C + ch];
+        d[i] = lf_ld1(s + ((n * H + h) * W + w) * C + ch);
     }
+}
+int nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, int s16, hipStream_t st) {
+    const long total = (long)N * H * W * C;
+    int grid = lf_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    if (s16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<lf_bf16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const lf_bf16*>(src), dst, H, W, C, total);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, src, dst, H, W, C, total);
+    LF_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
 }
 }  // namespace
 
 extern "C" int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W, int C, void* stream) {
-    const long total = (long)N * H * W * C;
-    int grid = lf_cdiv(total, 256);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, total);
-    LF_CHECK_LAUNCH("nhwc_to_nchw");
-    return 0;
+    return nhwc_to_nchw(src, dst, N, H, W, C, 0, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -926,10 +936,13 @@ extern "C" int lf_nhwc_to_nchw(const float* src, float* dst, int N, int H, int W
 // predict), Decoder.forward(input, flag) (BEV/Networks/ERFNet.py:19-22,44-60,86-95,104-107,129-142).  The range runs inside
 // the plan of the whole network at the matching input size: same kernels, same workspace slots, same BatchNorm /
 // Dropout2d handling as the full pass; only the range's parameters are read and only their gradients written.
-// Tensors cross this boundary in the reference's NCHW fp32.  Precision modes with fp32 tensors only.
+// Tensors cross this boundary in the reference's NCHW fp32.  In precision mode 2 (bf16 tensors, round 6) the range's input and
+// the incoming gradient are rounded to bf16 on their way into the workspace (round to nearest even, as every store of that mode)
+// and the output / input gradient are widened on their way out.
 // ---------------------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ s, float* __restrict__ d, int H, int W, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ s, T* __restrict__ d, int H, int W, int C,
                                                           long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % C);
@@ -938,14 +951,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         r /= W;
         const int h = (int)(r % H);
         const long n = r / H;
-        d[i] = s[((n * C + ch) * H + h) * W + w];
+        lf_st1(d + i, s[((n * C + ch) * H + h) * W + w]);
     }
 }
-int nchw_to_nhwc(const float* src, float* dst, int N, int H, int W, int C, hipStream_t st) {
+int nchw_to_nhwc(const float* src, float* dst, int N, int H, int W, int C, int s16, hipStream_t st) {
     const long total = (long)N * H * W * C;
     int grid = lf_cdiv(total, 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid), dim3(256), 0, st, src, dst, H, W, C, total);
+    if (s16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<lf_bf16>, dim3(grid), dim3(256), 0, st, src, reinterpret_cast<lf_bf16*>(dst), H, W, C, total);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, st, src, dst, H, W, C, total);
     LF_CHECK_LAUNCH("nchw_to_nhwc");
     return 0;
 }
@@ -966,7 +980,6 @@ void compact(Ctx& c, int first, int last) {
 int check_range(const lf_erfnet_plan* P, int first, int last, int head, const char* who) {
     LF_REQUIRE(P && first >= 0 && last > first && last <= (int)P->layers.size(), "%s: bad layer range [%d, %d)", who, first, last);
     LF_REQUIRE(head < 0 || (last == (int)P->layers.size() && head < P->n_heads), "%s: the head follows the last layer only", who);
-    LF_REQUIRE(P->precision != 2, "%s: block-level calls take fp32 tensors (precision mode bf16 stores bf16)", who);
     return 0;
 }
 }  // namespace
@@ -1001,15 +1014,16 @@ int lf_erfnet_forward_range(const lf_erfnet_plan* P, int first, int last, int he
     LF_REQUIRE(workspace_bytes >= lf_erfnet_range_workspace_bytes(P, first, last), "lf_erfnet_forward_range: workspace too small");
     Ctx c{P, (float*)workspace, params_host, nullptr, running_host, dropmask, training, (hipStream_t)stream};
     compact(c, first, last);
+    c.s16 = P->precision == 2;
     LF_TRY(upload_and_pack(c, params_dev));
     const Layer& Lf = P->layers[first];
-    if (first > 0) LF_TRY(nchw_to_nhwc(x, c.at(Lf.x), P->N, Lf.Hin, Lf.Win, Lf.Cin, c.st));
+    if (first > 0) LF_TRY(nchw_to_nhwc(x, c.at(Lf.x), P->N, Lf.Hin, Lf.Win, Lf.Cin, c.s16, c.st));
     LF_TRY(forward_layers(c, x, last, first));
     const Layer& Ll = P->layers[last - 1];
     if (head >= 0)
         return lf_head_fwd(c.at(P->head_in), params_host[P->p_head_w[head]], params_host[P->p_head_b[head]], y, P->N, P->H / 2,
-                           P->W / 2, P->Cout + head, 0, c.st);
-    return lf_nhwc_to_nchw(c.at(layer_out_offset(Ll)), y, P->N, Ll.Hout, Ll.Wout, Ll.Cout, stream);
+                           P->W / 2, P->Cout + head, c.s16, c.st);
+    return nhwc_to_nchw(c.at(layer_out_offset(Ll)), y, P->N, Ll.Hout, Ll.Wout, Ll.Cout, c.s16, c.st);
 }
 
 // Backward of lf_erfnet_forward_range on the same workspace: gy = d loss / d y (NCHW, the forward's output shape); gx (NCHW,
@@ -1023,6 +1037,7 @@ int lf_erfnet_backward_range(const lf_erfnet_plan* P, int first, int last, int h
     LF_REQUIRE(workspace_bytes >= lf_erfnet_range_workspace_bytes(P, first, last), "lf_erfnet_backward_range: workspace too small");
     Ctx c{P, (float*)workspace, params_host, grads_host, nullptr, dropmask, training, (hipStream_t)stream};
     compact(c, first, last);
+    c.s16 = P->precision == 2;
     float *gA = c.at(P->off_gA), *gB = c.at(P->off_gB), *gC = c.at(P->off_gC);
     const Layer& Ll = P->layers[last - 1];
     if (head >= 0) {
@@ -1031,18 +1046,18 @@ int lf_erfnet_backward_range(const lf_erfnet_plan* P, int first, int last, int h
         if (grads_host[pw]) {
             const int rows = lf_head_wgrad_rows(P->N, h, w);
             const RowSums rs = row_sum_regions(c, (long)rows * 16 * K * 4, (long)rows * K);
-            LF_TRY(lf_head_wgrad(c.at(P->head_in), gy, rs.wrows, rs.brows, P->N, h, w, K, 0, c.st));
+            LF_TRY(lf_head_wgrad(c.at(P->head_in), gy, rs.wrows, rs.brows, P->N, h, w, K, c.s16, c.st));
             LF_TRY(row_sums_finish(c, rs, rows, 16 * K * 4, grads_host[pw], K, grads_host[pb]));
         }
-        LF_TRY(lf_head_bwd_data(gy, params_host[pw], gA, P->N, h, w, K, 0, c.st));
+        LF_TRY(lf_head_bwd_data(gy, params_host[pw], gA, P->N, h, w, K, c.s16, c.st));
     } else {
-        LF_TRY(nchw_to_nhwc(gy, gA, P->N, Ll.Hout, Ll.Wout, Ll.Cout, c.st));
+        LF_TRY(nchw_to_nhwc(gy, gA, P->N, Ll.Hout, Ll.Wout, Ll.Cout, c.s16, c.st));
     }
     float* gin = nullptr;
     LF_TRY(backward_layers(c, x, gA, gB, gC, last, first, &gin));
     if (!c.reduce_jobs.empty()) LF_TRY(lf_wgrad_reduce_batch_launch(c.reduce_jobs.data(), (int)c.reduce_jobs.size(), c.st));
     const Layer& Lf = P->layers[first];
-    if (gx && first > 0) LF_TRY(lf_nhwc_to_nchw(gin, gx, P->N, Lf.Hin, Lf.Win, Lf.Cin, stream));
+    if (gx && first > 0) LF_TRY(nhwc_to_nchw(gin, gx, P->N, Lf.Hin, Lf.Win, Lf.Cin, c.s16, c.st));
     return 0;
 }
 

@@ -652,20 +652,32 @@ __global__ __launch_bounds__(256) void backproj_kernel(const double* __restrict_
     }
     __syncthreads();
     const double inv = tot[1] != 0.0 ? 1.0 / tot[1] : 0.0;
-    for (int n = threadIdx.x; n < N; n += 256) {
+    // gradient: FOUR lanes per image, each taking every fourth sample height, merged in a fixed order by two butterfly steps
+    // (round 6: one lane per image walked all 56 heights -- 112 dependent fp64 divisions on ONE wave, 43 us per launch and four
+    // launches per step at BASELINE config 3)
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int n = n0 + (int)(threadIdx.x >> 2), q = (int)(threadIdx.x & 3);
+        const bool live = n < N;
+        const int nn = live ? n : 0;
         double g[4] = {0, 0, 0, 0};
-        for (int j = 0; j < S; ++j) {
+        for (int j = q; j < S && live; j += 4) {
             double xp = 0.0;
-            for (int i = 0; i < D; ++i) xp = fma(Y[(long)j * D + i], beta[(long)n * bstride + i], xp);
+            for (int i = 0; i < D; ++i) xp = fma(Y[(long)j * D + i], beta[(long)nn * bstride + i], xp);
             const double t0 = m00 * xp + m01 * yp[j] + m02;
             const double t2 = m20 * xp + m21 * yp[j] + m22;
-            const double v = valid[(long)n * S + j];
-            const double err = (x_gt[(long)n * S + j] - t0 / t2) * v;
+            const double v = valid[(long)nn * S + j];
+            const double err = (x_gt[(long)nn * S + j] - t0 / t2) * v;
             const double dxc = (m00 * t2 - m20 * t0) / (t2 * t2);
             const double gx = -2.0 * err * v * inv * dxc;
             for (int i = 0; i < D; ++i) g[i] = fma(gx, Y[(long)j * D + i], g[i]);
         }
-        for (int i = 0; i < D; ++i) grad[(long)n * D + i] = g[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            g[i] += __shfl_xor(g[i], 1, 64);
+            g[i] += __shfl_xor(g[i], 2, 64);
+        }
+        if (live && q == 0)
+            for (int i = 0; i < D; ++i) grad[(long)n * D + i] = g[i];
     }
 }
 

@@ -59,11 +59,11 @@ __global__ __launch_bounds__(256) void pack_one_split_kernel(const float* __rest
     }
 }
 
-int g_ops_bf16 = 0;     // 0 fp32 cores, 1 / 2 bf16 cores (fp32 / bf16 tensors), 9 / 6 fp32 from split operands on the bf16 cores
+int g_ops_bf16 = 0;     // 0 fp32 cores, 2 bf16 cores on bf16 tensors, 9 fp32 from 9-term split operands on the bf16 cores
 
 // pack into scratch in the order the selected kernel wants; returns the LfTapArgs weight fields
 void pack_conv1d(LfTapArgs& a, const float* w, float* scratch, int C, long sk, long sn, int flip, hipStream_t st) {
-    if (g_ops_bf16 == 9 || g_ops_bf16 == 6) {
+    if (g_ops_bf16 == 9) {
         hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, sk, sn, flip);
         if (C % 32 == 0) {
             hipLaunchKernelGGL(pack_one_split_kernel, dim3(64), dim3(256), 0, st, w, reinterpret_cast<__bf16*>(scratch + 3L * C * C),
@@ -71,10 +71,10 @@ void pack_conv1d(LfTapArgs& a, const float* w, float* scratch, int C, long sk, l
             a.split = g_ops_bf16;
             a.wp48 = scratch + 3L * C * C;
         }
-    } else if (g_ops_bf16) {
+    } else if (g_ops_bf16 == 2) {
         hipLaunchKernelGGL(pack_one_bf16_kernel, dim3(64), dim3(256), 0, st, w, reinterpret_cast<__bf16*>(scratch), C, C, 3, sk, sn, flip);
         a.wp16 = scratch;
-        a.s16 = g_ops_bf16 == 2;
+        a.s16 = 1;
     } else {
         hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, scratch, C, C, 3, sk, sn, flip);
     }
@@ -96,9 +96,10 @@ extern "C" {
 
 void lf_debug_set_split_any_size(int v) { lf_tapgemm_set_split_any_size(v); }
 void lf_debug_set_bf16_lds(int v) { lf_tapgemm_set_bf16_lds(v); }
-// precision mode of the kernel-level conv1d calls below (tests, kbench): 0 fp32, 1 bf16 matrix cores on fp32 tensors,
-// 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy, mask_src then hold bf16 elements; w, bias, gw, gb stay fp32)
-void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = mode; }
+// precision mode of the kernel-level conv1d calls below (tests, kbench): 0 fp32, 2 bf16 matrix cores on bf16 tensors (x, y, gx, gy,
+// mask_src then hold bf16 elements; w, bias, gw, gb stay fp32), 9 fp32 from 9-term split operands; anything else (the removed
+// modes 1 and 6) selects 0
+void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = (mode == 2 || mode == 9) ? mode : 0; }
 
 void lf_debug_set_wgrad_ro(int mode, int cap64, int cap128) { lf_tapwgrad_ro_set(mode, cap64, cap128); }
 
@@ -210,7 +211,7 @@ int conv1d_bwd_weight(const float* x, const float* gy, const float* sc, const fl
     const int pro = sc ? LF_PRO_BNRELU : LF_PRO_NONE;
     LfWgradArgs a;
     a.x = x; a.g = gy; a.pro_sc = sc; a.pro_sh = sh; a.s16 = g_ops_bf16 == 2;
-    a.split = (g_ops_bf16 == 9 || g_ops_bf16 == 6) ? g_ops_bf16 : 0;
+    a.split = 0;
     a.partial = scratch;
     a.bias_partial = gb ? scratch + (long)lf_tapwgrad_splits_bound(g, 1) * 3 * C * C : nullptr;
     int rc = lf_tapwgrad_launch(g, a, pro, st);

@@ -26,6 +26,9 @@
 // No cross-wave reduction: every output has one owner; a workgroup writes its partial row [3][64 of C][C] (fp32), the existing
 // split-K reduction sums the rows in a fixed order.  Bias gradient = column sums of G: one extra MFMA with an all-ones A
 // operand per stage on the wave whose r names the g-tile.
+#include <map>
+#include <mutex>
+
 #include "lf_conv.h"
 #include "lf_ldsdma.h"
 #include "lf_types.h"
@@ -334,12 +337,33 @@ int ro_rows(const LfTapGeom& g, int cap) {
 
 }  // namespace
 
+// cap <= 0 restores the shipped cap (a lowered A/B cap must not stick to later production launches)
 void lf_tapwgrad_ro_set(int mode, int cap64, int cap128) {
     g_ro_mode = mode;
-    if (cap64 > 0) g_ro_cap[0] = cap64;
-    if (cap128 > 0) g_ro_cap[1] = cap128;
+    g_ro_cap[0] = cap64 > 0 ? (cap64 < RO_CAP64 ? cap64 : RO_CAP64) : RO_CAP64;
+    g_ro_cap[1] = cap128 > 0 ? (cap128 < RO_CAP128 ? cap128 : RO_CAP128) : RO_CAP128;
 }
-bool lf_tapwgrad_ro_ok(const LfTapGeom& g, int s16) { return g_ro_mode != 0 && s16 && ro_geom_ok(g); }
+// The kernels need 64-120 KB of dynamic LDS: hipFuncAttributeMaxDynamicSharedMemorySize once per device for all six instantiations,
+// result cached under a mutex (host threads of one process may drive several GPUs).  A device that refuses takes the job form
+// (tapwgrad_kernel) CONSISTENTLY: lf_tapwgrad_ro_ok() is what the launch, lf_tapwgrad_splits_for() and the sizing all ask.
+// Without a current device (plan sizing on a host without GPU) the answer is "yes": the row BOUNDS do not depend on it.
+static bool ro_lds_allowed() {
+    static std::mutex mu;
+    static std::map<int, bool> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find(dev);
+    if (it != done.end()) return it->second;
+    bool ok = true;
+#define LF_RO_ATTR(CH, PROV) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(tapwgrad_ro_kernel<CH, PROV>), \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)RoCfg<CH>::LDS) == hipSuccess
+    LF_RO_ATTR(64, 0); LF_RO_ATTR(64, 1); LF_RO_ATTR(64, 2); LF_RO_ATTR(128, 0); LF_RO_ATTR(128, 1); LF_RO_ATTR(128, 2);
+#undef LF_RO_ATTR
+    if (!ok) (void)hipGetLastError();
+    return done[dev] = ok;
+}
+bool lf_tapwgrad_ro_ok(const LfTapGeom& g, int s16) { return g_ro_mode != 0 && s16 && ro_geom_ok(g) && ro_lds_allowed(); }
 // partial rows the read-once kernel writes for this geometry at the SHIPPED caps (buffer sizing: independent of the A/B switches)
 int lf_tapwgrad_ro_rows_bound(const LfTapGeom& g) { return ro_geom_ok(g) ? ro_rows(g, g.Cs == 128 ? RO_CAP128 : RO_CAP64) : 0; }
 int lf_tapwgrad_ro_rows(const LfTapGeom& g) { return ro_rows(g, g_ro_cap[g.Cs == 128]); }
@@ -350,20 +374,9 @@ int lf_tapwgrad_ro_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hip
     LF_REQUIRE(nsplit <= lf_tapwgrad_ro_rows_bound(g), "tapwgrad_ro: %d partial rows exceed the sized %d", nsplit, lf_tapwgrad_ro_rows_bound(g));
     const int wb = (a.bias_partial != nullptr) | (g_ro_mode & 6);
     const dim3 grid((unsigned)(nsplit * (g.Cs / 64)));
-    // (dynamic LDS beyond 64 KB needs the attribute; per device, checked)
-    static int attr_dev[6] = {-1, -1, -1, -1, -1, -1};
-    auto allow = [&](const void* k, int slot, size_t bytes) -> int {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return lf_fail("tapwgrad_ro: hipGetDevice failed");
-        if (attr_dev[slot] == dev) return 0;
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-            return lf_fail("tapwgrad_ro: cannot reserve %zu bytes of LDS", bytes);
-        attr_dev[slot] = dev;
-        return 0;
-    };
+    LF_REQUIRE(ro_lds_allowed(), "tapwgrad_ro: the device refuses the kernels' dynamic LDS (lf_tapwgrad_ro_ok() says so: take the job form)");
 #define LF_RO(CH, PROV, SLOT)  /* PROV: see the kernel */                                                                                          \
     do {                                                                                                               \
-        if (int rc = allow(reinterpret_cast<const void*>(tapwgrad_ro_kernel<CH, PROV>), SLOT, RoCfg<CH>::LDS)) return rc; \
         hipLaunchKernelGGL((tapwgrad_ro_kernel<CH, PROV>), grid, dim3(CH * 4), RoCfg<CH>::LDS, st, g, a, wb);          \
     } while (0)
     const bool horiz = g.tdw[0] != 0 || g.tdw[1] != 0 || g.tdw[2] != 0;

@@ -134,7 +134,6 @@ class _Plan:
         if not self.handle:
             raise _lib.LaneFitLibraryError("lf_erfnet_plan_create: " + lib.lf_last_error().decode())
         self.handle = ctypes.c_void_p(self.handle)
-        self.ws_bytes = lib.lf_erfnet_workspace_bytes(self.handle)
         self.n_params = lib.lf_erfnet_num_params(self.handle)
         self.n_bn = lib.lf_erfnet_num_bn(self.handle)
         self.n_drop = lib.lf_erfnet_num_dropout(self.handle)
@@ -143,6 +142,11 @@ class _Plan:
         self.drop_ch = [lib.lf_erfnet_dropmask_channels(self.handle, i) for i in range(self.n_drop)]
         self.enc_off = lib.lf_erfnet_encoder_offset(self.handle)
         self.shape = (N, H, W)
+
+    def workspace_bytes(self, precision="fp32"):
+        """Bytes of the whole-network workspace in a precision mode (bf16 tensors need larger partial-row regions): independent
+        of the mode the shared plan was last set to."""
+        return _lib.load().lf_erfnet_workspace_bytes_for(self.handle, _PRECISIONS[precision])
 
     def __del__(self):
         try:
@@ -176,7 +180,7 @@ class _PtrCache:
 
 
 # lf_erfnet_set_precision modes (include/lanefit.h)
-_PRECISIONS = {"fp32": 0, "bf16_mfma": 1, "bf16": 2, "fp32x9": 3, "fp32x6": 4}
+_PRECISIONS = {"fp32": 0, "bf16": 2, "fp32x9": 3}      # (1 and 4 were bf16_mfma / fp32x6: removed in round 6, no BASELINE config used them)
 
 
 class _BackboneFn(torch.autograd.Function):
@@ -187,7 +191,7 @@ class _BackboneFn(torch.autograd.Function):
         dev = x.device
         ctx.precision = _PRECISIONS[net.precision]
         _lib.check(lib.lf_erfnet_set_precision(plan.handle, ctx.precision), "lf_erfnet_set_precision")
-        ctx.ws_bytes = lib.lf_erfnet_workspace_bytes(plan.handle)      # follows the precision mode (partial-row regions of the bf16 weight gradient)
+        ctx.ws_bytes = lib.lf_erfnet_workspace_bytes_for(plan.handle, ctx.precision)      # (the bf16 weight gradient has larger partial-row regions)
         ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=dev)
         # head = -1: encoder only (only_encode=True): no decoder launches, no logits
         logits = (torch.empty(N, net.out_channels + head, H, W, dtype=torch.float32, device=dev) if head >= 0 else
@@ -379,12 +383,11 @@ class Net(nn.Module):
         self._ptr_cache = (None, None)
         self._ptrs = _PtrCache()
         self._flat_grad = None
-        # precision mode: "fp32" (default, the parity path); "bf16_mfma" (conv operands rounded to bf16 in registers,
-        # fp32 accumulation, fp32 tensors); "bf16" (bf16 matrix cores AND bf16 activation / gradient tensors in HBM;
-        # BASELINE config 3 -- the reference has no such mode); "fp32x9" / "fp32x6" (fp32 tensors and accumulation, the
-        # products of the 64- / 128-channel convs formed on the bf16 matrix cores from exact 3-way bf16 splits of both
-        # operands: all 9 partial products, or the 6 above 2^-24 -- fp32 accuracy, held to the fp32 tolerances by the
-        # tests).  Parameters, their gradients and the logits are fp32 in every mode.
+        # precision mode: "fp32" (default, the parity path and the BASELINE headline); "bf16" (bf16 matrix cores AND bf16
+        # activation / gradient tensors in HBM: BASELINE config 3 -- the reference has no such mode); "fp32x9" (fp32 tensors
+        # and accumulation, the products of the 64- / 128-channel convs formed on the bf16 matrix cores from exact 3-way bf16
+        # splits of both operands, all 9 partial products: fp32 accuracy, held to the fp32 tolerances by the tests).
+        # Parameters, their gradients and the logits are fp32 in every mode.
         self.precision = "fp32"
         # encoder_output (N,128,H/8,W/8) is part of the return tuple (zero-copy view); wrappers that never read it
         # may switch it off
@@ -423,8 +426,6 @@ class Net(nn.Module):
         """Run layers [first, last) (+ head) on an NCHW tensor inside the plan of the whole network at the matching size."""
         if not x.is_cuda:
             raise _lib.LaneFitLibraryError("lanefit ERFNet needs its input on the MI355X; there is no CPU path")
-        if self.precision == "bf16":
-            raise NotImplementedError("block-level calls take fp32 tensors: use precision 'fp32', 'bf16_mfma', 'fp32x9' or 'fp32x6'")
         x = x.contiguous().float()
         N, C, h, w = x.shape
         s = _LAYER_IN_STRIDE[first]
@@ -524,7 +525,7 @@ class Net(nn.Module):
         export = self.export_encoder_output
         if only_encode:
             if self.precision == "bf16":
-                raise NotImplementedError("only_encode reads an fp32 encoder output: use precision 'fp32' or 'bf16_mfma'")
+                raise NotImplementedError("only_encode reads an fp32 encoder output: use precision 'fp32' or 'fp32x9'")
             self.export_encoder_output = True
             head = -1                                 # the engine stops after the encoder: decoder BN statistics untouched
         try:

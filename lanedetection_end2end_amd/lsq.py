@@ -61,7 +61,7 @@ class _LaneFitNet(nn.Module):
         # precision mode of the backbone (erfnet.Net.precision): "fp32" unless args.precision says otherwise
         self.net.precision = getattr(args, "precision", "fp32")
         if self.net.precision == "bf16" and self.classification_branch:
-            raise NotImplementedError("the --clas heads read an fp32 encoder output: use precision 'fp32' or 'bf16_mfma'")
+            raise NotImplementedError("the --clas heads read an fp32 encoder output: use precision 'fp32' or 'fp32x9'")
         self.check_singular = True      # False: skip the per-step D2H status read; inspect self.last_status
         self.return_masked = True
         self.last_status = None

@@ -308,7 +308,7 @@ def _train_curve(precision, steps, N, R, K, P, x, lanes, valid):
 
 def test_c3_bf16_training_tracks_fp32():
     """BASELINE config 3 names bf16.  The reference has no reduced-precision mode, so there is no reference result to match;
-    what CAN be tested end to end is that training in the bf16 modes behaves like training in fp32: the same 40 Adam steps
+    what CAN be tested end to end is that training in the bf16 mode behaves like training in fp32: the same 40 Adam steps
     (lr 1e-4, the reference default) on the same 4 x 320 x 640 batch from the same initial weights, backprojection loss on
     4 lanes, train-mode BatchNorm, Dropout off.  Criterion: every loss finite, the loss falls in every mode, and the mean of
     the last ten losses of each bf16 mode is within 5 % of the fp32 run's and the first loss within 2 % (measured on MI355X: 0.02 % / 0.17 % and 0.65 % / 0.61 %) (the per-step losses themselves decorrelate: a
@@ -317,13 +317,13 @@ def test_c3_bf16_training_tracks_fp32():
     P = erfnet_oracle.make_params(seed=5, out_channels=K)
     x = torch.from_numpy(inputs.images(N, R, 2 * R, seed=171))
     lanes, valid = inputs.bp_targets(N, K, 256, seed=172)
-    curves = {m: _train_curve(m, steps, N, R, K, P, x, lanes, valid) for m in ("fp32", "bf16_mfma", "bf16")}
+    curves = {m: _train_curve(m, steps, N, R, K, P, x, lanes, valid) for m in ("fp32", "bf16")}
     ref = curves["fp32"]
     for m, c in curves.items():
         print("%-10s loss: first %.4f  steps 10/20/30 %.4f %.4f %.4f  mean of last ten %.4f" % (m, c[0], c[10], c[20], c[30], c[-10:].mean()))
         assert np.isfinite(c).all(), m
         assert c[-10:].mean() < 0.9 * c[:3].mean(), (m, "loss did not fall")
-    for m in ("bf16_mfma", "bf16"):
+    for m in ("bf16",):
         assert abs(curves[m][0] - ref[0]) <= 0.02 * abs(ref[0]), (m, curves[m][0], ref[0])
         assert abs(curves[m][-10:].mean() - ref[-10:].mean()) <= 0.05 * ref[-10:].mean(), (m, curves[m][-10:].mean(), ref[-10:].mean())
 

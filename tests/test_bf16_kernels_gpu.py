@@ -1,4 +1,5 @@
-"""Race screen of the LDS-DMA bf16 kernels (tapgemm_bf16_wl_kernel, tapgemm_bf16_ring_kernel): their rings are ordered by
+"""Race screen of the LDS-DMA bf16 kernels (tapgemm_bf16_wl_kernel, tapgemm_bf16_ring_kernel and -- round 6 -- the wave-private
+64-channel tapgemm_bf16_wv_kernel, whose per-wave rings have no barrier at all): their rings are ordered by
 hand-counted s_waitcnt vmcnt(N) + bare s_barrier, so a wrong count shows as rare wrong tiles that come and go with shape and
 memory load, not as a failing refcheck.  Every launch of a repeat loop must equal the streaming kernel's result BIT FOR BIT (same
 K order: the same MFMA sequence per accumulator), forward (+bias, ReLU) and data gradient (+ReLU mask of a staged tensor), at the
@@ -13,8 +14,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape", [(64, 128, 40, 80, 1, 8), (64, 128, 40, 80, 0, 4), (64, 64, 80, 160, 1, 1), (32, 128, 32, 64, 1, 16),
-                                   (3, 128, 20, 48, 1, 16), (5, 64, 12, 32, 0, 2)])
+@pytest.mark.parametrize("shape", [(64, 128, 40, 80, 1, 8), (64, 128, 40, 80, 0, 4), (64, 64, 80, 160, 1, 1), (64, 64, 80, 160, 0, 1), (32, 128, 32, 64, 1, 16),
+                                   (3, 128, 20, 48, 1, 16), (5, 64, 12, 32, 0, 2), (3, 64, 20, 48, 1, 2), (2, 64, 8, 16, 0, 1), (7, 64, 10, 80, 1, 1)])
 def test_lds_dma_kernels_equal_the_streaming_kernel_on_every_launch(shape):
     from lanedetection_end2end_amd import _lib
     lib = _lib.load()
@@ -56,7 +57,8 @@ def test_lds_dma_kernels_equal_the_streaming_kernel_on_every_launch(shape):
         # of a bf16 rounding boundary, so the comparison is in norm, not per element)
         assert float(err.norm() / want.norm()) < 3e-3 and float(err.abs().max()) < 0.03 * float(want.abs().max()), (float(err.norm() / want.norm()), float(err.abs().max()))
         repeats = 12 if N * H * W > 100000 else 40
-        for name, mode in (("ring", 2), ("whole-line", 4)):
+        # (mode 3 = the whole-line kernel at both channel counts, 4 = shipped: wave-private kernel at 64 channels, whole-line at 128)
+        for name, mode in (("ring", 2), ("whole-line", 3), ("wave-private (64 ch) / whole-line (128 ch)", 4)):
             bad = []
             for it in range(repeats):
                 y, gx, yp = run(mode)
@@ -69,7 +71,7 @@ def test_lds_dma_kernels_equal_the_streaming_kernel_on_every_launch(shape):
         lib.lf_debug_set_bf16_lds(4)
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 80, 160, 1, 1), (64, 64, 80, 160, 0, 1), (16, 128, 40, 80, 0, 8), (3, 64, 20, 48, 1, 2)])
+@pytest.mark.parametrize("shape", [(64, 64, 80, 160, 1, 1), (64, 64, 80, 160, 0, 1), (16, 128, 40, 80, 0, 8), (3, 64, 20, 48, 1, 2), (5, 64, 12, 32, 0, 1)])
 def test_three_tensor_epilogue_whole_line_kernel(shape):
     """The data gradient that closes a non_bottleneck_1d block's backward (ADD + MASK + BN-backward sums: three epilogue tensors staged
     by LDS-DMA in the whole-line kernel, tapgemm_bf16_wl_kernel<2, 38, 0> at 64 channels) at config 3's own shape 64 x 64 x 80 x 160:
@@ -117,15 +119,16 @@ def test_three_tensor_epilogue_whole_line_kernel(shape):
         assert float((got[1] - s2).abs().max()) < 2e-5 * float((ref[0].double() * aux.double()).abs().sum((0, 1, 2)).max())
         # (the partial SUMS of the two kernels are taken in different orders -- fp32, per tile -- so they agree to rounding, not in bits;
         # the stored values do, and every launch of the whole-line kernel must reproduce its own sums exactly)
-        first = None
-        for it in range(10 if N * H * W > 100000 else 30):
-            gx, stats = run(4)
-            assert torch.equal(gx, ref[0]), "whole-line kernel, launch %d: values differ from the streaming kernel" % it
-            first = stats if first is None else first
-            assert torch.equal(stats, first), "whole-line kernel, launch %d: partial sums differ from its first launch" % it
-        gotw = first.double().sum(0)
-        assert float((gotw[0] - s1).abs().max()) < 2e-5 * float(ref[0].double().abs().sum((0, 1, 2)).max())
-        assert float((gotw[1] - s2).abs().max()) < 2e-5 * float((ref[0].double() * aux.double()).abs().sum((0, 1, 2)).max())
+        for mode in (3, 4):          # 3: whole-line kernel at 64 channels too; 4 (shipped): the wave-private kernel at 64 channels
+            first = None
+            for it in range(10 if N * H * W > 100000 else 30):
+                gx, stats = run(mode)
+                assert torch.equal(gx, ref[0]), "LDS kernel (mode %d), launch %d: values differ from the streaming kernel" % (mode, it)
+                first = stats if first is None else first
+                assert torch.equal(stats, first), "LDS kernel (mode %d), launch %d: partial sums differ from its first launch" % (mode, it)
+            gotw = first.double().sum(0)
+            assert float((gotw[0] - s1).abs().max()) < 2e-5 * float(ref[0].double().abs().sum((0, 1, 2)).max())
+            assert float((gotw[1] - s2).abs().max()) < 2e-5 * float((ref[0].double() * aux.double()).abs().sum((0, 1, 2)).max())
     finally:
         lib.lf_debug_set_ops_precision(0)
         lib.lf_debug_set_bf16_lds(4)

@@ -52,7 +52,9 @@ def test_every_block_kind_against_the_oracle(training):
         prefix, kind, cin, cout, _, d = table[li]
         cin = 3 if cin is None else cin
         h, w = H // stride[li], W // stride[li]
-        rng = np.random.default_rng(100 + li)
+        # (seeds 200 + li: with 100 + li, encoder.layers.9 in train mode has ONE pre-activation inside fp32 rounding of zero -- the
+        # centred BatchNorm statistics of round 6 moved it across: d / d input 1.1e-1 where five other seeds give 2e-7, tools/diag/block9.py)
+        rng = np.random.default_rng(200 + li)
         x = torch.from_numpy(rng.random((N, cin, h, w), dtype=np.float32) + (0 if li == 0 else rng.standard_normal((N, cin, h, w)).astype(np.float32) * 0.5))
         xg = x.cuda().requires_grad_(li > 0)
         y = mods[li](xg)
@@ -83,6 +85,115 @@ def test_every_block_kind_against_the_oracle(training):
         assert e_y < 1e-5 and e_x < 2e-4 and e_p < 2e-4, (prefix, e_y, e_x, e_p)
         worst = max(worst, e_y, e_x, e_p)
     print("worst %.1e" % worst)
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+# one block of every kind and channel count at BASELINE config 3's layer shapes (4 x 320 x 640 input): (layer index, N, C_in, h, w)
+_C3_BLOCKS = [(1, 4, 16, 160, 320), (3, 4, 64, 80, 160), (7, 4, 64, 80, 160), (10, 4, 128, 40, 80), (15, 4, 128, 40, 80),
+              (16, 4, 128, 40, 80), (17, 4, 64, 80, 160), (19, 4, 64, 80, 160), (21, 4, 16, 160, 320)]
+
+
+def _block_state(net, y, li, prefix, kind, N, cout, ho, wo):
+    """The block's saved forward tensors (bf16 elements in the COMPACT range workspace the call owns until its backward), keyed like
+    the oracle's taps; for a non_bottleneck_1d also bn1's folded (scale, shift), with which the engine decided relu(bn1(t2))."""
+    from lanedetection_end2end_amd import _lib
+    lib = _lib.load()
+    ws = y.grad_fn.ws
+    plan = y.grad_fn.plan
+    lo = lib.lf_erfnet_activation_offset(plan.handle, li - 1, {"down": 1, "nb1d": 4, "up": 1}[erfnet_oracle.layer_table()[li - 1][1]])   # = the block's input slot
+    n = N * ho * wo * cout
+    out = {}
+    nslots = {"down": 2, "nb1d": 5, "up": 2}[kind]
+    for slot in range(nslots):
+        off = lib.lf_erfnet_activation_offset(plan.handle, li, slot) - lo
+        t = ws.view(torch.bfloat16)[2 * off: 2 * off + n].view(N, ho, wo, cout).permute(0, 3, 1, 2).float().cpu()
+        out[prefix if slot == nslots - 1 else "%s#%d" % (prefix, slot)] = t
+    if kind == "nb1d":
+        vec = []
+        for which in (0, 1):
+            off = lib.lf_erfnet_bn_vector_offset(plan.handle, li, 0, which) - lo
+            vec.append(ws.view(torch.float32)[off: off + cout].clone().cpu())
+        out[prefix + "#bn1"] = tuple(vec)
+    return out
+
+
+@pytest.mark.parametrize("li,N,cin,h,w", _C3_BLOCKS)
+def test_bf16_blocks_at_config3_shapes(li, N, cin, h, w):
+    """precision mode "bf16" at the block level.  The whole-network bf16 backward test sits behind 38
+    BatchNorm backwards that amplify the 2^-9 rounding of every stored gradient (one tensor moves 7e-3 .. 9e-2 with the seed); a
+    single block has NO such chain, so a mis-scaled tap, a wrong mask or a wrong BatchNorm-backward term at config 3's own layer
+    shapes shows at the bf16 rounding level.  Every block kind at the shapes BASELINE config 3 gives it (4 x 3 x 320 x 640), train
+    mode: input, upstream gradient and convolution weights rounded to bf16 on BOTH sides (what the engine's tensors and MFMA
+    operands hold).
+      * forward: output against the fp64 block oracle on those operands (what differs: the bf16 rounding of t1 .. t4, 2^-9 each);
+      * backward: the fp64 oracle evaluated STRAIGHT-THROUGH at the engine's own forward state (its saved bf16 tensors and the ReLU
+        masks it decided, read back from the call's compact workspace) -- a plain fp64 backward flips ~0.3 % of the mask elements
+        against a forward that rounds its pre-activations to bf16, and sqrt(0.003) = 5 % of relative L2 is what that measured
+        (8e-2 on d / d input) -- so that what remains is backward arithmetic and the rounding of the stored gradients."""
+    net, P = _build(out_channels=4)
+    table = erfnet_oracle.layer_table()
+    prefix, kind, _, cout, _, d = table[li]
+    mods = [net.encoder.initial_block] + list(net.encoder.layers) + list(net.decoder.layers)
+    # convolution weights as the bf16 matrix cores see them (the engine packs RNE-rounded copies; biases and BatchNorm stay fp32)
+    Pr = {k: (_bf16(v) if (k.startswith(prefix + ".") and k.endswith(".weight") and v.dim() == 4) else v.clone()) for k, v in P.items()}
+    net.load_state_dict(Pr)
+    net.precision = "bf16"
+    net.train()
+    rng = np.random.default_rng(300 + li)
+    x = _bf16(torch.from_numpy(rng.random((N, cin, h, w), dtype=np.float32) + rng.standard_normal((N, cin, h, w)).astype(np.float32) * 0.5))
+    xg = x.cuda().requires_grad_(True)
+    y = mods[li](xg)
+    _, _, ho, wo = y.shape
+    state = _block_state(net, y, li, prefix, kind, N, cout, ho, wo)
+    assert torch.equal(state[prefix], y.detach().cpu())              # the workspace mapping of this test reads the right tensors
+    gy = _bf16(torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)))
+    for p in net.parameters():
+        p.grad = None
+    (y * gy.cuda()).sum().backward()
+    Pd = erfnet_oracle.cast_params(Pr, torch.float64)
+    own = [k for k in Pd if k.startswith(prefix + ".") and Pd[k].is_floating_point() and "running" not in k]
+    # forward, plain fp64 on the rounded operands
+    with torch.no_grad():
+        yd = _oracle_block(kind, x.double(), Pd, prefix, d, True)
+    e_y = _rel_l2(y.detach().cpu(), yd)
+    # backward, straight-through at the engine's forward state
+    for k in own:
+        Pd[k].requires_grad_(True)
+    xd = x.double().requires_grad_(True)
+    fn = {"down": erfnet_oracle._down, "up": erfnet_oracle._up}.get(kind)
+    ys = fn(xd, Pd, prefix, True, None, None, state) if fn else erfnet_oracle._nb1d(xd, Pd, prefix, d, True, None, None, None, state)
+    ys = erfnet_oracle._tap(None, state, prefix, ys)
+    (ys * gy.double()).sum().backward()
+    e_x = _rel_l2(xg.grad.cpu(), xd.grad)
+    named = dict(net.named_parameters())
+    gmax = max(float(Pd[k].grad.abs().max()) for k in own)
+    e_p, worst_k, e_b, worst_b = 0.0, None, 0.0, None
+    for k in own:
+        if float(Pd[k].grad.abs().max()) < 1e-6 * gmax:
+            continue                          # conv biases in front of a train-mode BatchNorm: analytically zero
+        e = _rel_l2(named[k].grad.cpu(), Pd[k].grad)
+        # Sums that CANCEL behind a BatchNorm backward (its output has zero mean and zero x-hat component over the batch): the biases of
+        # conv3x1_1 / conv3x1_2, and the weights of the convolution in front of a BatchNorm (sum x * g of what that backward left of
+        # g).  They keep ~1 / sqrt(pixels) of their terms, which amplifies the 2^-9 of the stored gradient: 1.6e-2 / 2.0e-2 at
+        # 4 x 160 x 320 x 16, <= 5e-3 at the other shapes -- gated on their own
+        if k.endswith(("conv3x1_1.bias", "conv3x1_2.bias", "conv1x3_1.weight", "conv1x3_2.weight")):
+            if e > e_b:
+                e_b, worst_b = e, k
+        elif e > e_p:
+            e_p, worst_k = e, k
+    print("bf16 %-26s %-5s (%d, %d, %d, %d): out %.2e  d/d input %.2e  parameter gradients %.2e (%s)  cancelling sums %.2e   [2^-8 = 3.9e-3]"
+          % (prefix, kind, N, cin, h, w, e_y, e_x, e_p, worst_k, e_b))
+    others = [k for k, p in named.items() if not k.startswith(prefix + ".") and p.grad is not None]
+    assert not others, others
+    # measured (round 6, all nine blocks): out 2.2e-3 .. 4.8e-3, d / d input 2.3e-3 .. 3.9e-3, parameter gradients 1.8e-3 .. 5.4e-3
+    assert e_y < 2 ** -7 and e_x < 2 ** -7 and e_p < 2 ** -7 and e_b < 2 ** -5, (prefix, e_y, e_x, e_p, worst_k, e_b, worst_b)
 
 
 def test_encoder_and_decoder_compose_to_the_network():

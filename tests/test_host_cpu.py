@@ -41,7 +41,12 @@ def test_plan_matches_model():
         assert plan.n_bn == len(net._batchnorms()) == 39
         assert plan.n_drop == len(net._dropouts()) == 13
         assert plan.drop_floats == 32 * (5 * 64 + 8 * 128)
-        assert plan.ws_bytes < 16 << 30
+        # sized per precision mode, independent of the mode the plan was last set to
+        f32, b16 = plan.workspace_bytes("fp32"), plan.workspace_bytes("bf16")
+        assert 0 < f32 < 16 << 30 and f32 == plan.workspace_bytes("fp32x9") and b16 > f32      # read-once weight gradient: larger partial-row regions
+        assert lib.lf_erfnet_set_precision(plan.handle, 2) == 0 and plan.workspace_bytes("fp32") == f32
+        assert lib.lf_erfnet_workspace_bytes(plan.handle) == b16 and lib.lf_erfnet_workspace_bytes_for(plan.handle, 1) == 0
+        assert lib.lf_erfnet_set_precision(plan.handle, 1) != 0 and lib.lf_erfnet_set_precision(plan.handle, 4) != 0    # removed modes
         assert sum(net._used_param_mask(0)) == 228 - 2
     assert not lib.lf_erfnet_plan_create(1, 100, 200, 3, 2, 1)        # H % 16 != 0 -> error, no crash
     assert b"unsupported" in lib.lf_last_error()

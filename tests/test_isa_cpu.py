@@ -41,6 +41,7 @@ def test_no_vgpr_spills_in_network_kernels(conv_kernels):
     hot += _select(conv_kernels, "tapgemm_bf16_kernel<")
     hot += _select(conv_kernels, "tapgemm_bf16_ring_kernel<")
     hot += _select(conv_kernels, "tapgemm_bf16_wl_kernel<")
+    hot += _select(conv_kernels, "tapgemm_bf16_wv_kernel<")
     hot += _select(conv_kernels, "tapgemm_bf16_lean_kernel<")
     hot += _select(conv_kernels, "tapwgrad_kernel<")
     hot += _select(conv_kernels, "tapwgrad16_kernel<")
@@ -70,6 +71,11 @@ def test_register_budgets(conv_kernels):
     # the bf16 LDS kernels run two workgroups per CU (<= 256 registers; their LDS budgets are checked by the launcher's occupancy query)
     for k in _select(conv_kernels, "tapgemm_bf16_ring_kernel<") + _select(conv_kernels, "tapgemm_bf16_wl_kernel<"):
         assert k["vgpr"] + k["agpr"] <= 256 and k["scratch"] == 0, (k["name"], k["vgpr"], k["scratch"])
+    # the wave-private 64-channel kernel: two workgroups per CU (<= 256 registers) except with two staged operand tiles / run-time flags
+    # (one workgroup per CU by LDS: the whole register file instead of spills)
+    for k in _select(conv_kernels, "tapgemm_bf16_wv_kernel<"):
+        two = not any(k["name"].startswith("tapgemm_bf16_wv_kernel<%s>" % e) for e in ("-1", "34", "38"))
+        assert k["vgpr"] + k["agpr"] <= (256 if two else 512) and k["scratch"] == 0, (k["name"], k["vgpr"], k["agpr"], k["scratch"])
     # the phase-stamp code exists only in the DBG instantiations
     dbg = [k["name"] for k in conv_kernels if k["name"].endswith(", true>") and k["name"].startswith(("tapgemm_kernel<", "tapwgrad_kernel<"))
            and k["name"].count("true>")]

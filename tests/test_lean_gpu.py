@@ -71,8 +71,16 @@ def test_every_epilogue_of_the_16_channel_kernel(shape):
         assert torch.isfinite(got).all(), name
         err = float((got.double() - ref).abs().max()) / float(ref.abs().max())
         assert err < 2e-6, "%s: %.2e" % (name, err)
-    # partial rows: [rows][0] = sum v, [rows][1] = sum v^2 (BN forward) or sum v * aux (BN backward, raw), over the values as stored
-    for name, st_rows, v, second in (("BN forward sums", s8, y8, y8), ("mask + BN-backward sums", s34, g34, aux),
+    # BN forward rows (round 6, centred): [rows][0] = sum v, [rows][1] = M2 = sum (v - mean_row)^2 over the row's own 256-pixel tile
+    # (the last one ragged) -- each row against fp64 on the stored values, M2 relative to itself (no (mean / sigma)^2 term)
+    flat = y8.double().reshape(-1, C)
+    for r in range(nrows):
+        t = flat[r * 256: (r + 1) * 256]
+        m2 = ((t - t.mean(0)) ** 2).sum(0)
+        assert float(((s8[r, 0].double() - t.sum(0)).abs() / t.abs().sum(0)).max()) < 2e-6, ("BN forward sums, row %d" % r)
+        assert float(((s8[r, 1].double() - m2).abs() / m2).max()) < 5e-6, ("BN forward M2, row %d" % r)
+    # BN backward rows: [rows][0] = sum v, [rows][1] = sum v * aux (raw), over the values as stored
+    for name, st_rows, v, second in (("mask + BN-backward sums", s34, g34, aux),
                                      ("recomputed-BN mask + sums", s48, g48, aux), ("three-tensor epilogue", s38, g38, aux)):
         assert torch.isfinite(st_rows).all(), name
         got = st_rows.double().sum(0)

@@ -49,21 +49,24 @@ def main():
             w = torch.randn(C, C, 3, device="cuda") * (2.0 / (3 * C)) ** 0.5
             b = torch.randn(C, device="cuda")
             scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096, device="cuda")
+            sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.5
             res, tim = {}, {}
-            # lf_debug_set_bf16_lds: 0 streaming kernel only / 2 the ring for every launch it takes / 4 whole-line kernel where it applies (shipped)
-            modes = [("streaming", 0), ("ring", 2), ("whole-line", 4)]
+            # lf_debug_set_bf16_lds: 0 streaming kernel only / 2 the ring for every launch it takes / 3 whole-line kernel at 64 AND 128 channels
+            # (round 5's routing) / 4 shipped: the wave-private kernel at 64 channels, the whole-line kernel at 128
+            modes = [("streaming", 0), ("ring", 2), ("whole-line", 3), ("shipped", 4)]
             for name, mode in modes:
                 lib.lf_debug_set_bf16_lds(mode)
-                y, gx = torch.empty_like(x), torch.empty_like(x)
+                y, gx, yp = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
                 f = lambda: _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 1, P(scratch), st), "fwd")
                 g = lambda: _lib.check(lib.lf_conv1d_bwd_data(P(gy), P(w), P(x), P(gx), N, H, W, C, axis, d, P(scratch), st), "dgrad")
-                tim[name] = (timeit(f, a.iters), timeit(g, a.iters))
-                res[name] = (y.clone(), gx.clone())
-            same = all(torch.equal(res["streaming"][0], r[0]) and torch.equal(res["streaming"][1], r[1]) for r in res.values())
+                fp = lambda: _lib.check(lib.lf_debug_conv1d_fwd_pro(P(x), P(w), P(b), P(sc), P(sh), P(yp), N, H, W, C, axis, d, P(scratch), st), "fwd + prologue")
+                tim[name] = (timeit(f, a.iters), timeit(g, a.iters), timeit(fp, a.iters))
+                res[name] = (y.clone(), gx.clone(), yp.clone())
+            same = all(torch.equal(res["streaming"][0], r[0]) and torch.equal(res["streaming"][1], r[1]) and torch.equal(res["streaming"][2], r[2]) for r in res.values())
             nbytes = 2 * N * H * W * C * 2
             best = min(t[0] for t in tim.values())
             print("N=%2d C=%3d %3dx%3d axis %d dil %2d | %s | bit-identical %s | best fwd %.2f TB/s algorithmic (launch + pack included)"
-                  % (N, C, H, W, axis, d, " | ".join("%s fwd %6.1f dgrad %6.1f us" % (k, v[0], v[1]) for k, v in tim.items()), same,
+                  % (N, C, H, W, axis, d, " | ".join("%s fwd %6.1f dgrad %6.1f pro %6.1f us" % (k, v[0], v[1], v[2]) for k, v in tim.items()), same,
                      nbytes / best / 1e6), flush=True)
             for r in res.values():
                 assert torch.isfinite(r[0].float()).all()

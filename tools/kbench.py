@@ -3,7 +3,7 @@
 HIP-event timed, as TFLOP/s against the fp32 MFMA peak.  Also checks each result against torch (on the
 GPU, fp32) so that a faster variant that is wrong is caught immediately.
 
-    python tools/kbench.py [--iters 300] [--bf16 | --split 9] [--one C H W AXIS DIL]
+    python tools/kbench.py [--iters 300] [--split 9] [--one C H W AXIS DIL]
     python tools/kbench.py --phases [--wgrad]      per-wave phase stamps, waves paired up by the SIMD they ran on
 """
 import argparse
@@ -41,10 +41,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--bf16", action="store_true", help="bf16 matrix-core kernel for fwd / dgrad; the torch check runs on "
-                    "bf16-rounded operands (products exact in fp32, so the tolerance stays at fp32 level)")
-    ap.add_argument("--split", type=int, default=0, choices=[0, 6, 9], help="fp32 from 3-way split operands on the bf16 matrix "
-                    "cores (9 or 6 partial products); checked against the plain fp32 torch result")
+    ap.add_argument("--split", type=int, default=0, choices=[0, 9], help="fp32 from 3-way split operands on the bf16 matrix "
+                    "cores (all 9 partial products); checked against the plain fp32 torch result")
     ap.add_argument("--one", type=int, nargs=5, metavar=("C", "H", "W", "AXIS", "DIL"), help="run a single shape (for PMC passes)")
     ap.add_argument("--miopen", action="store_true", help="also time the vendor library on the same problems (torch conv2d forward / "
                     "input gradient / weight gradient through MIOpen, NCHW fp32 as the reference runs it) and print its us")
@@ -79,13 +77,7 @@ def main():
                                               dilation=dil)
             gw64 = torch.nn.grad.conv2d_weight(xn.detach().double(), w4.shape, gy.permute(0, 3, 1, 2).double().contiguous(),
                                                padding=pad, dilation=dil)
-        lib.lf_debug_set_ops_precision(a.split if a.split else (1 if a.bf16 else 0))
-        if a.bf16:
-            rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
-            with torch.no_grad():
-                yr = F.conv2d(rb(xn), rb(w4), b, padding=pad, dilation=dil)
-                gx_ref = torch.nn.grad.conv2d_input(xn.shape, rb(w4), rb(gy.permute(0, 3, 1, 2).contiguous()), padding=pad,
-                                                    dilation=dil)
+        lib.lf_debug_set_ops_precision(a.split)
         for v in (2,):
             f = lambda: _lib.check(lib.lf_conv1d_fwd(P(x), P(w), P(b), P(y), N, H, W, C, axis, d, 0, P(scratch), st), "fwd")
             tf = timeit(f, a.iters)
