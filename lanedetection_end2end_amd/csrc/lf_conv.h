@@ -53,12 +53,14 @@ struct LfTapArgs {
     const float* asc;       // (unused since round 3: the BatchNorm-backward sums are written raw)
     const float* ash;
     const float* dm;        // optional Dropout2d keep-mask [N][Cd] applied to the STATS_XHAT sums only (gm = v * dm)
-    float* stats;           // [rows][2][Cd] per-workgroup partial sums, rows = lf_tapgemm_stat_rows()
+    float* stats;           // per-workgroup partial sums, channel-major: [2][Cd][stats_ld], row r = 256-pixel tile r of the launch
+    int stats_ld;           //   (rows = lf_tapgemm_stat_rows(); stats_ld >= rows: lf_eltwise.h, LfStatPart)
     unsigned long long* dbg;  // optional: per-wave phase timestamps (s_memtime), 8 words per wave (tools/kbench.py --phases)
 };
 
 void lf_tapgemm_set_split_any_size(int v);
 void lf_tapgemm_set_bf16_lds(int v);
+void lf_tapwgrad_set_pair(int v);      // tools / A-B runs: 1 (shipped) paired-job workgroups of the fp32 weight gradient, 0 one job per workgroup
 int lf_tapgemm_stat_rows(const LfTapGeom& g);                          // upper bound over the kernels (buffer sizing)
 int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a);  // rows the launch with these arguments writes
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);

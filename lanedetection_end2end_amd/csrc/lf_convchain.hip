@@ -169,7 +169,8 @@ lf_convchain_plan* lf_convchain_plan_create(int N, int H, int W, int nlayers, co
     P->stat_floats = lf_maxl(P->stat_floats, (long)lf_bn_bwd_reduce_rows(npix) * 2 * cmax);
     P->off_entries = ws.take((long)(P->packs.size() * sizeof(LfPackEntry) + 3) / 4);
     P->off_packed = ws.take(P->packed_floats);
-    P->off_stat = ws.take(P->stat_floats);
+    P->stat_floats += 2L * cmax * 4;                 // (channel-major rows: leading dimensions are rounded up to 4)
+    P->off_stat = ws.take((P->stat_floats + 3) / 4 * 4);
     P->off_wpart = ws.take(P->wpart_floats);
     P->off_bpart = ws.take(P->bpart_floats);
     P->gbuf_floats = npix * cmax;
@@ -204,12 +205,12 @@ int lf_convchain_forward(const lf_convchain_plan* P, const float* x, const float
         a.dst = ws + P->z[i];
         a.wp = ws + P->off_packed + P->packs[P->pk_fwd[i]].dst_off;
         a.bias = params_host[4 * i + 1];
-        a.stats = stat;
+        a.stats = stat; a.stats_ld = lf_stat_ld(lf_tapgemm_stat_rows(P->fwd[i]));
         int pro = LF_PRO_NONE;
         if (i > 0) { a.pro_sc = ws + P->sc[i - 1]; a.pro_sh = ws + P->sh[i - 1]; pro = LF_PRO_BNRELU; }
         LF_TRY(lf_tapgemm_launch(P->fwd[i], a, pro, training ? LF_EPI_STATS_SQ : 0, st));
         const int srows = lf_tapgemm_stat_rows_for(P->fwd[i], a);
-        LfStatPart part = lf_stat_part_tiles(stat, srows, P->C[i + 1], 0, srows, npix);      // centred rows (LfStatPart)
+        LfStatPart part = lf_stat_part_tiles(stat, srows, a.stats_ld, P->C[i + 1], 0, srows, npix);      // centred rows (LfStatPart)
         LF_TRY(lf_bn_finalize_fwd(&part, 1, P->C[i + 1], (double)npix, params_host[4 * i + 2], params_host[4 * i + 3],
                                   running_host[2 * i], running_host[2 * i + 1], momentum, eps, training, ws + P->sc[i],
                                   ws + P->sh[i], ws + P->asc[i], ws + P->ash[i], st));
@@ -234,8 +235,9 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
     float *A = ws + P->off_gA, *B = ws + P->off_gB;
     // last block: BatchNorm + ReLU backward from the saved output
     int l = P->L - 1;
-    LF_TRY(lf_bn_bwd_reduce(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], nullptr, stat, npix, P->C[l + 1], ppi, 0, st));
-    LfStatPart rp = {stat, lf_bn_bwd_reduce_rows(npix), P->C[l + 1], 0};
+    const int rrows = lf_bn_bwd_reduce_rows(npix);
+    LF_TRY(lf_bn_bwd_reduce(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], nullptr, stat, lf_stat_ld(rrows), npix, P->C[l + 1], ppi, 0, st));
+    LfStatPart rp = {stat, rrows, P->C[l + 1], 0, lf_stat_ld(rrows)};
     LF_TRY(lf_bn_bwd_finalize(&rp, 1, P->C[l + 1], (double)npix, ws + P->asc[l], ws + P->ash[l], ws + P->c1[l], ws + P->c2[l],
                               grads_host[4 * l + 2], grads_host[4 * l + 3], training, st));
     LF_TRY(lf_bn_bwd_apply(gy, y, ws + P->z[l], ws + P->asc[l], ws + P->ash[l], params_host[4 * l + 2], ws + P->c1[l],
@@ -269,9 +271,9 @@ int lf_convchain_backward(const lf_convchain_plan* P, const float* x, const floa
         const int j = i - 1;
         a.dst = other;
         a.aux = ws + P->z[j]; a.msc = ws + P->sc[j]; a.msh = ws + P->sh[j]; a.asc = ws + P->asc[j]; a.ash = ws + P->ash[j];
-        a.stats = stat;
+        a.stats = stat; a.stats_ld = lf_stat_ld(lf_tapgemm_stat_rows(P->dg[i]));
         LF_TRY(lf_tapgemm_launch(P->dg[i], a, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, st));
-        LfStatPart sp = {stat, lf_tapgemm_stat_rows_for(P->dg[i], a), P->C[i], 0};
+        LfStatPart sp = {stat, lf_tapgemm_stat_rows_for(P->dg[i], a), P->C[i], 0, a.stats_ld};
         LF_TRY(lf_bn_bwd_finalize(&sp, 1, P->C[i], (double)npix, ws + P->asc[j], ws + P->ash[j], ws + P->c1[j], ws + P->c2[j],
                                   grads_host[4 * j + 2], grads_host[4 * j + 3], training, st));
         LF_TRY(lf_bn_bwd_apply(other, nullptr, ws + P->z[j], ws + P->asc[j], ws + P->ash[j], params_host[4 * j + 2],

@@ -27,18 +27,21 @@ int lf_debug_conv1d_fwd_pro(const float* x, const float* w, const float* bias, c
 /* the read-once bf16 weight gradient (lf_wgrad_ro.hip): mode 0 = off (tapwgrad_kernel's job form takes every launch), 1 = shipped;
  * cap64 / cap128 > 0: workgroups per launch at 64 / 128 channels (A/B runs; at most the shipped 512 / 256 the buffers are sized for) */
 void lf_debug_set_wgrad_ro(int mode, int cap64, int cap128);
+/* the fp32 weight gradient at two 64-channel g-blocks: 1 (shipped) = 8-wave workgroups running the two jobs that share an X stream side by
+ * side; 0 = one job per 4-wave workgroup (round 5's form) -- A/B runs (tools/wgrad_traffic.py) */
+void lf_debug_set_wgrad_pair(int v);
 /* lf_conv1d_bwd_weight with the BN+ReLU operand prologue on x (the weight gradient of a non_bottleneck_1d block's third convolution):
  * gw = d/dw of conv1d(relu(x * sc + sh)), gb = column sums of gy */
 int lf_debug_conv1d_wgrad_pro(const float* x, const float* gy, const float* sc, const float* sh, float* gw, float* gb, int N, int H, int W,
                               int C, int axis, int dilation, float* scratch, void* stream);
 /* lf_conv1d_bwd_data with the THREE-TENSOR epilogue of the network's last data gradient per block (ADD + MASK + BN-backward sums,
  * ERFNet.py:44-60 backward): gx = (conv1d^T(gy) + add_src) * [mask_src > 0]; stats receives the per-tile partial rows
- * [rows][2][C] = (sum gx, sum gx * aux) -- raw, as lf_bn_bwd_finalize consumes them.  Returns the number of rows, -1 on error. */
+ * [2][C][rows] (channel-major: element (kind, c, row)) = (sum gx, sum gx * aux) -- raw, as lf_bn_bwd_finalize consumes them.  Returns the number of rows, -1 on error. */
 int lf_debug_conv1d_bwd_data_epi3(const float* gy, const float* w, const float* mask_src, const float* add_src, const float* aux,
                                   float* gx, float* stats, int N, int H, int W, int C, int axis, int dilation, float* scratch, void* stream);
 /* one convolution launch with any epilogue flag set of csrc/lf_conv.h (1 ReLU, 2 mask by mask_src > 0, 4 + add_src, 8 BN forward sums,
  * 16 mask by aux * msc + msh > 0, 32 BN-backward sums over aux); transposed = 1: the data gradient's weights.  Returns the number of
- * statistics rows written ([rows][2][C]), 0 without a sums flag, -1 on error.  (tests/test_lean_gpu.py) */
+ * statistics rows written (channel-major [2][C][rows]; BN forward sums: kind 1 = M2 about the row's own mean), 0 without a sums flag, -1 on error.  (tests/test_lean_gpu.py) */
 int lf_debug_conv1d_epi(const float* src, const float* w, const float* bias, float* dst, int transposed, int epi, const float* mask_src,
                         const float* add_src, const float* aux, const float* msc, const float* msh, float* stats, int N, int H, int W, int C,
                         int axis, int dilation, float* scratch, void* stream);

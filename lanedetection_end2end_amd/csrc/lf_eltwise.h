@@ -5,8 +5,9 @@
 #pragma once
 #include "lf_common.h"
 
-struct LfStatPart {   // one source of per-channel partial sums: rows x 2 x C floats
-    const float* rows; int nrows; int C; int ch_off;
+struct LfStatPart {   // one source of per-channel partial sums, CHANNEL-MAJOR (round 6): [2][C][ld] floats, element (kind, c, row)
+                      // = rows[(kind * C + c) * ld + row]; ld >= nrows, a multiple of 4 (the finalise kernels take four rows per load)
+    const float* rows; int nrows; int C; int ch_off; int ld;
     // tile_pix = 0: RAW rows [sum v][sum v^2] (or [sum g][sum g t] for the backward sums).
     // tile_pix > 0: CENTRED rows of the tap-GEMM epilogues (round 6): [sum v][M2 = sum (v - mean_row)^2] where row r covers pixels
     // (r % seg_rows) * tile_pix .. + tile_pix - 1 of a launch of seg_pix pixels (the four sub-pixel phases of a transposed
@@ -14,8 +15,9 @@ struct LfStatPart {   // one source of per-channel partial sums: rows x 2 x C fl
     // sum v^2 = M2_r + (sum v)_r^2 / n_r, so the fp32 partials never hold a sum of squares about the origin.
     int tile_pix = 0; int seg_rows = 0; long seg_pix = 0;
 };
-inline LfStatPart lf_stat_part_tiles(const float* rows, int nrows, int C, int ch_off, int seg_rows, long seg_pix, int tile_pix = 256) {
-    LfStatPart p = {rows, nrows, C, ch_off};
+inline int lf_stat_ld(int nrows) { return (nrows + 3) / 4 * 4; }      // the leading dimension the engine gives a use of the statistics buffers
+inline LfStatPart lf_stat_part_tiles(const float* rows, int nrows, int ld, int C, int ch_off, int seg_rows, long seg_pix, int tile_pix = 256) {
+    LfStatPart p = {rows, nrows, C, ch_off, ld};
     p.tile_pix = tile_pix; p.seg_rows = seg_rows; p.seg_pix = seg_pix;
     return p;
 }
@@ -35,7 +37,7 @@ int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm,
 // DESIGN.md section 2 -- so the raw form, which keeps the epilogues free of per-channel vectors, stays.
 int lf_bn_bwd_reduce_rows(long npix);
 int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* dm,
-                     float* rows, long npix, int C, long pix_per_image, int s16, hipStream_t st);
+                     float* rows, int ld, long npix, int C, long pix_per_image, int s16, hipStream_t st);
 // partial rows -> c1 = sum/M, c2 = sumx/M (both 0 when the forward ran in eval mode: running statistics, no mean terms),
 // and the parameter gradients ggamma = sumx, gbeta = sum
 // rows = [sum g, sum g * t] (RAW, t = the pre-BatchNorm tensor; asc / ash = rstd, -mean * rstd turn them into sum g * xhat in fp64)
@@ -48,14 +50,14 @@ int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float*
 
 // DownsamplerBlock pool branch: cat[..., choff:choff+Cin] = maxpool2x2(x), + stat partial rows
 int lf_pool_rows(long npix_out);
-int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat, int cat_pix, int choff, float* rows,
+int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat, int cat_pix, int choff, float* rows, int ld,
                        int s16, hipStream_t st);
 int lf_pool_bwd(const float* x, const float* gcat, int N, int H, int W, int Cin, int cat_pix, int choff, float* gx,
                 int s16, hipStream_t st);
 
 // stem: DownsamplerBlock(3,16) on the NCHW input image: conv3x3 s2 (3->13) || maxpool -> cat (N,H/2,W/2,16)
 int lf_stem_rows(int N, int H, int W);
-int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, const float* b, float* cat, float* rows,
+int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, const float* b, float* cat, float* rows, int ld,
                 int s16, hipStream_t st);
 int lf_stem_wgrad_rows(int N, int H, int W);
 int lf_stem_wgrad(const float* img, const float* gcat, int N, int Cin, int H, int W, float* wrows, float* brows,

@@ -47,99 +47,78 @@ __device__ __forceinline__ void block_reduce_quads(f32x4 (&a1)[NQ], f32x4 (&a2)[
 
 struct StatParts { LfStatPart p[2]; int n; };
 
-// Column sums of the partial rows for the 4 channels c0..c0+3 by one FIN_THREADS-thread block: thread t takes rows t, t + FIN_THREADS, ... as
-// 16-byte loads (independent: all in flight at once), fp64 accumulation, wave shuffle + 4-slot LDS combine, fixed order.
-// (The first version -- 16 channels x 64 row groups per 1024-thread block, scalar loads, a 64-step serial combine -- ran on 4-8
-// workgroups: 7 us for a kernel that is pure latency.)
-// (256 threads.  1024 were measured in round 5 -- four times the rows in flight per workgroup -- and are SLOWER: 9.7 vs 7.1 us at
-// batch 32, 14.1 vs 12.0 at config 3: the kernel's time is its launch, one or two memory round trips and the fp64 shuffle /
-// combine / divide tail that every wave runs, not the row loop)
+// Column sums of the partial rows of ONE channel by one FIN_THREADS-thread block.  The rows are stored CHANNEL-MAJOR (round 6):
+// [2][C][ld] -- a channel's partial sums are one contiguous run of nrows floats per kind -- so a thread takes four consecutive rows
+// of both kinds as two 16-byte loads, two such pairs in flight (2048 rows per trip), fp64 accumulation, wave shuffle + 4-slot LDS
+// combine, fixed order.  Through round 5 the layout was [rows][2][C] and a block took 4 channels = 16 bytes of every 256- /
+// 512-byte row half: every 128-byte line of the rows was fetched by 8 different blocks (16-32 blocks per launch), 7 us per launch at
+// batch 32 and 11-12 us at config 3's 3200 rows -- and more loads in flight made it slower, not faster (U = 16: 21.8 us).
+// Centred rows (LfStatPart::tile_pix > 0): sum v^2 about the origin = M2_r + (sum v)_r^2 / n_r, formed here in fp64 (n_r from the
+// launch geometry).  Floats between nrows and ld are never used (select, not multiply: they may hold anything).
 constexpr int FIN_THREADS = 256;
-// U = rows per thread and loop trip, all 2 U loads requested before the first add: 4 (1024 rows per trip).  Round 6 measured U = 16 --
-// config 3's 3200 rows per BatchNorm in ONE trip, 128 registers of loads in flight -- and it is SLOWER: 21.8 vs 11.9 us (forward),
-// 19.0 vs 10.7 (backward): the kernel is not bound by its dependent trips but by what each workgroup drags through its L1: it
-// uses 16 bytes of every 256-byte row half, so the 16-32 workgroups of a launch fetch every line 8 times.
-template <int U>
-__device__ __forceinline__ void stat_rows_sum4(const StatParts& sp, int c0, double (&s1)[4], double (&s2)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+__device__ __forceinline__ void stat_channel_sums(const StatParts& sp, int c, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
     for (int k = 0; k < sp.n; ++k) {
         const LfStatPart& q = sp.p[k];
-        const int cc = c0 - q.ch_off;
+        const int cc = c - q.ch_off;
         if (cc < 0 || cc >= q.C) continue;
-        // four rows = eight 16-byte loads requested before the first add: the kernel is ONE memory round trip per loop trip (rows
-        // written by the previous launch: L2 / Infinity Cache, ~1 us), and at config 3's 3200 rows the two-load form made 13 of them
-        // -- 12 us per BatchNorm, 0.9 ms per step.  Rows beyond the count re-read row 0 and are skipped by a scalar-free select.
-        for (int r0 = threadIdx.x; r0 < q.nrows; r0 += U * FIN_THREADS) {
-            f32x4 a[U], b[U];
+        const float* p1 = q.rows + (long)cc * q.ld;
+        const float* p2 = q.rows + ((long)q.C + cc) * q.ld;
+        for (int r0 = 4 * (int)threadIdx.x; r0 < q.nrows; r0 += 8 * FIN_THREADS) {
+            f32x4 a[2], b[2];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * FIN_THREADS < q.nrows ? r0 + u * FIN_THREADS : 0;
-                a[u] = ld4(q.rows + ((long)r * 2 + 0) * q.C + cc);
-                b[u] = ld4(q.rows + ((long)r * 2 + 1) * q.C + cc);
+            for (int u = 0; u < 2; ++u) {
+                const int r = r0 + u * 4 * FIN_THREADS < q.nrows ? r0 + u * 4 * FIN_THREADS : 0;
+                a[u] = ld4(p1 + r);
+                b[u] = ld4(p2 + r);
             }
-            asm volatile("" ::: "memory");      // all eight requests are out before the first add (with a `break` in the sum loop hipcc
-                                                // fused the two loops back into load, load, wait, add: one round trip per row)
+            asm volatile("" ::: "memory");      // all four requests are out before the first add
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * FIN_THREADS;
-                const bool v = r < q.nrows;  // a row beyond the count adds +0.0
-                // centred rows: sum v^2 about the origin = M2_r + (sum v)_r^2 / n_r, formed in fp64 (n_r from the launch geometry)
-                double inv = 0.0;
-                if (q.tile_pix > 0) {
-                    const long left = q.seg_pix - (long)(r % q.seg_rows) * q.tile_pix;
-                    const long n = left < q.tile_pix ? left : q.tile_pix;
-                    inv = n > 0 ? 1.0 / (double)n : 0.0;
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = r0 + u * 4 * FIN_THREADS + e;
+                    const bool v = r < q.nrows;
+                    double inv = 0.0;
+                    if (q.tile_pix > 0) {
+                        const long left = q.seg_pix - (long)(r % q.seg_rows) * q.tile_pix;
+                        const long n = left < q.tile_pix ? left : q.tile_pix;
+                        inv = n > 0 ? 1.0 / (double)n : 0.0;
+                    }
+                    const double av = (double)a[u][e];
+                    s1 += v ? av : 0.0;
+                    s2 += v ? (double)b[u][e] + av * av * inv : 0.0;
                 }
-                const double ax = (double)a[u].x, ay = (double)a[u].y, az = (double)a[u].z, aw = (double)a[u].w;
-                s1[0] += v ? ax : 0.0; s1[1] += v ? ay : 0.0; s1[2] += v ? az : 0.0; s1[3] += v ? aw : 0.0;
-                s2[0] += v ? (double)b[u].x + ax * ax * inv : 0.0; s2[1] += v ? (double)b[u].y + ay * ay * inv : 0.0;
-                s2[2] += v ? (double)b[u].z + az * az * inv : 0.0; s2[3] += v ? (double)b[u].w + aw * aw * inv : 0.0;
-            }
         }
     }
     constexpr int NWV = FIN_THREADS / 64;
-    __shared__ double sm[NWV][8];
+    __shared__ double sm[NWV][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
-    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { sm[w][i] = s1[i]; sm[w][4 + i] = s2[i]; }
-    }
+    if ((threadIdx.x & 63) == 0) { sm[w][0] = s1; sm[w][1] = s2; }
     __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {          // fixed order: deterministic
-        double a = 0.0, b = 0.0;
-#pragma unroll
-        for (int k = 0; k < NWV; ++k) { a += sm[k][i]; b += sm[k][4 + i]; }
-        s1[i] = a; s2[i] = b;
-    }
+    for (int k = 0; k < NWV; ++k) { t1 += sm[k][0]; t2 += sm[k][1]; }      // fixed order: deterministic
+    s1 = t1; s2 = t2;
 }
 
-template <int U>
+// one block per channel
 __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_fwd_kernel(StatParts sp, int C, double count,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ rmean, float* __restrict__ rvar,
                                                             float momentum, float eps, int training,
                                                             float* __restrict__ scale, float* __restrict__ shift,
                                                             float* __restrict__ asc, float* __restrict__ ash) {
-    const int c0 = blockIdx.x * 4;
-    double s1[4], s2[4];
-    if (training) stat_rows_sum4<U>(sp, c0, s1, s2);
-    const int c = c0 + (int)threadIdx.x;
-    if (threadIdx.x < 4 && c < C) {
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    if (training) stat_channel_sums(sp, c, s1, s2);
+    if (threadIdx.x == 0 && c < C) {
         double mean, var;
         if (training) {
-            double t1 = s1[0], t2 = s2[0];          // (select chain: no dynamic register indexing)
-            if (threadIdx.x == 1) { t1 = s1[1]; t2 = s2[1]; }
-            if (threadIdx.x == 2) { t1 = s1[2]; t2 = s2[2]; }
-            if (threadIdx.x == 3) { t1 = s1[3]; t2 = s2[3]; }
-            mean = t1 / count;
-            var = t2 / count - mean * mean;
+            mean = s1 / count;
+            var = s2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
             rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mean);
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -192,7 +171,7 @@ template <typename T, int NQ>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                            const T* __restrict__ t, const float* __restrict__ asc,
                                                            const float* __restrict__ ash, const float* __restrict__ dm,
-                                                           float* __restrict__ rows, long npix, int U, long pix_per_image) {
+                                                           float* __restrict__ rows, int ld, long npix, int U, long pix_per_image) {
     constexpr int V = 4 * NQ;
     const int C = U * V, ppi = 256 / U;
     const int cq = threadIdx.x % U, pr = threadIdx.x / U;
@@ -229,12 +208,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
     __shared__ float sm[256][8 * NQ];
     block_reduce_quads<NQ>(a1, a2, U, sm);
-    if (threadIdx.x < U) {
+    if (threadIdx.x < U) {         // channel-major rows: [2][C][ld]
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            st4(rows + ((long)blockIdx.x * 2 + 0) * C + c + 4 * q, a1[q]);
-            st4(rows + ((long)blockIdx.x * 2 + 1) * C + c + 4 * q, a2[q]);
-        }
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rows[(long)(c + 4 * q + e) * ld + blockIdx.x] = a1[q][e];
+                rows[((long)C + c + 4 * q + e) * ld + blockIdx.x] = a2[q][e];
+            }
     }
 }
 
@@ -242,22 +223,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // terms of the data gradient vanish (c1 = c2 = 0); the parameter gradients are the same sums.
 // (mean_scale = 1 / count in training mode, 0 in eval mode -- decided on the host: a run-time `training ? :` in here made hipcc
 // unroll the final sum into 128 registers + 564 bytes of scratch, 19 us per launch instead of 6)
-template <int U>
 __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(StatParts sp, int C, double mean_scale, const float* __restrict__ asc,
                                                             const float* __restrict__ ash, float* __restrict__ c1,
                                                             float* __restrict__ c2, float* __restrict__ ggamma,
                                                             float* __restrict__ gbeta) {
     // rows: [sum g, sum g * t] with t the PRE-BatchNorm tensor (raw: the producing epilogues carry no per-channel vectors);
     // sum g * x^ = rstd * sum g t - mean rstd * sum g, formed here in fp64 from the fp64 column sums
-    const int c0 = blockIdx.x * 4;
-    double s1[4], s2[4];
-    stat_rows_sum4<U>(sp, c0, s1, s2);
-    const int c = c0 + (int)threadIdx.x;
-    if (threadIdx.x < 4 && c < C) {
-        double t1 = s1[0], t2 = s2[0];
-        if (threadIdx.x == 1) { t1 = s1[1]; t2 = s2[1]; }
-        if (threadIdx.x == 2) { t1 = s1[2]; t2 = s2[2]; }
-        if (threadIdx.x == 3) { t1 = s1[3]; t2 = s2[3]; }
+    const int c = blockIdx.x;
+    double t1, t2;
+    stat_channel_sums(sp, c, t1, t2);
+    if (threadIdx.x == 0 && c < C) {
         const double rstd = (double)asc[c], mr = (double)ash[c];       // mr = -mean * rstd
         t2 = rstd * t2 + mr * t1;
         c1[c] = (float)(t1 * mean_scale);
@@ -308,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 template <typename T, int NQ>
 __global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int U,
                                                              T* __restrict__ cat, int cat_pix, int choff,
-                                                             float* __restrict__ rows) {
+                                                             float* __restrict__ rows, int ld) {
     constexpr int V = 4 * NQ;
     const int C = U * V, ppi = 256 / U, Ho = H / 2, Wo = W / 2;
     const int cq = threadIdx.x % U, pr = threadIdx.x / U, c = cq * V;
@@ -341,12 +316,14 @@ __global__ __launch_bounds__(256) void pool_concat_fwd_kernel(const T* __restric
     }
     __shared__ float sm[256][8 * NQ];
     block_reduce_quads<NQ>(a1, a2, U, sm);
-    if (rows && threadIdx.x < U) {
+    if (rows && threadIdx.x < U) {         // channel-major rows: [2][C][ld]
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            st4(rows + ((long)blockIdx.x * 2 + 0) * C + c + 4 * q, a1[q]);
-            st4(rows + ((long)blockIdx.x * 2 + 1) * C + c + 4 * q, a2[q]);
-        }
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rows[(long)(c + 4 * q + e) * ld + blockIdx.x] = a1[q][e];
+                rows[((long)C + c + 4 * q + e) * ld + blockIdx.x] = a2[q][e];
+            }
     }
 }
 
@@ -484,7 +461,10 @@ int lf_bn_finalize_fwd(const LfStatPart* parts, int nparts, int C, double count,
     for (int i = 0; i < nparts; ++i)
         LF_REQUIRE(parts[i].tile_pix == 0 || (parts[i].seg_rows > 0 && parts[i].seg_pix > 0 && parts[i].nrows % parts[i].seg_rows == 0),
                    "bn_finalize: centred rows need the launch geometry (seg_rows, seg_pix)");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel<4>, dim3(lf_cdiv(C, 4)), dim3(FIN_THREADS), 0, st, sp, C, count, gamma, beta,
+    for (int i = 0; i < nparts; ++i)
+        LF_REQUIRE(parts[i].ld >= parts[i].nrows && parts[i].ld % 4 == 0 && ((size_t)parts[i].rows & 15) == 0,
+                   "bn_finalize: channel-major rows need a 16-byte aligned base and a leading dimension >= nrows, multiple of 4 (ld=%d nrows=%d)", parts[i].ld, parts[i].nrows);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(FIN_THREADS), 0, st, sp, C, count, gamma, beta,
                        running_mean, running_var, momentum, eps, training, scale, shift, asc, ash);
     LF_CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
@@ -508,15 +488,15 @@ int lf_bn_act(const float* x, const float* sc, const float* sh, const float* dm,
 int lf_bn_bwd_reduce_rows(long npix) { return grid_for(npix * 4, 1024); }
 
 int lf_bn_bwd_reduce(const float* g, const float* y, const float* t, const float* asc, const float* ash, const float* dm,
-                     float* rows, long npix, int C, long pix_per_image, int s16, hipStream_t st) {
+                     float* rows, int ld, long npix, int C, long pix_per_image, int s16, hipStream_t st) {
     LF_REQUIRE(quad_ok(C), "bn_bwd_reduce: unsupported channel count %d", C);
     const dim3 grid(lf_bn_bwd_reduce_rows(npix));
     const bool oct = oct_ok(s16, C);
     const int V = oct ? 8 : 4;
     LF_BY_STORAGE3(s16, oct,
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, dm, rows, npix, C / V, pix_per_image),
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, dm, rows, npix, C / V, pix_per_image),
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), grid, dim3(256), 0, st, g, y, t, asc, ash, dm, rows, npix, C / V, pix_per_image));
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, dm, rows, ld, npix, C / V, pix_per_image),
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(g), as<lf_bf16>(y), as<lf_bf16>(t), asc, ash, dm, rows, ld, npix, C / V, pix_per_image),
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), grid, dim3(256), 0, st, g, y, t, asc, ash, dm, rows, ld, npix, C / V, pix_per_image));
     LF_CHECK_LAUNCH("bn_bwd_reduce");
     return 0;
 }
@@ -528,7 +508,10 @@ int lf_bn_bwd_finalize(const LfStatPart* parts, int nparts, int C, double count,
     sp.n = nparts;
     for (int i = 0; i < nparts; ++i) sp.p[i] = parts[i];
     for (int i = 0; i < nparts; ++i) LF_REQUIRE(parts[i].C % 4 == 0 && parts[i].ch_off % 4 == 0, "bn_bwd_finalize: channel ranges must be multiples of 4");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(lf_cdiv(C, 4)), dim3(FIN_THREADS), 0, st, sp, C, training ? 1.0 / count : 0.0, asc, ash,
+    for (int i = 0; i < nparts; ++i)
+        LF_REQUIRE(parts[i].ld >= parts[i].nrows && parts[i].ld % 4 == 0 && ((size_t)parts[i].rows & 15) == 0,
+                   "bn_bwd_finalize: channel-major rows need a 16-byte aligned base and a leading dimension >= nrows, multiple of 4 (ld=%d nrows=%d)", parts[i].ld, parts[i].nrows);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, sp, C, training ? 1.0 / count : 0.0, asc, ash,
                        c1, c2, ggamma, gbeta);
     LF_CHECK_LAUNCH("bn_bwd_finalize");
     return 0;
@@ -552,7 +535,7 @@ int lf_bn_bwd_apply(const float* g, const float* y, const float* t, const float*
 
 int lf_pool_rows(long npix_out) { return grid_for(npix_out * 4, 1024); }
 
-int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat, int cat_pix, int choff, float* rows,
+int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat, int cat_pix, int choff, float* rows, int ld,
                        int s16, hipStream_t st) {
     LF_REQUIRE(quad_ok(Cin) && H % 2 == 0 && W % 2 == 0, "pool_concat: unsupported shape");
     const long npo = (long)N * (H / 2) * (W / 2);
@@ -560,9 +543,9 @@ int lf_pool_concat_fwd(const float* x, int N, int H, int W, int Cin, float* cat,
     const bool oct = oct_ok(s16, Cin) && cat_pix % 8 == 0 && choff % 8 == 0;
     const int V = oct ? 8 : 4;
     LF_BY_STORAGE3(s16, oct,
-        hipLaunchKernelGGL((pool_concat_fwd_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(x), N, H, W, Cin / V, as<lf_bf16>(cat), cat_pix, choff, rows),
-        hipLaunchKernelGGL((pool_concat_fwd_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(x), N, H, W, Cin / V, as<lf_bf16>(cat), cat_pix, choff, rows),
-        hipLaunchKernelGGL((pool_concat_fwd_kernel<float, 1>), grid, dim3(256), 0, st, x, N, H, W, Cin / V, cat, cat_pix, choff, rows));
+        hipLaunchKernelGGL((pool_concat_fwd_kernel<lf_bf16, 2>), grid, dim3(256), 0, st, as<lf_bf16>(x), N, H, W, Cin / V, as<lf_bf16>(cat), cat_pix, choff, rows, ld),
+        hipLaunchKernelGGL((pool_concat_fwd_kernel<lf_bf16, 1>), grid, dim3(256), 0, st, as<lf_bf16>(x), N, H, W, Cin / V, as<lf_bf16>(cat), cat_pix, choff, rows, ld),
+        hipLaunchKernelGGL((pool_concat_fwd_kernel<float, 1>), grid, dim3(256), 0, st, x, N, H, W, Cin / V, cat, cat_pix, choff, rows, ld));
     LF_CHECK_LAUNCH("pool_concat_fwd");
     return 0;
 }

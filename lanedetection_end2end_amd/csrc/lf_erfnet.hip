@@ -306,8 +306,9 @@ lf_erfnet_plan* lf_erfnet_plan_create(int N, int H, int W, int in_channels, int 
     P->off_packed = ws.take(P->packed_floats);
     P->off_packed16 = ws.take((P->packed16_elems + 1) / 2);
     P->off_packed48 = ws.take((3 * P->packed16_elems + 1) / 2);
-    P->off_stat0 = ws.take(P->stat_floats);
-    P->off_stat1 = ws.take(P->stat_floats);
+    P->stat_floats += 2 * 128 * 4;                              // (channel-major rows: a use's leading dimension is its row count rounded up to 4)
+    P->off_stat0 = ws.take((P->stat_floats + 3) / 4 * 4);       // (16-byte aligned bases: the finalise kernels load four rows at once)
+    P->off_stat1 = ws.take((P->stat_floats + 3) / 4 * 4);
     P->off_wpart = ws.take(P->wpart_floats);
     P->off_bpart = ws.take(P->bpart_floats);
     P->gbuf_floats = (long)N * (H / 2) * (W / 2) * 16;          // largest activation (= N*(H/4)*(W/4)*64)
@@ -471,18 +472,20 @@ int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
             LfStatPart parts[2];
             int np = 0;
             if (L.x < 0) {
+                const int srows = lf_stem_rows(N, L.Hin, L.Win);
                 LF_TRY(lf_stem_fwd(img, N, L.Cin, L.Hin, L.Win, c.params[L.cv[0].p_w], c.params[L.cv[0].p_b], c.at(L.b[0]),
-                                   c.training ? stat0 : nullptr, c.s16, c.st));
-                parts[np++] = {stat0, lf_stem_rows(N, L.Hin, L.Win), 16, 0};
+                                   c.training ? stat0 : nullptr, lf_stat_ld(srows), c.s16, c.st));
+                parts[np++] = {stat0, srows, 16, 0, lf_stat_ld(srows)};
             } else {
                 LfTapArgs a = lf_no_args();
-                a.stats = stat0;
+                a.stats = stat0; a.stats_ld = lf_stat_ld(lf_tapgemm_stat_rows(L.cv[0].fwd.geom));
                 LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
-                parts[np++] = lf_stat_part_tiles(stat0, c.last_rows, L.Cout - L.Cin, 0, c.last_rows, npo);     // centred rows (LfStatPart)
+                parts[np++] = lf_stat_part_tiles(stat0, c.last_rows, a.stats_ld, L.Cout - L.Cin, 0, c.last_rows, npo);     // centred rows (LfStatPart)
+                const int prows = lf_pool_rows(npo);
                 LF_TRY(lf_pool_concat_fwd(c.at(L.x), N, L.Hin, L.Win, L.Cin, c.at(L.b[0]), L.Cout, L.Cout - L.Cin,
-                                          c.training ? stat1 : nullptr, c.s16, c.st));
-                parts[np++] = {stat1, lf_pool_rows(npo), L.Cin, L.Cout - L.Cin};
+                                          c.training ? stat1 : nullptr, lf_stat_ld(prows), c.s16, c.st));
+                parts[np++] = {stat1, prows, L.Cin, L.Cout - L.Cin, lf_stat_ld(prows)};
             }
             LF_TRY(bn_finalize(c, L.bn[0], parts, np, (double)npo));
             LF_TRY(lf_bn_act(c.at(L.b[0]), c.at(L.bn[0].sc), c.at(L.bn[0].sh), nullptr, nullptr, c.at(L.b[1]), npo, L.Cout,
@@ -490,19 +493,19 @@ int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
         } else if (L.kind == K_NB) {
             LfTapArgs a = lf_no_args();
             LF_TRY(run_gemm(c, L.cv[0].fwd, c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE, LF_EPI_RELU, a));
-            a.stats = stat0;
+            a.stats = stat0; a.stats_ld = lf_stat_ld(lf_tapgemm_stat_rows(L.cv[1].fwd.geom));
             LF_TRY(run_gemm(c, L.cv[1].fwd, c.at(L.b[0]), c.at(L.b[1]), c.params[L.cv[1].p_b], LF_PRO_NONE,
                             c.training ? LF_EPI_STATS_SQ : 0, a));
-            LfStatPart p0 = lf_stat_part_tiles(stat0, c.last_rows, L.Cout, 0, c.last_rows, npo);
+            LfStatPart p0 = lf_stat_part_tiles(stat0, c.last_rows, a.stats_ld, L.Cout, 0, c.last_rows, npo);
             LF_TRY(bn_finalize(c, L.bn[0], &p0, 1, (double)npo));
             a = lf_no_args();
             a.pro_sc = c.at(L.bn[0].sc); a.pro_sh = c.at(L.bn[0].sh);
             LF_TRY(run_gemm(c, L.cv[2].fwd, c.at(L.b[1]), c.at(L.b[2]), c.params[L.cv[2].p_b], LF_PRO_BNRELU, LF_EPI_RELU, a));
             a = lf_no_args();
-            a.stats = stat0;
+            a.stats = stat0; a.stats_ld = lf_stat_ld(lf_tapgemm_stat_rows(L.cv[3].fwd.geom));
             LF_TRY(run_gemm(c, L.cv[3].fwd, c.at(L.b[2]), c.at(L.b[3]), c.params[L.cv[3].p_b], LF_PRO_NONE,
                             c.training ? LF_EPI_STATS_SQ : 0, a));
-            p0.nrows = p0.seg_rows = c.last_rows;
+            p0.nrows = p0.seg_rows = c.last_rows; p0.ld = a.stats_ld;
             LF_TRY(bn_finalize(c, L.bn[1], &p0, 1, (double)npo));
             const float* dm = (c.training && L.drop_idx >= 0 && c.dropmask) ? c.dropmask + P->drop_off[L.drop_idx] : nullptr;
             LF_TRY(lf_bn_act(c.at(L.b[3]), c.at(L.bn[1].sc), c.at(L.bn[1].sh), dm, c.at(L.x), c.at(L.b[4]), npo, L.Cout,
@@ -510,15 +513,16 @@ int forward_layers(const Ctx& c, const float* img, int nlayers, int first = 0) {
         } else {
             LfStatPart parts[1];
             // the 4 sub-pixel phases write disjoint pixels of c; their stat rows are laid end to end
-            int rows = 0;
+            int rows = 0, rows4 = 0;
+            for (int ph = 0; ph < 4; ++ph) rows4 += lf_tapgemm_stat_rows(L.cv[0].fph[ph].geom);
             for (int ph = 0; ph < 4; ++ph) {
                 LfTapArgs a = lf_no_args();
-                a.stats = stat0 + (long)rows * 2 * L.Cout;
+                a.stats = stat0 + rows; a.stats_ld = lf_stat_ld(rows4);      // (the phases' rows side by side in every channel's run)
                 LF_TRY(run_gemm(c, L.cv[0].fph[ph], c.at(L.x), c.at(L.b[0]), c.params[L.cv[0].p_b], LF_PRO_NONE,
                                 c.training ? LF_EPI_STATS_SQ : 0, a));
                 rows += c.last_rows;
             }
-            parts[0] = lf_stat_part_tiles(stat0, rows, L.Cout, 0, rows / 4, npo / 4);      // every phase: N * Hin * Win pixels, rows / 4 rows
+            parts[0] = lf_stat_part_tiles(stat0, rows, lf_stat_ld(rows4), L.Cout, 0, rows / 4, npo / 4);      // every phase: N * Hin * Win pixels, rows / 4 rows
             LF_TRY(bn_finalize(c, L.bn[0], parts, 1, (double)npo));
             LF_TRY(lf_bn_act(c.at(L.b[0]), c.at(L.bn[0].sc), c.at(L.bn[0].sh), nullptr, nullptr, c.at(L.b[1]), npo, L.Cout,
                              (long)L.Hout * L.Wout, c.s16, c.st));
@@ -656,7 +660,7 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
     float* bufs[3] = {g0, g1, g2};
     float* in = g0;
     bool prepped = false;        // `in` already masked by the layer's output ReLU, BN sums in stat0
-    int prep_rows = 0;
+    int prep_rows = 0, prep_ld = 0;
     for (int li = nlayers - 1; li >= first; --li) {
         const Layer& L = P->layers[li];
         P->prof_layer = 100 + li;
@@ -669,10 +673,10 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         Prep nx;
         const bool can_prep = li > first && (L.kind == K_NB || L.kind == K_UP);
         if (can_prep) nx = prep_for(c, P->layers[li - 1]);
-        auto add_prep = [&](LfTapArgs& a, int& epi) {
+        auto add_prep = [&](LfTapArgs& a, int& epi, const LfTapGeom& dg) {
             if (!can_prep) return;
             a.mask_src = nx.y; a.aux = nx.pre; a.asc = c.at(nx.bn->asc); a.ash = c.at(nx.bn->ash); a.dm = nx.dm;
-            a.stats = stat0;
+            a.stats = stat0; a.stats_ld = lf_stat_ld(lf_tapgemm_stat_rows(dg));      // (the data gradient's own rows: one per 256 pixels of the layer's input)
             epi |= LF_EPI_MASK | LF_EPI_STATS_XHAT;
         };
         const BNRef& blast = L.kind == K_NB ? L.bn[1] : L.bn[0];
@@ -682,15 +686,16 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
         // ---- last BatchNorm (+dropout +residual) + ReLU backward: g_pre -> X ; g_z (masked incoming gradient)
         const float* gz;
         if (!prepped) {
-            LF_TRY(lf_bn_bwd_reduce(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), dm, stat0, npo, L.Cout, ppi, c.s16, c.st));
-            LfStatPart rp = {stat0, lf_bn_bwd_reduce_rows(npo), L.Cout, 0};
+            const int rrows = lf_bn_bwd_reduce_rows(npo);
+            LF_TRY(lf_bn_bwd_reduce(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), dm, stat0, lf_stat_ld(rrows), npo, L.Cout, ppi, c.s16, c.st));
+            LfStatPart rp = {stat0, rrows, L.Cout, 0, lf_stat_ld(rrows)};
             LF_TRY(bn_bwd_finalize(c, blast, &rp, 1, (double)npo));
             LF_TRY(lf_bn_bwd_apply(in, ylast, prelast, c.at(blast.asc), c.at(blast.ash), c.params[blast.p_g], c.at(blast.c1),
                                    c.at(blast.c2), dm, X, L.kind == K_NB ? Y : nullptr, npo, L.Cout, ppi, c.s16, c.st));
             gz = Y;
             // `in` is free from here on
         } else {
-            LfStatPart rp = {stat0, prep_rows, L.Cout, 0};
+            LfStatPart rp = {stat0, prep_rows, L.Cout, 0, prep_ld};
             LF_TRY(bn_bwd_finalize(c, blast, &rp, 1, (double)npo));
             LF_TRY(lf_bn_bwd_apply(in, nullptr, prelast, c.at(blast.asc), c.at(blast.ash), c.params[blast.p_g], c.at(blast.c1),
                                    c.at(blast.c2), dm, X, nullptr, npo, L.Cout, ppi, c.s16, c.st));
@@ -713,9 +718,9 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             LF_TRY(run_wgrad(c, L.cv[2].fwd, L.cv[2], t2, F, c.at(b1.sc), c.at(b1.sh), 0));
             a = lf_no_args();
             a.aux = t2; a.msc = c.at(b1.sc); a.msh = c.at(b1.sh); a.asc = c.at(b1.asc); a.ash = c.at(b1.ash);
-            a.stats = stat0;
+            a.stats = stat0; a.stats_ld = lf_stat_ld(lf_tapgemm_stat_rows(L.cv[2].dg[0].geom));
             LF_TRY(run_gemm(c, L.cv[2].dg[0], F, X, nullptr, LF_PRO_NONE, LF_EPI_MASKBN | LF_EPI_STATS_XHAT, a, true));
-            LfStatPart sp = {stat0, c.last_rows, L.Cout, 0};
+            LfStatPart sp = {stat0, c.last_rows, L.Cout, 0, a.stats_ld};
             LF_TRY(bn_bwd_finalize(c, b1, &sp, 1, (double)npo));
             LF_TRY(lf_bn_bwd_apply(X, nullptr, t2, c.at(b1.asc), c.at(b1.ash), c.params[b1.p_g], c.at(b1.c1), c.at(b1.c2),
                                    nullptr, F /*g_t2*/, nullptr, npo, L.Cout, ppi, c.s16, c.st));
@@ -729,10 +734,10 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
             a = lf_no_args();
             a.add_src = gz;
             int epi = LF_EPI_ADD;
-            add_prep(a, epi);
+            add_prep(a, epi, L.cv[0].dg[0].geom);
             LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a, true));
             out = F;
-            if (can_prep) { prepped = true; prep_rows = c.last_rows; }
+            if (can_prep) { prepped = true; prep_rows = c.last_rows; prep_ld = a.stats_ld; }
         } else if (L.kind == K_UP) {
             // (the four phases' reductions join the batched launch when their regions fit: eight 6 us launches per step, each
             // between two dependent weight-gradient launches, otherwise)
@@ -753,10 +758,10 @@ int backward_layers(const Ctx& c, const float* img, float* g0, float* g1, float*
                 a.add_src = c.g_enc;
                 epi |= LF_EPI_ADD;
             }
-            add_prep(a, epi);
+            add_prep(a, epi, L.cv[0].dg[0].geom);
             LF_TRY(run_gemm(c, L.cv[0].dg[0], X, F, nullptr, LF_PRO_NONE, epi, a));
             out = F;
-            if (can_prep) { prepped = true; prep_rows = c.last_rows; }
+            if (can_prep) { prepped = true; prep_rows = c.last_rows; prep_ld = a.stats_ld; }
         } else if (L.x < 0) {
             // stem: weight gradient only (the image needs no gradient)
             const int Cc = 16 - L.Cin, rows = lf_stem_wgrad_rows(N, L.Hin, L.Win);

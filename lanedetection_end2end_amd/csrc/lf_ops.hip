@@ -102,6 +102,7 @@ void lf_debug_set_bf16_lds(int v) { lf_tapgemm_set_bf16_lds(v); }
 void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = (mode == 2 || mode == 9) ? mode : 0; }
 
 void lf_debug_set_wgrad_ro(int mode, int cap64, int cap128) { lf_tapwgrad_ro_set(mode, cap64, cap128); }
+void lf_debug_set_wgrad_pair(int v) { lf_tapwgrad_set_pair(v); }
 
 // same as lf_conv1d_fwd with per-wave phase timestamps: dbg receives 8 uint64 per wave
 // (start, tap table built, main loop done, stores retired); waves = ceil(N*H*W/256)*4*(C/64)
@@ -183,6 +184,7 @@ int lf_debug_conv1d_bwd_data_epi3(const float* gy, const float* w, const float* 
     memset(&a, 0, sizeof(a));
     pack_conv1d(a, w, scratch, C, 3L * C, 3L, 1, st);
     a.src = gy; a.dst = gx; a.mask_src = mask_src; a.add_src = add_src; a.aux = aux; a.stats = stats;
+    a.stats_ld = lf_tapgemm_stat_rows(g);        // the caller's buffer: [2][C][rows], rows = ceil(N * H * W / 256)
     if (lf_tapgemm_launch(g, a, LF_PRO_NONE, LF_EPI_ADD | LF_EPI_MASK | LF_EPI_STATS_XHAT, st)) return -1;
     return lf_tapgemm_stat_rows_for(g, a);
 }
@@ -200,6 +202,7 @@ int lf_debug_conv1d_epi(const float* src, const float* w, const float* bias, flo
     if (transposed) pack_conv1d(a, w, scratch, C, 3L * C, 3L, 1, st);
     else pack_conv1d(a, w, scratch, C, 3L, 3L * C, 0, st);
     a.src = src; a.dst = dst; a.bias = bias; a.mask_src = mask_src; a.add_src = add_src; a.aux = aux; a.msc = msc; a.msh = msh; a.stats = stats;
+    a.stats_ld = lf_tapgemm_stat_rows(g);        // the caller's buffer: [2][C][rows], rows = ceil(N * H * W / 256)
     if (lf_tapgemm_launch(g, a, LF_PRO_NONE, epi, st)) return -1;
     return (epi & (LF_EPI_STATS_SQ | LF_EPI_STATS_XHAT)) ? lf_tapgemm_stat_rows_for(g, a) : 0;
 }

@@ -42,7 +42,7 @@ __device__ __forceinline__ float row_sum(float v) {
 // Workgroup = 256 pixels (one BatchNorm partial row, as before).
 template <int CIN, typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, int N, int H, int W, const float* __restrict__ w,
-                                                      const float* __restrict__ b, T* __restrict__ cat, float* __restrict__ rows) {
+                                                      const float* __restrict__ b, T* __restrict__ cat, float* __restrict__ rows, int ld) {
     constexpr int Cc = 16 - CIN, KK = 9 * CIN, KS = (KK + 3) / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pl = lane & 15, kq = lane >> 4;
     const int Ho = H / 2, Wo = W / 2;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         __syncthreads();
         if (threadIdx.x < 32) {
             const int which = threadIdx.x >> 4, c = threadIdx.x & 15;
-            rows[((long)blockIdx.x * 2 + which) * 16 + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+            rows[(long)(which * 16 + c) * ld + blockIdx.x] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);      // channel-major
         }
     }
 }
@@ -256,7 +256,7 @@ inline int wgrad_wgs(long ngroups) {
 
 int lf_stem_rows(int N, int H, int W) { return lf_cdiv((long)N * (H / 2) * (W / 2), 256); }
 
-int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, const float* b, float* cat, float* rows,
+int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, const float* b, float* cat, float* rows, int ld,
                 int s16, hipStream_t st) {
     LF_REQUIRE(Cin >= 1 && Cin <= 4, "stem: in_channels %d not in 1..4", Cin);
     LF_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: odd image size");
@@ -264,8 +264,8 @@ int lf_stem_fwd(const float* img, int N, int Cin, int H, int W, const float* w, 
     const dim3 grid(lf_stem_rows(N, H, W));
 #define LF_STEM(CI)                                                                                                                  \
     do {                                                                                                                             \
-        if (s16) hipLaunchKernelGGL((stem_fwd_kernel<CI, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows); \
-        else hipLaunchKernelGGL((stem_fwd_kernel<CI, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows);                \
+        if (s16) hipLaunchKernelGGL((stem_fwd_kernel<CI, lf_bf16>), grid, dim3(256), 0, st, img, N, H, W, w, b, as<lf_bf16>(cat), rows, ld); \
+        else hipLaunchKernelGGL((stem_fwd_kernel<CI, float>), grid, dim3(256), 0, st, img, N, H, W, w, b, cat, rows, ld);            \
     } while (0)
     switch (Cin) { case 1: LF_STEM(1); break; case 2: LF_STEM(2); break; case 3: LF_STEM(3); break; default: LF_STEM(4); break; }
 #undef LF_STEM

@@ -2,7 +2,7 @@
 full-resolution stage, 20 launches per step) ONE LAUNCH AT A TIME through the C ABI against torch fp64: plain / ReLU forward, BN forward
 sums, BN+ReLU operand prologue, data gradient plain / times the ReLU mask / plus the residual gradient, mask + BN-backward sums, mask by a
 recomputed BatchNorm + BN-backward sums, and the three-tensor epilogue that closes a block's backward -- values to fp32 rounding, the
-per-tile partial rows ([rows][2][C]) summed in fp64 against the column sums of the stored values.  (The whole-network tests cover the same
+per-tile partial rows (channel-major [2][C][rows]) summed in fp64 against the column sums of the stored values.  (The whole-network tests cover the same
 kernels only through the chain of a full pass; lf_debug_conv1d_epi is the hook that launches one of them.)"""
 import ctypes
 
@@ -37,7 +37,7 @@ def test_every_epilogue_of_the_16_channel_kernel(shape):
     scratch = torch.empty(lib.lf_conv1d_scratch_floats(N, H, W, C) + 4096, device="cuda")
     nrows = (N * H * W + 255) // 256
     nan = lambda: torch.full_like(x, float("nan"))
-    rows = lambda: torch.full((nrows, 2, C), float("nan"), device="cuda")
+    rows = lambda: torch.full((2, C, nrows), float("nan"), device="cuda")      # channel-major partial rows: [kind][channel][row]
     epi = lambda *args: lib.lf_debug_conv1d_epi(*args, N, H, W, C, axis, d, P(scratch), st)
 
     y0, y1, y8, yp, g0, g2, g4, g34, g48, g38 = (nan() for _ in range(10))
@@ -71,19 +71,19 @@ def test_every_epilogue_of_the_16_channel_kernel(shape):
         assert torch.isfinite(got).all(), name
         err = float((got.double() - ref).abs().max()) / float(ref.abs().max())
         assert err < 2e-6, "%s: %.2e" % (name, err)
-    # BN forward rows (round 6, centred): [rows][0] = sum v, [rows][1] = M2 = sum (v - mean_row)^2 over the row's own 256-pixel tile
+    # BN forward rows (round 6, centred): [0][c][r] = sum v, [1][c][r] = M2 = sum (v - mean_row)^2 over row r's own 256-pixel tile
     # (the last one ragged) -- each row against fp64 on the stored values, M2 relative to itself (no (mean / sigma)^2 term)
     flat = y8.double().reshape(-1, C)
     for r in range(nrows):
         t = flat[r * 256: (r + 1) * 256]
         m2 = ((t - t.mean(0)) ** 2).sum(0)
-        assert float(((s8[r, 0].double() - t.sum(0)).abs() / t.abs().sum(0)).max()) < 2e-6, ("BN forward sums, row %d" % r)
-        assert float(((s8[r, 1].double() - m2).abs() / m2).max()) < 5e-6, ("BN forward M2, row %d" % r)
-    # BN backward rows: [rows][0] = sum v, [rows][1] = sum v * aux (raw), over the values as stored
+        assert float(((s8[0, :, r].double() - t.sum(0)).abs() / t.abs().sum(0)).max()) < 2e-6, ("BN forward sums, row %d" % r)
+        assert float(((s8[1, :, r].double() - m2).abs() / m2).max()) < 5e-6, ("BN forward M2, row %d" % r)
+    # BN backward rows: [0] = sum v, [1] = sum v * aux (raw), over the values as stored
     for name, st_rows, v, second in (("mask + BN-backward sums", s34, g34, aux),
                                      ("recomputed-BN mask + sums", s48, g48, aux), ("three-tensor epilogue", s38, g38, aux)):
         assert torch.isfinite(st_rows).all(), name
-        got = st_rows.double().sum(0)
+        got = st_rows.double().sum(2)
         s1, s2 = v.double().sum((0, 1, 2)), (v.double() * second.double()).sum((0, 1, 2))
         a1, a2 = v.double().abs().sum((0, 1, 2)), (v.double() * second.double()).abs().sum((0, 1, 2))
         assert float(((got[0] - s1).abs() / a1).max()) < 2e-6 and float(((got[1] - s2).abs() / a2).max()) < 2e-6, name
