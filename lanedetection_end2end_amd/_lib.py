@@ -99,7 +99,6 @@ def _declare(lib):
         "lf_debug_set_split_any_size": (None, [I]),
         "lf_debug_set_bf16_lds": (None, [I]),
         "lf_debug_set_ops_precision": (None, [I]),
-        "lf_debug_set_wgrad_pair": (None, [I]),
         "lf_debug_conv1d_fwd_phases": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P]),
         "lf_debug_conv1d_wgrad_phases": (I, [P, P, I, I, I, I, I, I, P, P, P]),
         "lf_debug_conv1d_fwd_pro": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P]),

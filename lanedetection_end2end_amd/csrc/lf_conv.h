@@ -60,7 +60,6 @@ struct LfTapArgs {
 
 void lf_tapgemm_set_split_any_size(int v);
 void lf_tapgemm_set_bf16_lds(int v);
-void lf_tapwgrad_set_pair(int v);      // tools / A-B runs: 1 (shipped) paired-job workgroups of the fp32 weight gradient, 0 one job per workgroup
 int lf_tapgemm_stat_rows(const LfTapGeom& g);                          // upper bound over the kernels (buffer sizing)
 int lf_tapgemm_stat_rows_for(const LfTapGeom& g, const LfTapArgs& a);  // rows the launch with these arguments writes
 int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, hipStream_t st);

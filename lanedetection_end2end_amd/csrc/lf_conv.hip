@@ -2116,7 +2116,6 @@ __global__ __launch_bounds__(256, 4) void tapgemm_lean_kernel(const LfTapGeom g,
     LF_TAPGEMM_EPILOGUE
 }
 
-int g_wgrad_pair = 1;          // tools / A-B runs only: 0 = the fp32 weight gradient's one-job workgroups for every launch (round 5's form)
 int g_split_any_size = 0;      // kernel-level tests only: let the split kernel take launches below its shipped size rule
 int g_bf16_lds = 4;            // tools / A-B runs only: 4 = wave-private (64 ch) / whole-line (128 ch) + 16-channel kernels where they apply, else the ring (shipped);
                                // 3 = the whole-line kernel at 64 channels too (round 5's routing); 2 = the ring
@@ -2134,7 +2133,6 @@ int pick_nt(int Cd) {
 
 void lf_tapgemm_set_split_any_size(int v) { g_split_any_size = v; }
 void lf_tapgemm_set_bf16_lds(int v) { g_bf16_lds = v; }
-void lf_tapwgrad_set_pair(int v) { g_wgrad_pair = v; }
 
 // launches the split kernel takes: whole 32-channel K-steps, 64-channel output slabs (NT = 4), whole 512-pixel
 // workgroups (its two 4-wave groups each own one 256-pixel statistics row), 16-byte aligned pixels
@@ -2519,21 +2517,18 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // sub-steps become ONE v_mfma_f32_16x16x16_bf16 per tile -- a lane's four pixels (p+kq, +4, +8, +12) are exactly its
 // four k of the K=16 step -- with the operands assembled from the raw 8-byte loads by v_perm_b32 (no widening).
 // PROT: 0 / 1 = the BN+ReLU prologue flag compiled in (the fp32 64-channel-block launches of the network), -1 = run-time
-// PAIR (round 6: the fp32 launches with TWO 64-channel g-blocks -- 128 output channels): an 8-wave workgroup runs the two jobs
-// (tap, x-block, g-block 0 / 1) of one pixel range side by side, waves w and w + 4 on the SAME pixels.  tools/wgrad_traffic.py
-// (profiles/r6_wgrad_traffic.txt): the job form's launches take requested bytes / 6.0-6.4 TB/s whatever the channel count and
-// whether the operands sit in the Infinity Cache or in HBM -- the kernel is bound by what its L2s request from the fabric, and
-// every job re-streams its halves of X and G.  The two jobs of a pair read the same X stream: kept in step by one workgroup
-// barrier per loop trip, the partner's load finds the line in (or on its way into) the CU's L1.
-template <bool XV, bool GV, int XT, int GT, int U, bool S16, bool BFM = false, int PROT = -1, bool DBG = false, bool PAIR = false>
-__global__ __launch_bounds__(PAIR ? 512 : 256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro_rt,
+// (Round 6 built a PAIRED form -- 8-wave workgroups running the two jobs (tap, x-block, g-block 0 / 1) that read the same X stream side
+// by side, one barrier per loop trip so that the partner's load finds the line in the CU's L1 -- to test whether the job form's
+// re-reads bound the kernel: FETCH_SIZE fell 25 % (283 vs 376 MB per launch) and the launch did NOT get faster (64.2 vs 63.0 us, the
+// step +0.13 ms); neither do operands from HBM instead of the Infinity Cache cost anything (profiles/r6_wgrad_traffic.txt).  The kernel
+// is bound by issue / the matrix pipes; the form was removed (git: commit 45fe98c has it).)
+template <bool XV, bool GV, int XT, int GT, int U, bool S16, bool BFM = false, int PROT = -1, bool DBG = false>
+__global__ __launch_bounds__(256, 2) void tapwgrad_kernel(const LfTapGeom g, const LfWgradArgs a, const int pro_rt,
                                                       const long pps, const int write_bias, const int gxs) {
     constexpr int XTiles = XV ? 4 : XT, GTiles = GV ? 4 : GT;
     const int pro = PROT >= 0 ? (PROT ? LF_PRO_BNRELU : LF_PRO_NONE) : pro_rt;
     constexpr int XB = XTiles * 16, GB = GTiles * 16;
-    const int lane = threadIdx.x & 63;
-    const int job = PAIR ? (int)(threadIdx.x >> 8) : 0;            // which job of the pair
-    const int wave = (threadIdx.x >> 6) & 3;                        // K-split index inside the job
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl = lane & 15, kq = lane >> 4;
     unsigned long long tstamp[4] = {0ull, 0ull, 0ull, 0ull};
     if constexpr (DBG) tstamp[0] = __builtin_amdgcn_s_memrealtime();
@@ -2544,12 +2539,12 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, 2) void tapwgrad_kernel(const LfT
     const int ncob = g.Cd / GB;
     unsigned ord = blockIdx.x;
     if ((gridDim.x & 7u) == 0) ord = (ord & 7u) * (gridDim.x >> 3) + (ord >> 3);
-    const unsigned nz = PAIR ? (unsigned)(g.Cs / XB) : (unsigned)((g.Cs / XB) * ncob);      // PAIR: the grid enumerates x-blocks only
+    const unsigned nz = (unsigned)((g.Cs / XB) * ncob);
     const int t = (int)(ord % (unsigned)g.ntaps);
     const int bz = (int)((ord / (unsigned)g.ntaps) % nz);                 // channel-block pair: next fastest
     const unsigned bxs = ord / ((unsigned)g.ntaps * nz);                  // pixel-split index: slowest
     (void)gxs;
-    const int cib = PAIR ? bz : bz / ncob, cob = PAIR ? job : bz % ncob;
+    const int cib = bz / ncob, cob = bz % ncob;
     // Loop state is WAVE-UNIFORM (scalar registers): a wave walks its pixel range in groups of 4U consecutive pixels of one
     // image row; lane (pl, kq) takes pixel kq + 4u of the group.  A VALU instruction issued beside the partner wave's MFMA
     // stream costs ~13 cycles, so the per-lane address / mask arithmetic of the first version (~150 instructions per 64 MFMAs)
@@ -2781,7 +2776,6 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, 2) void tapwgrad_kernel(const LfT
             }
             const int n = ph < 3 ? qp : npairs - 3 * qp;
             for (int i = 0; i < n; ++i) {
-                if constexpr (PAIR) __builtin_amdgcn_s_barrier();      // the pair's waves issue the same X loads together
                 wload(B); advance();
                 step(A);
                 wload(A); advance();
@@ -2790,9 +2784,6 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, 2) void tapwgrad_kernel(const LfT
         }
         if (niter & 1) step(A);
     };
-    // PAIR: every wave of the workgroup passes the same number of barriers -- a full pixel range's loop trips; a wave whose range
-    // is cut short by the end of the tensor (or empty) makes up the difference behind its loop
-    const int wg_npairs = (int)(pps / (4 * U)) >> 1;
     if (niter > 0) {
         if constexpr (PROT >= 0) {
             if (need_bias) run(std::true_type{}, std::integral_constant<bool, PROT == 1>{});
@@ -2803,19 +2794,11 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, 2) void tapwgrad_kernel(const LfT
             else { if (prologue) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
         }
     }
-    if constexpr (PAIR) {
-        for (int i = niter > 0 ? (niter >> 1) : 0; i < wg_npairs; ++i) __builtin_amdgcn_s_barrier();
-    }
     if constexpr (DBG) { asm volatile("" ::"v"(acc[0][0][0])); tstamp[2] = __builtin_amdgcn_s_memrealtime(); }
     // ---- reduce the 4 waves of the workgroup through LDS, wave 0 writes one partial row
     __builtin_amdgcn_s_setprio(3);
-    // (PAIR: one reduction area per job, 2 x 52 KB: dynamic LDS)
-    typedef float RedT[XTiles * GTiles * 4][64];
-    typedef float BredT[GTiles][64];
-    __shared__ float red_s[PAIR ? 1 : WG_WAVES - 1][PAIR ? 1 : XTiles * GTiles * 4][PAIR ? 1 : 64];
-    __shared__ float bred_s[PAIR ? 1 : WG_WAVES][PAIR ? 1 : GTiles][PAIR ? 1 : 64];
-    RedT* red = PAIR ? reinterpret_cast<RedT*>(lf_tap_lds) + job * (WG_WAVES - 1) : reinterpret_cast<RedT*>(red_s);
-    BredT* bred = PAIR ? reinterpret_cast<BredT*>(lf_tap_lds + 2 * (WG_WAVES - 1) * sizeof(RedT)) + job * WG_WAVES : reinterpret_cast<BredT*>(bred_s);
+    __shared__ float red[WG_WAVES - 1][XTiles * GTiles * 4][64];
+    __shared__ float bred[WG_WAVES][GTiles][64];
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < XTiles; ++r)
@@ -2872,7 +2855,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, 2) void tapwgrad_kernel(const LfT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp[3] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0 && a.dbg) {
-            unsigned long long* d = a.dbg + ((unsigned long long)blockIdx.x * WG_WAVES * (PAIR ? 2 : 1) + (threadIdx.x >> 6)) * 8;
+            unsigned long long* d = a.dbg + ((unsigned long long)blockIdx.x * WG_WAVES + wave) * 8;
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -3357,18 +3340,6 @@ int lf_tapwgrad_launch(const LfTapGeom& g, const LfWgradArgs& a, int pro, hipStr
         return 0;
     }
     dim3 grid(c.gx * g.ntaps * (g.Cs / xb) * (g.Cd / gb));
-    // fp32 tensors, two 64-channel g-blocks: the two jobs of a pixel range that share an X stream as ONE 8-wave workgroup (PAIR)
-    if (g_wgrad_pair && !a.dbg && !a.s16 && c.xv && c.gv && c.u == 4 && g.Cd / gb == 2) {
-        constexpr size_t pair_lds = 2 * (WG_WAVES - 1) * (size_t)(16 * 4 * 64 * 4) + 2 * WG_WAVES * (size_t)(4 * 64 * 4);
-        const dim3 pgrid(c.gx * g.ntaps * (g.Cs / xb));
-        bool launched = false;
-#define LF_WGP(PROV) do { auto kern = tapwgrad_kernel<true, true, 4, 4, 4, false, false, PROV, false, true>;                         \
-                          if (allow_big_lds(reinterpret_cast<const void*>(kern), 128 * 1024)) {                                       \
-                              hipLaunchKernelGGL(kern, pgrid, dim3(512), pair_lds, st, g, a, pro, c.pps, wb, c.gx); launched = true; } } while (0)
-        if (pro == LF_PRO_BNRELU) LF_WGP(1); else LF_WGP(0);
-#undef LF_WGP
-        if (launched) { LF_CHECK_LAUNCH("tapwgrad (paired jobs)"); return 0; }
-    }
     if (a.dbg) {           // phase stamps (tools/kbench.py --phases --wgrad): the fp32 64-channel-block kernel without prologue only
         LF_REQUIRE(c.xv && c.gv && c.u == 4 && !a.s16 && pro == LF_PRO_NONE, "tapwgrad: phase stamps are compiled into the plain fp32 kernel only");
         hipLaunchKernelGGL((tapwgrad_kernel<true, true, 4, 4, 4, false, false, 0, true>), grid, dim3(256), 0, st, g, a, pro, c.pps, wb, c.gx);

@@ -27,9 +27,6 @@ int lf_debug_conv1d_fwd_pro(const float* x, const float* w, const float* bias, c
 /* the read-once bf16 weight gradient (lf_wgrad_ro.hip): mode 0 = off (tapwgrad_kernel's job form takes every launch), 1 = shipped;
  * cap64 / cap128 > 0: workgroups per launch at 64 / 128 channels (A/B runs; at most the shipped 512 / 256 the buffers are sized for) */
 void lf_debug_set_wgrad_ro(int mode, int cap64, int cap128);
-/* the fp32 weight gradient at two 64-channel g-blocks: 1 (shipped) = 8-wave workgroups running the two jobs that share an X stream side by
- * side; 0 = one job per 4-wave workgroup (round 5's form) -- A/B runs (tools/wgrad_traffic.py) */
-void lf_debug_set_wgrad_pair(int v);
 /* lf_conv1d_bwd_weight with the BN+ReLU operand prologue on x (the weight gradient of a non_bottleneck_1d block's third convolution):
  * gw = d/dw of conv1d(relu(x * sc + sh)), gb = column sums of gy */
 int lf_debug_conv1d_wgrad_pro(const float* x, const float* gy, const float* sc, const float* sh, float* gw, float* gb, int N, int H, int W,

@@ -102,7 +102,6 @@ void lf_debug_set_bf16_lds(int v) { lf_tapgemm_set_bf16_lds(v); }
 void lf_debug_set_ops_precision(int mode) { g_ops_bf16 = (mode == 2 || mode == 9) ? mode : 0; }
 
 void lf_debug_set_wgrad_ro(int mode, int cap64, int cap128) { lf_tapwgrad_ro_set(mode, cap64, cap128); }
-void lf_debug_set_wgrad_pair(int v) { lf_tapwgrad_set_pair(v); }
 
 // same as lf_conv1d_fwd with per-wave phase timestamps: dbg receives 8 uint64 per wave
 // (start, tap table built, main loop done, stores retired); waves = ceil(N*H*W/256)*4*(C/64)

@@ -46,16 +46,7 @@ def main():
             _lib.check(lib.lf_conv1d_bwd_weight(P(xs[k]), P(gs[k]), P(gw), P(gb), N, H, W, C, axis, d, P(scratch), st), "wgrad")
 
         out = {}
-        # (round 6) pair = the 8-wave workgroups running the two jobs that share an X stream side by side (128 output channels only)
-        res = {}
-        for pair in (0, 1):
-            lib.lf_debug_set_wgrad_pair(pair)
-            run(0)
-            torch.cuda.synchronize()
-            res[pair] = (gw.clone(), gb.clone())
-        same = torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-        for name, pick, pair in (("warm", lambda i: 0, 0), ("cold", lambda i: i % npairs, 0), ("warm, paired jobs", lambda i: 0, 1), ("cold, paired jobs", lambda i: i % npairs, 1)):
-            lib.lf_debug_set_wgrad_pair(pair)
+        for name, pick in (("warm", lambda i: 0), ("cold", lambda i: i % npairs)):
             for i in range(20):
                 run(pick(i))
             torch.cuda.synchronize()
@@ -66,10 +57,11 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             out[name] = e0.elapsed_time(e1) / a.iters * 1e3
-        lib.lf_debug_set_wgrad_pair(1)
         flops = 2.0 * N * H * W * C * C * 3
-        print("fp32 wgrad C=%3d %3dx%3d axis %d dil %2d: %2d jobs per pixel range (%d x the tensors = %4.0f MB requested of %3.0f MB) | " % (C, H, W, axis, d, jobs, reread, reread * mb, mb)
-              + " | ".join("%s %6.1f us (%5.1f TF/s)" % (k, v, flops / v / 1e6) for k, v in out.items()) + " | paired == one-job results: %s" % same, flush=True)
+        print("fp32 wgrad C=%3d %3dx%3d axis %d dil %2d: %2d jobs per pixel range (%d x the tensors = %4.0f MB requested of %3.0f MB) | "
+              "warm %6.1f us (%5.1f TF/s, %4.2f TB/s of requests) | cold %6.1f us (%5.1f TF/s, %4.2f TB/s of requests)"
+              % (C, H, W, axis, d, jobs, reread, reread * mb, mb, out["warm"], flops / out["warm"] / 1e6, reread * mb / out["warm"],
+                 out["cold"], flops / out["cold"] / 1e6, reread * mb / out["cold"]), flush=True)
 
 
 if __name__ == "__main__":
