@@ -227,6 +227,20 @@ def cpu_baseline_and_parity(precision):
     e64 = e2e_oracle.bev_step(x4, Pe, gt4, torch.float64, R, training=False)
     teb = e2e_oracle.triple(ebeta, e32["beta"], e64["beta"])
     teg = e2e_oracle.triple(eout.detach().cpu().numpy(), e32["logits"], e64["logits"])
+    # the same batch once more in precision mode fp32x9 (fp32 tensors and accumulation, exact products from 3-way bf16 splits): the
+    # accuracy statement behind the fp32_split_x9 throughput figure of the line
+    x9 = None
+    if precision == "fp32":
+        model.net.precision = "fp32x9"
+        q0, q1, _, _, _, _, qout, _, _ = model(x4.cuda(), True)
+        qbeta = torch.stack([q0, q1], 1)[..., 0].detach().double().cpu().numpy()
+        tq = e2e_oracle.triple(qbeta, o32["beta"], o64["beta"])
+        tqg = e2e_oracle.triple(qout.detach().cpu().numpy(), o32["logits"], o64["logits"])
+        x9 = {"lane_coeff_max_rel_err": dict(zip(keys, (float("%.3e" % v) for v in tq))),
+              "logits_max_rel_err": dict(zip(keys, (float("%.3e" % v) for v in tqg))),
+              "hip_over_cpu32_distance_to_fp64": {"lane_coeff": round(tq[0] / max(tq[2], 1e-30), 3), "logits_max": round(tqg[0] / max(tqg[2], 1e-30), 3)},
+              "note": "train mode, the parity batch; six-seed distribution: tests/test_baseline_configs_gpu.py::test_bev_distance_ratio_over_seeds"}
+        model.net.precision = precision
     bf16 = precision == "bf16"
     fit_err = e2e_oracle.relerr(beta, c["beta"])
     fit_ok = bool(fit_err <= 1e-5)
@@ -256,6 +270,8 @@ def cpu_baseline_and_parity(precision):
               # train-mode figures above are reported only, so `ok` is null (not true): read fit_ok / eval_ok
               "ok": (fit_ok and eval_ok and train_ok) if not bf16 else None,
               "failed": not (fit_ok and eval_ok and train_ok is not False)}
+    if x9 is not None:
+        parity["fp32x9"] = x9
     return base, parity
 
 

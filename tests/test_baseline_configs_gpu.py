@@ -195,7 +195,10 @@ def test_bev_distance_ratio_over_seeds():
     from lanedetection_end2end_amd.bev.Loss_crit import Area_Loss
     from lanedetection_end2end_amd.bev.Networks.LSQ_layer import Net
     N, R = 8, 256
-    ratios = {"beta": [], "beta_rms": [], "logits": [], "dlogits": []}
+    # (round 6: precision mode fp32x9 -- fp32 tensors and accumulation, exact products from 3-way bf16 splits, ONE chain per output
+    # element in the split kernel -- through the same seeds and CPU legs: the accuracy statement behind bench.py's fp32_split_x9 figure)
+    modes = ("fp32", "fp32x9")
+    ratios = {m: {"beta": [], "beta_rms": [], "logits": [], "dlogits": []} for m in modes}
     model = None
     for seed in range(6):
         P = erfnet_oracle.make_params(seed=40 + seed, out_channels=2)
@@ -209,22 +212,32 @@ def test_bev_distance_ratio_over_seeds():
             model.net.load_state_dict(P)
         crit = Area_Loss(2, "none")
         gtc = torch.from_numpy(gt).cuda()
-        model.zero_grad(set_to_none=True)
-        b0, b1, _, _, _, _, output, _, _ = model(x.cuda(), True)
-        output.retain_grad()
-        (crit(b0, gtc[:, 0]) + crit(b1, gtc[:, 1])).backward()
-        beta = torch.stack([b0, b1], 1)[..., 0].detach().cpu().numpy()
         rms = lambda a, b: float(np.sqrt(np.mean((np.asarray(a, dtype=np.float64) - b) ** 2)))
-        ratios["beta"].append(np.abs(beta - o64["beta"]).max() / max(np.abs(o32["beta"] - o64["beta"]).max(), 1e-30))
-        ratios["beta_rms"].append(rms(beta, o64["beta"]) / max(rms(o32["beta"], o64["beta"]), 1e-30))     # over all 48 coefficients
-        ratios["logits"].append(rms(output.detach().cpu().numpy(), o64["logits"]) / rms(o32["logits"], o64["logits"]))
-        ratios["dlogits"].append(rms(output.grad.cpu().numpy(), o64["dlogits"]) / rms(o32["dlogits"], o64["dlogits"]))
-    for k, v in ratios.items():
-        v = np.array(v)
-        print("|hip - cpu64| / |cpu32 - cpu64|  %-8s  per seed %s   median %.2f  max %.2f" % (k, np.round(v, 2), np.median(v), v.max()))
-    for k, v in ratios.items():
+        for mode in modes:
+            model.net.precision = mode
+            model.zero_grad(set_to_none=True)
+            b0, b1, _, _, _, _, output, _, _ = model(x.cuda(), True)
+            output.retain_grad()
+            (crit(b0, gtc[:, 0]) + crit(b1, gtc[:, 1])).backward()
+            beta = torch.stack([b0, b1], 1)[..., 0].detach().cpu().numpy()
+            r = ratios[mode]
+            r["beta"].append(np.abs(beta - o64["beta"]).max() / max(np.abs(o32["beta"] - o64["beta"]).max(), 1e-30))
+            r["beta_rms"].append(rms(beta, o64["beta"]) / max(rms(o32["beta"], o64["beta"]), 1e-30))     # over all 48 coefficients
+            r["logits"].append(rms(output.detach().cpu().numpy(), o64["logits"]) / rms(o32["logits"], o64["logits"]))
+            r["dlogits"].append(rms(output.grad.cpu().numpy(), o64["dlogits"]) / rms(o32["dlogits"], o64["dlogits"]))
+        model.net.precision = "fp32"
+    for mode in modes:
+        for k, v in ratios[mode].items():
+            v = np.array(v)
+            print("[%-6s] |hip - cpu64| / |cpu32 - cpu64|  %-8s  per seed %s   median %.2f  max %.2f" % (mode, k, np.round(v, 2), np.median(v), v.max()))
+    for k, v in ratios["fp32"].items():
         lim = (1.3, 2.0) if k.startswith("beta") else (1.0, 1.1)
         assert np.median(v) <= lim[0] and max(v) <= lim[1], (k, v)
+    # fp32x9 keeps ONE fp32 chain over the whole contraction in the 64- / 128-channel launches it takes (round 3's fp32 kernel did the same
+    # and sat at 1.21-1.35): held to the reference arithmetic's own distance from fp64 times 1.5 (RMS) / the maximum-norm band
+    for k, v in ratios["fp32x9"].items():
+        lim = (1.6, 2.5) if k.startswith("beta") else (1.4, 1.5)
+        assert np.median(v) <= lim[0] and max(v) <= lim[1], ("fp32x9", k, v)
 
 
 def test_c3_bp_4x320x640():
