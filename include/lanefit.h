@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 4
+#define LF_ABI_VERSION 5      /* 5 (round 6): lf_erfnet_workspace_bytes_for added; lf_erfnet_set_precision refuses the removed modes 1 and 4;
+                                 lf_erfnet_forward_range / _backward_range take precision mode 2 */
 
 /* activation applied to the backbone logits: BEV/Networks/LSQ_layer.py:43-63 */
 enum { LF_ACT_SQUARE = 0, LF_ACT_ABS = 1, LF_ACT_RELU = 2, LF_ACT_SIGMOID = 3,
@@ -151,7 +152,7 @@ void lf_erfnet_plan_destroy(lf_erfnet_plan* plan);
  *     convolutions and data gradients formed from exact 3-way bf16 splits of both fp32 operands (all 9 partial products, i.e.
  *     exact products); parity as mode 0 (tests/test_backbone_gpu.py); launches the split kernel cannot take (other channel
  *     counts, pixel counts not a multiple of 512) and the weight gradient run on the fp32 matrix cores.
- * (Modes 1 and 4 -- bf16 operands with fp32 tensors, and the 6-term split -- existed until ABI 4; no BASELINE configuration
+ * (Modes 1 and 4 -- bf16 operands with fp32 tensors, and the 6-term split -- existed through ABI 4; no BASELINE configuration
  * used them and they were removed in round 6: the call returns an error for them.) */
 int lf_erfnet_set_precision(const lf_erfnet_plan* plan, int mode);
 size_t lf_erfnet_workspace_bytes(const lf_erfnet_plan* plan);   /* follows the precision mode (bf16 tensors: larger partial-row regions): query it after lf_erfnet_set_precision */

@@ -2427,6 +2427,15 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
             }
         } else if (nt == 4 && a.s16 && pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) {
             hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 1, LF_EPI_RELU, false>), grid, dim3(256), 0, st, g, a, pro, epi);
+        } else if (nt == 1 && a.s16 && pro != LF_PRO_BNRELU && ((g.Cs + 31) / 32 * 32 + g.s_choff <= g.s_pix) && (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB &&
+                   (epis == 0 || epis == LF_EPI_STATS_SQ || epis == LF_EPI_ADD)) {
+            // 16 output channels from whole 32-channel steps (round 6: the sub-pixel phases of UpsamplerBlock(64, 16) and the data gradient
+            // of DownsamplerBlock(16, 64)'s convolution: 8 launches per step on the run-time-flag form before): padding as out-of-range
+            // offsets, compiled-in epilogue.  A partial last step (48 source channels) reads the pixel's next channels -- they exist:
+            // the condition above -- against zero-padded weights
+            if (epis == 0) hipLaunchKernelGGL((tapgemm_bf16_kernel<1, 0, 0, true>), grid, dim3(256), 0, st, g, a, pro, epi);
+            else if (epis == LF_EPI_STATS_SQ) hipLaunchKernelGGL((tapgemm_bf16_kernel<1, 0, LF_EPI_STATS_SQ, true>), grid, dim3(256), 0, st, g, a, pro, epi);
+            else hipLaunchKernelGGL((tapgemm_bf16_kernel<1, 0, LF_EPI_ADD, true>), grid, dim3(256), 0, st, g, a, pro, epi);
         } else
         switch (nt) {
             case 4: LF_TG16(4); break;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 20
     for s in syms:
         assert hasattr(lib, s), "liblanefit_hip.so does not export " + s
-    assert lib.lf_abi_version() == 4
+    assert lib.lf_abi_version() == 5
     declared = set(_lib.exported_symbols())
     assert set(syms) <= declared | {"lf_erfnet_plan"}, sorted(set(syms) - declared)
 
