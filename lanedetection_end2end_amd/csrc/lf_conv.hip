@@ -2425,6 +2425,18 @@ int lf_tapgemm_launch(const LfTapGeom& g, const LfTapArgs& a, int pro, int epi, 
                 case LF_EPI_MASKBN | LF_EPI_STATS_XHAT: LF_TG16F(LF_EPI_MASKBN | LF_EPI_STATS_XHAT); break;
                 default: LF_TG16F(-1); break;
             }
+        } else if (nt == 4 && a.s16 && pro != LF_PRO_BNRELU && g.Cs == 16 && (epis == (LF_EPI_MASK | LF_EPI_STATS_XHAT) || epis == 0) &&
+                   (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB) {
+            // 16 source channels into a 64-channel slab (the data gradient of UpsamplerBlock(64, 16): 9 taps, stride 2, with the previous
+            // layer's mask + BN-backward sums; 204 us per launch at config 3 on the run-time-flag form): ONE 32-channel step per tap on the
+            // compiled-in form.  Lanes kq = 2, 3 read the 16 elements BEHIND the pixel's 16 channels -- the next pixel's (or, past the
+            // tensor's end, the buffer bound's zeros): finite values against the zero-padded half of the packed weights
+            if (epis == 0) LF_TG16F(0); else LF_TG16F(LF_EPI_MASK | LF_EPI_STATS_XHAT);
+        } else if (nt == 3 && a.s16 && pro != LF_PRO_BNRELU && g.Cs == 16 && (epis == LF_EPI_STATS_SQ || epis == 0) &&
+                   (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB) {
+            // ... and the 16 -> 48 channel convolution of DownsamplerBlock(16, 64) (9 taps, stride 2, BN forward sums; 112 us on the run-time-flag form)
+            if (epis == 0) hipLaunchKernelGGL((tapgemm_bf16_kernel<3, 0, 0, true>), grid, dim3(256), 0, st, g, a, pro, epi);
+            else hipLaunchKernelGGL((tapgemm_bf16_kernel<3, 0, LF_EPI_STATS_SQ, true>), grid, dim3(256), 0, st, g, a, pro, epi);
         } else if (nt == 4 && a.s16 && pro == LF_PRO_BNRELU && epi == LF_EPI_RELU) {
             hipLaunchKernelGGL((tapgemm_bf16_kernel<4, 1, LF_EPI_RELU, false>), grid, dim3(256), 0, st, g, a, pro, epi);
         } else if (nt == 1 && a.s16 && pro != LF_PRO_BNRELU && ((g.Cs + 31) / 32 * 32 + g.s_choff <= g.s_pix) && (long)g.N * g.Hs * g.Ws * g.s_pix * 2 < (long)LF_OOB &&
