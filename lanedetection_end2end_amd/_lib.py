@@ -141,14 +141,18 @@ def check(rc, what):
         raise LaneFitLibraryError("%s failed: %s" % (what, load().lf_last_error().decode()))
 
 
-def ptr(t):
-    """Device pointer of a contiguous CUDA(HIP) tensor, or None."""
+def ptr(t, rows=False):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or None.  rows=True: a 2-D tensor with contiguous ROWS is enough (the
+    entry point takes the row stride: beta_stride of the loss kernels)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise LaneFitLibraryError("lanefit ops need tensors on the MI355X (got a %s tensor); "
                                   "there is no CPU path" % t.device)
-    assert t.is_contiguous(), "internal: tensor must be contiguous"
+    if rows:
+        assert t.dim() == 2 and t.stride(1) == 1, "internal: tensor rows must be contiguous"
+    else:
+        assert t.is_contiguous(), "internal: tensor must be contiguous"
     return c_void_p(t.data_ptr())
 
 

@@ -57,6 +57,9 @@ class WLSFit(torch.autograd.Function):
         ctx.save_for_backward(logits, grid, beta, zinv)
         ctx.cfg = (gbs, zero_rows, order, float(y_offset), act_kind)
         ctx.status = status
+        # (no zero tensors for the outputs nobody differentiates: autograd otherwise fills an (N, K, H, W) fp32 gradient for `masked`
+        # every step -- 205 MB, 27 us at config 3)
+        ctx.set_materialize_grads(False)
         if want_masked:
             ctx.mark_non_differentiable(masked)
             return beta, masked, status
@@ -68,6 +71,8 @@ class WLSFit(torch.autograd.Function):
         logits, grid, beta, zinv = ctx.saved_tensors
         gbs, zero_rows, order, y_offset, act_kind = ctx.cfg
         N, K, H, W = logits.shape
+        if gbeta is None:          # the coefficients were not used downstream
+            return torch.zeros_like(logits), None, None, None, None, None, None, None, None, None
         gbeta = gbeta.to(torch.float64).contiguous()
         gl = torch.empty_like(logits)
         _lib.check(lib.lf_wls_bwd(_lib.ptr(logits), _lib.ptr(grid), gbs, N, K, H, W, zero_rows, order, y_offset,
@@ -81,12 +86,13 @@ class AreaLossFn(torch.autograd.Function):
     def forward(ctx, params, gt, order, weight_funct):
         lib = _lib.load()
         p = params.squeeze(-1) if params.dim() == 3 else params
-        p = p.contiguous()
+        if p.stride(1) != 1:       # (rows of one lane out of an (N, K, D) tensor go in as they are: the kernel takes the row stride)
+            p = p.contiguous()
         gt = gt.to(p.dtype).contiguous()
         assert p.dtype in (torch.float32, torch.float64) and p.shape == gt.shape and p.shape[1] == order + 1
         loss = torch.empty((), dtype=p.dtype, device=p.device)
-        grad = torch.empty_like(p)
-        _lib.check(lib.lf_area_loss(_lib.ptr(p), p.shape[1], _lib.ptr(gt), p.shape[0], order, weight_funct,
+        grad = torch.empty(p.shape, dtype=p.dtype, device=p.device)
+        _lib.check(lib.lf_area_loss(_lib.ptr(p, rows=True), p.stride(0), _lib.ptr(gt), p.shape[0], order, weight_funct,
                                     1 if p.dtype == torch.float64 else 0, _lib.ptr(loss), _lib.ptr(grad),
                                     _lib.stream()), "lf_area_loss")
         ctx.save_for_backward(grad)
@@ -127,7 +133,9 @@ class BackprojLossFn(torch.autograd.Function):
     def forward(ctx, params, x_gt, valid, Y, y_prime, minv):
         lib = _lib.load()
         p = params.squeeze(-1) if params.dim() == 3 else params
-        p = p.to(torch.float64).contiguous()
+        p = p.to(torch.float64)
+        if p.stride(1) != 1:       # (a lane's rows out of an (N, K, D) tensor go in as they are: beta_stride)
+            p = p.contiguous()
         x_gt = x_gt.to(torch.float64).contiguous()
         valid = valid.to(torch.float64).contiguous()
         N, D = p.shape
@@ -136,18 +144,21 @@ class BackprojLossFn(torch.autograd.Function):
         xcv = torch.empty(N, S, dtype=torch.float64, device=p.device)
         grad = torch.empty(N, D, dtype=torch.float64, device=p.device)
         m = (ctypes.c_double * 9)(*[float(v) for v in minv.reshape(-1)])
-        _lib.check(lib.lf_backproj_loss(_lib.ptr(p), D, _lib.ptr(x_gt), _lib.ptr(valid), _lib.ptr(Y),
+        _lib.check(lib.lf_backproj_loss(_lib.ptr(p, rows=True), p.stride(0), _lib.ptr(x_gt), _lib.ptr(valid), _lib.ptr(Y),
                                         _lib.ptr(y_prime), ctypes.cast(m, ctypes.c_void_p), N, S, D - 1,
                                         _lib.ptr(loss), _lib.ptr(xcv), _lib.ptr(grad), _lib.stream()),
                    "lf_backproj_loss")
         ctx.save_for_backward(grad)
         ctx.pshape, ctx.pdtype = params.shape, params.dtype
         ctx.mark_non_differentiable(xcv)
+        ctx.set_materialize_grads(False)       # (no zero-filled (N, S) gradient for xcv on every call)
         return loss, xcv
 
     @staticmethod
     def backward(ctx, gout, _gx):
         (grad,) = ctx.saved_tensors
+        if gout is None:
+            return torch.zeros(ctx.pshape, dtype=ctx.pdtype, device=grad.device), None, None, None, None, None
         return (grad * gout).view(ctx.pshape).to(ctx.pdtype), None, None, None, None, None
 
 
