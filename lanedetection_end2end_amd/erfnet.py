@@ -504,10 +504,10 @@ class Net(nn.Module):
             for p, off, ch in zip(ps, plan.drop_off, plan.drop_ch):
                 pvec[off: off + N * ch] = p
             pvec = pvec.to(device)
-            plan._drop_cache = cache = (ps, pvec, 1.0 / (1.0 - pvec))
-        _, pvec, scale = cache
+            plan._drop_cache = cache = (ps, pvec, 1.0 / (1.0 - pvec), torch.zeros((), dtype=torch.float32, device=device))
+        _, pvec, scale, zero = cache
         u = torch.rand(plan.drop_floats, dtype=torch.float32, device=device)
-        return (u >= pvec).to(torch.float32).mul_(scale)
+        return torch.where(u >= pvec, scale, zero)      # (three launches per step, not five; p = 1 gives 0, not 0 * inf)
 
     # ---- forward -----------------------------------------------------------------------
     def forward(self, input, flag, only_encode=False):
