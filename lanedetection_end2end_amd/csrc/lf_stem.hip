@@ -76,15 +76,25 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             const bool in = valid && tap[s] && (oh > 0 || tkh[s] > 0) && (ow > 0 || tkw[s] > 0);    // (the far edges never pad: H, W even)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], ldf(ri, in ? (unsigned)(base + toff[s]) * 4u : OOB), acc, 0, 0, 0);
         }
+        // pooled channels (round 6): lane (pixel pl, kq < CIN) takes the 2x2 maximum of input channel kq -- FOUR load instructions per
+        // tile; the lanes kq = 3, which store the pooled channels 16 - CIN .. 15, fetch them with CIN lane permutes.  (Every lane used to
+        // issue the 16 loads of its four output channels, 13 of them out-of-range dummies for most lanes: the kernel was bound by
+        // the address path, 23 load instructions per 16 pixels.)
+        float pm;
+        {
+            const bool pool = valid && kq < CIN;
+            const unsigned o = (unsigned)(base + kq * H * W) * 4u;
+            const float v0 = ldf(ri, pool ? o : OOB), v1 = ldf(ri, pool ? o + 4u : OOB), v2 = ldf(ri, pool ? o + (unsigned)W * 4u : OOB),
+                        v3 = ldf(ri, pool ? o + (unsigned)W * 4u + 4u : OOB);
+            pm = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+        }
         f32x4 out;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int co = 4 * kq + e;
-            const bool pool = valid && co >= Cc;
-            const unsigned o = (unsigned)(base + (co - Cc) * H * W) * 4u;
-            const float v0 = ldf(ri, pool ? o : OOB), v1 = ldf(ri, pool ? o + 4u : OOB), v2 = ldf(ri, pool ? o + (unsigned)W * 4u : OOB),
-                        v3 = ldf(ri, pool ? o + (unsigned)W * 4u + 4u : OOB);
-            out[e] = co < Cc ? acc[e] + bv[e] : fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+            float pooled = 0.f;
+            if (e >= 4 - CIN) pooled = __shfl(pm, (e - (4 - CIN)) * 16 + pl, 64);      // (compile-time e: CIN permutes, every lane takes part)
+            out[e] = co < Cc ? acc[e] + bv[e] : pooled;
         }
         if (valid) lf_stv(cat + (size_t)p * 16 + 4 * kq, out);
         if (!valid) out = zero4();

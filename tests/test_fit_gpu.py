@@ -195,6 +195,41 @@ def test_backproj_loss(lf, golden_fit, order):
     assert float(L0) == 0.0
 
 
+def test_losses_take_a_lane_of_a_coefficient_tensor_by_stride(lf, golden_fit):
+    """Round 6: the loss kernels read a lane's (N, D) coefficient rows out of the fit's (N, K, D) tensor through `beta_stride` instead of
+    a copy, and `split_lanes` is one unbind (its backward one stack).  Same loss and gradient, bit for bit, as on contiguous copies
+    (reference call pattern: BEV main.py:217-218, BP main.py:297-300 -- one loss call per lane on `beta0 .. beta3`)."""
+    from argparse import Namespace
+    from lanedetection_end2end_amd import fit
+    order = 2
+    g = torch.Generator().manual_seed(3)
+    beta = (torch.randn(6, 4, order + 1, dtype=torch.float64, generator=g) * 0.1).cuda().requires_grad_(True)
+    # Area_Loss (fp32 betas as the BEV tree hands them over), lanes 0 and 1
+    gt = torch.rand(6, 2, order + 1, generator=g).cuda()
+    crit = lf.losses.Area_Loss(order, "none")
+    lanes_ = fit.split_lanes(beta, 4, torch.float32)
+    assert not lanes_[1].squeeze(-1).is_contiguous()                       # really the strided path
+    L = crit(lanes_[0], gt[:, 0]) + crit(lanes_[1], gt[:, 1])
+    L.backward()
+    b2 = beta.detach().clone().requires_grad_(True)
+    L2 = sum(crit(b2[:, k].float().contiguous().unsqueeze(2), gt[:, k].contiguous()) for k in range(2))
+    L2.backward()
+    assert float(L) == float(L2) and torch.equal(beta.grad, b2.grad)
+    assert float(beta.grad[:, 2:].abs().max()) == 0.0                        # unused lanes: zero rows from the one stack
+    # backprojection_loss (fp64 betas), all four lanes
+    critb = lf.losses.backprojection_loss(Namespace(resize=256, no_mapping=False, order=order, batch_size=6, no_cuda=False))
+    lanes, valid = inputs.bp_targets(6, 4, 256, seed=32)
+    lanes, valid = dev(lanes), dev(valid)
+    beta.grad = None
+    outs = fit.split_lanes(beta, 4, torch.float64)
+    Lb = sum(critb(outs[k], lanes[:, k], valid[:, k])[0] for k in range(4)) / 4
+    Lb.backward()
+    b3 = beta.detach().clone().requires_grad_(True)
+    Lc = sum(critb(b3[:, k].contiguous().unsqueeze(2), lanes[:, k], valid[:, k])[0] for k in range(4)) / 4
+    Lc.backward()
+    assert float(Lb) == float(Lc) and torch.equal(beta.grad, b3.grad) and float(beta.grad.abs().max()) > 0.0
+
+
 def test_cross_entropy(lf, golden_fit):
     tgt = inputs.seg_targets(2, 8, 16, 3, seed=41)
     z = dev(golden_fit["ce_logits"]).requires_grad_(True)
